@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *imported reference* and records what it did.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference \
+        python3 /root/repo/tests/golden/make_golden.py --out /root/repo/tests/golden
+
+What is recorded (data only -- inputs and expected outputs, no reference text):
+
+* the random stream the reference consumed, per single-spin update:
+  ``site`` (torch.randint(0, N, (1,)), spin_dynamics.py:69) and ``u``
+  (torch.rand(1), drawn only when dE > 0, spin_dynamics.py:145-146; NaN if not drawn);
+* the decision and dE it returned (spin_dynamics.py:131-152);
+* per-sweep energies (spin_dynamics.py:87), histories and the AnnealingResult fields of
+  GPUAnnealer.anneal (gpu_annealer.py:96-183) and ParallelTempering.run
+  (parallel_tempering.py:82-144), and the PT exchange log (parallel_tempering.py:214-258).
+
+The reference is run in its only working mode here: IsingModelConfig(use_sparse=False),
+ParallelTempering n_threads=1.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+assert not any(p.rstrip("/") == "/root/repo" for p in sys.path if p), "run from /tmp, not the repo"
+
+from spin_glass_rl.core.ising_model import IsingModel, IsingModelConfig  # noqa: E402
+from spin_glass_rl.core.spin_dynamics import SpinDynamics, UpdateRule  # noqa: E402
+from spin_glass_rl.annealing.gpu_annealer import GPUAnnealer, GPUAnnealerConfig  # noqa: E402
+from spin_glass_rl.annealing.parallel_tempering import (  # noqa: E402
+    ParallelTempering, ParallelTemperingConfig)
+from spin_glass_rl.annealing.temperature_scheduler import (  # noqa: E402
+    TemperatureScheduler, ScheduleType)
+from spin_glass_rl.annealing.cuda_kernels import CUDAKernelManager  # noqa: E402
+
+
+# --------------------------------------------------------------------------- recording
+class Recorder:
+    """Wraps the RNG entry points the hot path uses and logs every draw."""
+
+    def __init__(self):
+        self.sites, self.us, self.acc, self.dE = [], [], [], []
+        self._pending_u = None
+        self.np_log = []  # ("randint", v) / ("rand", v)
+        self._orig = {}
+
+    def __enter__(self):
+        self._orig["randint"] = torch.randint
+        self._orig["rand"] = torch.rand
+        self._orig["np_randint"] = np.random.randint
+        self._orig["np_rand"] = np.random.rand
+        self._orig["metro"] = SpinDynamics._metropolis_update
+        rec = self
+
+        def randint(*a, **k):
+            out = rec._orig["randint"](*a, **k)
+            if tuple(out.shape) == (1,) and "generator" not in k:
+                rec.sites.append(int(out.item()))
+            return out
+
+        def rand(*a, **k):
+            out = rec._orig["rand"](*a, **k)
+            if tuple(out.shape) == (1,):
+                rec._pending_u = float(out.item())
+            return out
+
+        def np_randint(*a, **k):
+            v = rec._orig["np_randint"](*a, **k)
+            rec.np_log.append(("randint", float(v)))
+            return v
+
+        def np_rand(*a, **k):
+            v = rec._orig["np_rand"](*a, **k)
+            rec.np_log.append(("rand", float(v)))
+            return v
+
+        def metro(self_dyn, site):
+            rec._pending_u = None
+            accepted, d = rec._orig["metro"](self_dyn, site)
+            rec.us.append(np.nan if rec._pending_u is None else rec._pending_u)
+            rec.acc.append(bool(accepted))
+            rec.dE.append(float(d))
+            return accepted, d
+
+        torch.randint = randint
+        torch.rand = rand
+        np.random.randint = np_randint
+        np.random.rand = np_rand
+        SpinDynamics._metropolis_update = metro
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint = self._orig["randint"]
+        torch.rand = self._orig["rand"]
+        np.random.randint = self._orig["np_randint"]
+        np.random.rand = self._orig["np_rand"]
+        SpinDynamics._metropolis_update = self._orig["metro"]
+
+    def stream(self):
+        assert len(self.sites) == len(self.us) == len(self.acc)
+        return dict(site=np.asarray(self.sites, np.int32), u=np.asarray(self.us, np.float32),
+                    accepted=np.asarray(self.acc, np.bool_), dE=np.asarray(self.dE, np.float64))
+
+
+# --------------------------------------------------------------------------- instances
+def pm1_couplings(n, seed):
+    """SURVEY.md 8(c) recipe: symmetric +-1, zero diagonal."""
+    g = torch.Generator().manual_seed(seed)
+    J = (torch.randint(0, 2, (n, n), generator=g) * 2 - 1).float()
+    J = torch.triu(J, 1)
+    return J + J.T
+
+
+def gaussian_couplings(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    J = torch.randn(n, n, generator=g)
+    J = torch.triu(J, 1)
+    return J + J.T
+
+
+def dense_model(J, h=None):
+    n = J.shape[0]
+    m = IsingModel(IsingModelConfig(n_spins=n, use_sparse=False))
+    m.set_couplings_from_matrix(J)
+    if h is not None:
+        m.set_external_fields(h)
+    return m
+
+
+def i8(t):
+    return t.detach().cpu().numpy().astype(np.int8)
+
+
+# --------------------------------------------------------------------------- cases
+def case_sweeps(name, J, h, T, n_sweeps, seed, out):
+    """SpinDynamics.sweep() at fixed temperature (spin_dynamics.py:73-94)."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    m = dense_model(J, h)
+    s0 = i8(m.spins)
+    e0 = m.compute_energy()
+    energies = []
+    with Recorder() as rec:
+        dyn = SpinDynamics(m, T, UpdateRule.METROPOLIS)  # binds the wrapped update
+        for _ in range(n_sweeps):
+            energies.append(dyn.sweep())
+    st = rec.stream()
+    np.savez_compressed(
+        os.path.join(out, name + ".npz"), kind="sweeps", J=J.numpy(),
+        h=m.external_fields.numpy(), s0=s0, e0=np.float64(e0), T=np.float64(T),
+        n_sweeps=np.int32(n_sweeps), sweep_energy=np.asarray(energies, np.float64),
+        s_final=i8(m.spins), n_accepted=np.int64(dyn.n_accepted),
+        n_rejected=np.int64(dyn.n_rejected), **st)
+    print(f"{name}: updates={len(st['site'])} E0={e0} E_end={energies[-1]} acc={dyn.n_accepted}")
+
+
+def case_sa(name, J, h, cfg_kwargs, model_seed, out):
+    """GPUAnnealer.anneal on the CPU path (gpu_annealer.py:96-183)."""
+    torch.manual_seed(model_seed)
+    m = dense_model(J, h)
+    s0 = i8(m.spins)
+    cfg = GPUAnnealerConfig(**cfg_kwargs)
+    ann = GPUAnnealer(cfg)  # seeds torch/numpy with cfg.random_seed (gpu_annealer.py:74-76)
+    with Recorder() as rec:
+        res = ann.anneal(m)
+    st = rec.stream()
+    n = J.shape[0]
+    assert len(st["site"]) == res.n_sweeps * n
+    # temperatures the reference used per executed sweep
+    sched = TemperatureScheduler.create_schedule(cfg.schedule_type, cfg.initial_temp,
+                                                 cfg.final_temp, cfg.n_sweeps,
+                                                 **cfg.schedule_params)
+    T = np.asarray([max(sched.get_temperature(s), 1e-10) for s in range(res.n_sweeps)])
+    np.savez_compressed(
+        os.path.join(out, name + ".npz"), kind="sa", J=J.numpy(), h=m.external_fields.numpy(),
+        s0=s0, n_sweeps_cfg=np.int32(cfg.n_sweeps), initial_temp=np.float64(cfg.initial_temp),
+        final_temp=np.float64(cfg.final_temp), schedule=cfg.schedule_type.value,
+        alpha=np.float64(cfg.schedule_params.get("alpha", 0.95)),
+        record_interval=np.int32(cfg.record_interval),
+        energy_tolerance=np.float64(cfg.energy_tolerance),
+        random_seed=np.int64(-1 if cfg.random_seed is None else cfg.random_seed),
+        T_per_sweep=T, n_sweeps=np.int32(res.n_sweeps), best_energy=np.float64(res.best_energy),
+        best_configuration=i8(res.best_configuration),
+        energy_history=np.asarray(res.energy_history, np.float64),
+        temperature_history=np.asarray(res.temperature_history, np.float64),
+        acceptance_rate_history=np.asarray(res.acceptance_rate_history, np.float64),
+        s_final=i8(m.spins), **st)
+    print(f"{name}: n_sweeps={res.n_sweeps} best={res.best_energy} hist={len(res.energy_history)}")
+
+
+def case_pt(name, J, h, cfg_kwargs, out):
+    """ParallelTempering.run, n_threads=1 (parallel_tempering.py:82-144)."""
+    cfg = ParallelTemperingConfig(n_threads=1, **cfg_kwargs)
+    pt = ParallelTempering(cfg)  # seeds (parallel_tempering.py:52-54)
+    m = dense_model(J, h)
+    snap = {}
+    orig_init = ParallelTempering._initialize_replicas
+    orig_exch = ParallelTempering._attempt_single_exchange
+    exch_log = []
+
+    def init(self, model, rule):
+        orig_init(self, model, rule)
+        snap["s0"] = np.stack([i8(r.spins) for r in self.replicas])
+
+    def exch(self, i, j):
+        ei, ej = self.replicas[i].compute_energy(), self.replicas[j].compute_energy()
+        before = self.exchange_accepts[min(i, j)]
+        orig_exch(self, i, j)
+        exch_log.append((i, j, ei, ej, int(self.exchange_accepts[min(i, j)] - before)))
+
+    ParallelTempering._initialize_replicas = init
+    ParallelTempering._attempt_single_exchange = exch
+    try:
+        with Recorder() as rec:
+            res = pt.run(m)
+    finally:
+        ParallelTempering._initialize_replicas = orig_init
+        ParallelTempering._attempt_single_exchange = orig_exch
+    st = rec.stream()
+    R, n = cfg.n_replicas, J.shape[0]
+    assert len(st["site"]) == cfg.n_sweeps * R * n
+    # np.random log: one randint per exchange round, one rand per attempted pair
+    starts = np.asarray([v for k, v in rec.np_log if k == "randint"], np.int32)
+    us = np.asarray([v for k, v in rec.np_log if k == "rand"], np.float64)
+    assert len(us) == len(exch_log)
+    ex = np.asarray(exch_log, np.float64).reshape(-1, 5)
+    np.savez_compressed(
+        os.path.join(out, name + ".npz"), kind="pt", J=J.numpy(), h=m.external_fields.numpy(),
+        s0=snap["s0"], n_replicas=np.int32(R), n_sweeps=np.int32(cfg.n_sweeps),
+        temp_min=np.float64(cfg.temp_min), temp_max=np.float64(cfg.temp_max),
+        temp_distribution=cfg.temp_distribution, exchange_interval=np.int32(cfg.exchange_interval),
+        record_interval=np.int32(cfg.record_interval), random_seed=np.int64(cfg.random_seed),
+        temperatures=np.asarray(pt.temperatures, np.float64),
+        # stream order: sweep-major, then replica (ladder slot), then update
+        site=st["site"].astype(np.uint8 if n <= 256 else np.int32), u=st["u"],
+        accepted=st["accepted"],
+        exch_start=starts, exch_i=ex[:, 0].astype(np.int32), exch_j=ex[:, 1].astype(np.int32),
+        exch_Ei=ex[:, 2], exch_Ej=ex[:, 3], exch_accepted=ex[:, 4].astype(np.bool_), exch_u=us,
+        exchange_attempts=pt.exchange_attempts, exchange_accepts=pt.exchange_accepts,
+        energy_histories=np.asarray(pt.energy_histories, np.float64),
+        best_energy=np.float64(res.best_energy), best_configuration=i8(res.best_configuration),
+        acceptance_rates=np.asarray(res.acceptance_rate_history, np.float64),
+        s_final=np.stack([i8(r.spins) for r in pt.replicas]))
+    print(f"{name}: best={res.best_energy} accepts={pt.exchange_accepts.tolist()} "
+          f"attempts={pt.exchange_attempts.tolist()} hist0={pt.energy_histories[0][:4]}")
+
+
+def case_operator(name, J, h, T, seed, out):
+    """CUDAKernelManager fallbacks = what the operator API really computes
+    (cuda_kernels.py:371-443): sequential-order sweep, energy, PT exchange."""
+    n = J.shape[0]
+    torch.manual_seed(seed)
+    mgr = CUDAKernelManager(torch.device("cpu"))
+    s0 = (torch.randint(0, 2, (n,)) * 2 - 1).float()
+    us = []
+    orig_rand = torch.rand
+
+    def rand(*a, **k):
+        out_ = orig_rand(*a, **k)
+        if tuple(out_.shape) == (1,):
+            us.append(float(out_.item()))
+        return out_
+
+    spins = s0.clone()
+    torch.rand = rand
+    try:
+        new_spins, accepted, dE = mgr.metropolis_update_optimized(spins, J, h, T, n_updates=2)
+    finally:
+        torch.rand = orig_rand
+    energy = mgr.compute_energy_optimized(new_spins, J, h)
+    # PT exchange operator on 6 replicas
+    R = 6
+    sp = (torch.randint(0, 2, (R, n)) * 2 - 1).float()
+    en = torch.tensor([mgr.compute_energy_optimized(sp[r], J, h) for r in range(R)])
+    temps = torch.tensor([10.0 * (0.1 / 10.0) ** (i / (R - 1)) for i in range(R)])
+    sp_in, en_in = sp.clone(), en.clone()
+    pus = []
+
+    def rand2(*a, **k):
+        out_ = orig_rand(*a, **k)
+        if tuple(out_.shape) == (1,):
+            pus.append(float(out_.item()))
+        return out_
+
+    torch.rand = rand2
+    try:
+        n_ex = mgr.parallel_tempering_exchange_optimized(sp, en, temps)
+    finally:
+        torch.rand = orig_rand
+    np.savez_compressed(
+        os.path.join(out, name + ".npz"), kind="operator", J=J.numpy(), h=h.numpy(), s0=i8(s0),
+        T=np.float64(T), n_updates=np.int32(2), u=np.asarray(us, np.float32),
+        s_out=i8(new_spins), accepted=np.int64(accepted), energy_changes=dE.numpy(),
+        energy=np.float64(energy), pt_spins_in=i8(sp_in), pt_energies_in=en_in.numpy(),
+        pt_temps=temps.numpy(), pt_u=np.asarray(pus, np.float32), pt_spins_out=i8(sp),
+        pt_energies_out=en.numpy(), pt_exchanges=np.int64(n_ex))
+    print(f"{name}: accepted={accepted} E={energy} pt_exchanges={n_ex} n_u={len(us)}")
+
+
+def case_schedules(out):
+    """TemperatureSchedule.get_temperature tables (temperature_scheduler.py:68-213)."""
+    d = {}
+    for st in (ScheduleType.LINEAR, ScheduleType.EXPONENTIAL, ScheduleType.GEOMETRIC,
+               ScheduleType.LOGARITHMIC, ScheduleType.POWER_LAW, ScheduleType.FAST,
+               ScheduleType.BOLTZMANN):
+        s = TemperatureScheduler.create_schedule(st, 10.0, 0.01, 1000)
+        d[st.value] = np.asarray([s.get_temperature(k) for k in range(0, 1200)], np.float64)
+    # adaptive: driven by a fixed synthetic acceptance sequence
+    s = TemperatureScheduler.create_schedule(ScheduleType.ADAPTIVE, 10.0, 0.01, 1000)
+    rng = np.random.RandomState(0)
+    accs = rng.rand(400)
+    d["adaptive_acc"] = accs
+    d["adaptive"] = np.asarray([s.update(k, acceptance_rate=float(accs[k])) for k in range(400)])
+    np.savez_compressed(os.path.join(out, "schedules.npz"), kind="schedules", **d)
+    print("schedules: ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(1)
+    want = lambda n: (not a.only) or a.only in n  # noqa: E731
+
+    z = lambda n: torch.zeros(n)  # noqa: E731
+    if want("sweeps_pm1_n8"):
+        case_sweeps("sweeps_pm1_n8", pm1_couplings(8, 1), z(8), 1.5, 40, 42, a.out)
+    if want("sweeps_pm1_n16"):
+        case_sweeps("sweeps_pm1_n16", pm1_couplings(16, 1), z(16), 2.0, 40, 42, a.out)
+    if want("sweeps_pm1_n64"):
+        case_sweeps("sweeps_pm1_n64", pm1_couplings(64, 1), z(64), 3.0, 60, 42, a.out)
+    if want("sweeps_pm1_n64_cold"):
+        case_sweeps("sweeps_pm1_n64_cold", pm1_couplings(64, 1), z(64), 0.4, 60, 7, a.out)
+    if want("sweeps_gauss_n64"):
+        case_sweeps("sweeps_gauss_n64", gaussian_couplings(64, 5), z(64), 1.0, 40, 42, a.out)
+    if want("sweeps_field_n64"):
+        g = torch.Generator().manual_seed(9)
+        h = (torch.randint(-2, 3, (64,), generator=g)).float()
+        case_sweeps("sweeps_field_n64", pm1_couplings(64, 1), h, 2.0, 40, 42, a.out)
+    if want("sweeps_pm1_n300"):
+        # N not a multiple of 4/64/256: ragged row tail for the kernels
+        case_sweeps("sweeps_pm1_n300", pm1_couplings(300, 3), z(300), 4.0, 8, 11, a.out)
+    if want("sa_default_n64"):
+        # defaults: geometric alpha=.95 floors at sweep 135, early stop at sweep 480
+        case_sa("sa_default_n64", pm1_couplings(64, 1), z(64), dict(random_seed=42), 123, a.out)
+    if want("sa_linear_n20"):
+        case_sa("sa_linear_n20", pm1_couplings(20, 4), z(20),
+                dict(n_sweeps=200, initial_temp=5.0, final_temp=0.05,
+                     schedule_type=ScheduleType.LINEAR, schedule_params={}, random_seed=3,
+                     record_interval=5), 5, a.out)
+    if want("pt_c1_n64_r8"):
+        # BASELINE.json configs[0]: 64-spin dense +-1, 8 replicas, 1000 sweeps
+        case_pt("pt_c1_n64_r8", pm1_couplings(64, 1), z(64),
+                dict(n_replicas=8, n_sweeps=1000, temp_min=0.1, temp_max=10.0,
+                     exchange_interval=10, record_interval=10, random_seed=42), a.out)
+    if want("pt_small_n16_r4"):
+        case_pt("pt_small_n16_r4", pm1_couplings(16, 2), z(16),
+                dict(n_replicas=4, n_sweeps=120, temp_min=0.5, temp_max=5.0,
+                     temp_distribution="linear", exchange_interval=3, record_interval=4,
+                     random_seed=7), a.out)
+    if want("operator_n48"):
+        g = torch.Generator().manual_seed(13)
+        h = torch.randint(-1, 2, (48,), generator=g).float()
+        case_operator("operator_n48", pm1_couplings(48, 6), h, 1.7, 21, a.out)
+    if want("schedules"):
+        case_schedules(a.out)
+
+
+if __name__ == "__main__":
+    main()
