@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the Ising spin-sweep hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): spin-flip attempts per second = replicas x spins x sweeps / wall time.
+Workload at N=1 (BASELINE configs[1], SURVEY.md 8(d) "C2a"): 10 000-spin dense +-1 SK instance
+(fp32 couplings, 400 MB), 1024 replicas on a geometric temperature ladder 10 -> 0.1, random
+sites with replacement (per-replica Philox streams).  One *step* = one Metropolis sweep of
+every replica (R x N single-spin updates); every `--exchange-interval` steps a replica
+exchange round runs (default 10, the reference's default).  With N > 1 GPUs every rank holds
+its own 1024 replicas of one global ladder (weak scaling, J replicated); the exchange step
+all-gathers the R_global energies over RCCL and every rank applies the same decisions.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the dense sweep):
+algorithmic bytes = attempts x N x sizeof(J element) (one coupling-row read per attempt,
+SURVEY.md 8(d)) divided by its HIP-event-timed launch duration.  `cpu_baseline` times the CPU
+oracle (oracle/, a C restatement of the reference's algorithm; OpenMP over replicas) on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def geometric_ladder(R, tmax=10.0, tmin=0.1):
+    # reference annealing/parallel_tempering.py:148-155, index 0 = hottest
+    ratio = tmin / tmax
+    return np.asarray([tmax * ratio ** (i / max(R - 1, 1)) for i in range(R)], np.float64)
+
+
+def make_sk_instance(n, seed, device):
+    """Dense symmetric +-1 couplings, zero diagonal (SURVEY.md 8(c) recipe), built on device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    J = (torch.randint(0, 2, (n, n), generator=g, device=device, dtype=torch.int8) * 2 - 1)
+    J = torch.triu(J, 1)
+    J = (J + J.T).to(torch.float32)
+    return J
+
+
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=4, sweeps=1):
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    R = max(cores * budget_replicas_per_core, 1)
+    prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
+    oracle.set_exact_f32(True)  # +-1 couplings: fp32 SIMD accumulation is exact
+    s = oracle.init_spins(n, R, seed)
+    e0 = np.zeros(R)
+    temps = geometric_ladder(R)
+    t0 = time.perf_counter()
+    oracle.sweeps(prob, s, temps, sweeps, seed=seed, energy=e0, n_threads=cores)
+    dt = time.perf_counter() - t0
+    oracle.set_exact_f32(False)
+    return {"value": R * n * sweeps / dt, "unit": "spin-flip attempts/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin dense instance, "
+                      f"OpenMP over replicas, fp32 SIMD row dot, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spins", type=int, default=10000)
+    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
+    ap.add_argument("--storage", default="f32", choices=["f32", "i8"])
+    ap.add_argument("--exchange-interval", type=int, default=10)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import spin_glass_anneal_rl_amd as sg
+    from spin_glass_anneal_rl_amd.sharded import ShardedTempering
+
+    n, R = a.spins, a.replicas
+    Rg = R * world
+    J = make_sk_instance(n, 2, dev)
+    h = torch.zeros(n, device=dev)
+    eng = sg.AnnealEngine(local_rank)
+    eng.use_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_tuning(waves_per_replica=a.waves, sweeps_per_launch=1)
+    eng.set_dense(J, h, storage=a.storage)
+    pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
+                          slot_temps=geometric_ladder(Rg), n_ladders=1,
+                          dist=dist, device=dev)
+    geometry = eng.describe()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_no = 0
+
+    def step():
+        nonlocal step_no
+        pt.sweep(1)
+        step_no += 1
+        if a.exchange_interval > 0 and step_no % a.exchange_interval == 0:
+            pt.exchange()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    eng.enable_timing(True)
+    eng.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = eng.kernel_time(reset=True)
+    eng.enable_timing(False)
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    attempts = float(Rg) * n * a.steps
+    value = attempts / dt
+    elem = 4 if a.storage == "f32" else 1
+    per_launch_attempts = float(R) * n  # one sweep per launch on this rank
+    avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = per_launch_attempts * n * elem / avg_launch_s / 1e9 if launches else 0.0
+    best_e, _, _ = eng.best(with_spins=False)
+
+    out = {
+        "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
+        "value": value,
+        "unit": "attempts/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if a.storage == "f32" else "i8",
+        "data": "synthetic",
+        "config": {"workload": f"C2a: {n}-spin dense +-1 SK Ising, {R} replicas/GPU, geometric "
+                               f"ladder T 10->0.1, random-site Metropolis sweeps, exchange "
+                               f"every {a.exchange_interval}",
+                   "spins": n, "replicas_per_gpu": R, "replicas_total": Rg,
+                   "coupling_storage": a.storage, "geometry": geometry,
+                   "best_energy_rank0": best_e},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "sweep_dense_kernel", "launches": launches,
+                     "avg_launch_ms": avg_launch_s * 1e3,
+                     "algorithmic_bytes_per_attempt": n * elem},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(J.cpu().numpy(), n, 42)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

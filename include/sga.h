@@ -1,0 +1,167 @@
+/*
+ * sga.h -- C ABI of the MI355X (gfx950) digital-annealing engine: the drop-in boundary for
+ * the reference's Ising spin-sweep hot path.  Plain C, opaque handle, int status returns,
+ * no torch types.  Shared library: spin-glass-anneal-rl_amd/csrc/libsga.so.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *
+ *   sga_set_dense / sga_set_csr   IsingModel.couplings / external_fields buffers handed to the
+ *                                 kernels: spin_glass_rl/annealing/cuda_kernels.py:228-236
+ *                                 (dense fp32 [n,n]); core/ising_model.py:69-84 (dense | COO)
+ *   sga_init_replicas             ParallelTempering._initialize_replicas,
+ *                                 annealing/parallel_tempering.py:175-189 (copy + reset_to_random)
+ *   sga_sweep                     CUDAKernelManager.metropolis_update_optimized,
+ *                                 annealing/cuda_kernels.py:228-282 (+ fallback :371-398) and
+ *                                 SpinDynamics.sweep, core/spin_dynamics.py:73-94, batched over
+ *                                 replicas (ParallelTempering._parallel_sweeps, :191-203)
+ *   sga_recompute_energies        CUDAKernelManager.compute_energy_optimized,
+ *                                 annealing/cuda_kernels.py:284-324 (+ fallback :400-413);
+ *                                 IsingModel.compute_energy, core/ising_model.py:149-174
+ *   sga_exchange                  CUDAKernelManager.parallel_tempering_exchange_optimized,
+ *                                 annealing/cuda_kernels.py:326-369 (+ fallback :415-443) and
+ *                                 ParallelTempering._nearest_neighbor_exchange /
+ *                                 _attempt_single_exchange, annealing/parallel_tempering.py:214-258
+ *   sga_get_best                  best tracking in GPUAnnealer.anneal, gpu_annealer.py:151-153,
+ *                                 and ParallelTempering._find_best_solution, :303-313
+ *   sga_get_stats                 SpinDynamics.n_accepted / n_rejected, spin_dynamics.py:44-45
+ *
+ * Pointers: every user buffer may be a host pointer or a device pointer on the engine's device
+ * (copies use hipMemcpyDefault); PyTorch-ROCm tensors are passed as tensor.data_ptr().  J / h
+ * are repacked into engine-owned HBM at set time, so the caller's tensors are not borrowed
+ * after the call returns.  Calls on one handle must be serialised by the caller; different
+ * handles are independent.  No call throws; on failure a negative code is returned and
+ * sga_last_error() (thread-local) describes it.
+ */
+#ifndef SGA_H
+#define SGA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sga_engine sga_engine;
+
+/* status codes */
+#define SGA_OK 0
+#define SGA_ERR_INVALID -1 /* bad argument / state  -> AnnealingError in the Python shim   */
+#define SGA_ERR_DEVICE -2  /* no / invalid GPU, HIP failure -> DeviceError                 */
+#define SGA_ERR_MEMORY -3  /* allocation failure                                           */
+#define SGA_ERR_UNSUPPORTED -4
+
+/* coupling storage in HBM */
+#define SGA_J_AUTO 0 /* int8 if every J is an integer in [-127,127], else fp32 */
+#define SGA_J_F32 1
+#define SGA_J_I8 2
+
+/* site order of a sweep */
+#define SGA_SITE_RANDOM 0     /* uniform with replacement, Philox4x32-10 (spin_dynamics.py:69) */
+#define SGA_SITE_SEQUENTIAL 1 /* i = 0..n-1 (cuda_kernels.py:381)                             */
+#define SGA_SITE_REPLAY 2     /* caller-supplied sites (parity tests)                         */
+
+/* arithmetic of the accept rule */
+#define SGA_ARITH_F64 0 /* spin_dynamics.py:131-152 (double dE, fp32 exp)                     */
+#define SGA_ARITH_F32 1 /* cuda_kernels.py:383-390 (fp32 throughout, minus J_ii s_i)          */
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int sga_create(int device, sga_engine **out);
+void sga_destroy(sga_engine *e);
+const char *sga_last_error(void);
+int sga_version(void);
+/* Run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * engine's own stream (default). */
+int sga_set_stream(sga_engine *e, void *hip_stream);
+
+/* ---- problem -------------------------------------------------------------------------- */
+/* Dense couplings J[n][ldJ] (fp32, row-major, symmetric as the reference stores them) and
+ * fields h[n]. */
+int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
+                  int storage);
+/* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]. */
+int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                const float *h, int n, int64_t nnz);
+
+/* ---- replicas ------------------------------------------------------------------------- */
+/* R_local replicas live on this engine; they are replicas [replica0, replica0+R_local) of a
+ * global set of R_global (R_global == R_local, replica0 == 0 on one GPU).  s0 == NULL draws
+ * the initial spins from the Philox stream (domain 2), else s0 is int8 +-1 [R_local][n].
+ * Energies are computed, best = initial, counters zeroed, sweep counter = 0. */
+int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
+                      const int8_t *s0);
+/* Temperature of each local replica (used when sga_sweep gets no schedule). */
+int sga_set_temperatures(sga_engine *e, const double *T /* [R_local] */);
+/* Temperature ladder(s) over the GLOBAL replica set: n_ladders ladders of R_global/n_ladders
+ * slots, slot_temps[R_global]; slot i initially holds replica i.  Sets local temperatures. */
+int sga_set_ladder(sga_engine *e, const double *slot_temps /* [R_global] */, int n_ladders);
+
+/* ---- hot path ------------------------------------------------------------------------- */
+/* n_sweeps Metropolis sweeps (n single-spin updates each) of every local replica.
+ *   sched: optional temperatures T(k, r) = sched[k*sched_sweep_stride + r*sched_replica_stride]
+ *          (k = sweep within this call, r = local replica); NULL = current temperatures.
+ *   replay_site [R_local][n_sweeps*n] int32, replay_u [R_local][n_sweeps*n] fp32: SITE_REPLAY
+ *          needs both; SITE_SEQUENTIAL takes replay_u if non-NULL (else Philox uniforms).
+ *   energy_trace: optional [n_sweeps][R_local] doubles, energy after each sweep.
+ *   accept_trace / dE_trace: optional [R_local][n_sweeps*n] per-update records (parity tests).
+ */
+int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const double *sched,
+              int64_t sched_sweep_stride, int64_t sched_replica_stride,
+              const int32_t *replay_site, const float *replay_u, double *energy_trace,
+              uint8_t *accept_trace, double *dE_trace);
+
+/* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s */
+int sga_recompute_energies(sga_engine *e);
+
+/* One nearest-neighbour replica-exchange round over the ladder(s)
+ * (parallel_tempering.py:214-258: even/odd pairs, accept min(1, exp((b_j-b_i)(E_j-E_i)))).
+ *   energies_global: [R_global] doubles indexed by GLOBAL replica id (after an all-gather);
+ *                    NULL = the engine's own energies (requires R_local == R_global).
+ *   start: [n_ladders] int32 0/1 parity per ladder, NULL = Philox (domain 1).
+ *   u: [n_ladders][slots/2] doubles in attempt order, NULL = Philox.
+ *   n_accepted: optional out (host int). */
+int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *start,
+                 const double *u, int *n_accepted);
+
+/* Stateless operator form of CUDAKernelManager.parallel_tempering_exchange_optimized
+ * (annealing/cuda_kernels.py:326-369, fallback :415-443): sequential adjacent pairs, fp32,
+ * p = exp((1/T[i+1] - 1/T[i]) * (E[i] - E[i+1])), accepted pairs swap spin rows and energies
+ * in place.  spins fp32 [R][n], energies fp32 [R], temps fp32 [R]; u fp32 [R-1] or NULL
+ * (Philox, domain 1).  Device or host pointers. */
+int sga_op_pt_exchange(int device, float *spins, float *energies, const float *temps,
+                       const float *u, uint64_t seed, uint32_t round, int R, int n,
+                       int *n_accepted);
+
+/* ---- state access --------------------------------------------------------------------- */
+int sga_get_energies(sga_engine *e, double *out /* [R_local] */);
+int sga_get_temperatures(sga_engine *e, double *out /* [R_local] */);
+int sga_get_spins(sga_engine *e, int r, int8_t *out /* [n]; r<0: all, [R_local][n] */);
+int sga_set_spins(sga_engine *e, int r, const int8_t *s /* recomputes that energy */);
+/* r >= 0: best (energy, spins) seen by local replica r at sweep ends; r < 0: the best over
+ * all local replicas; *r_out (optional) receives its local index. */
+int sga_get_best(sga_engine *e, int r, double *energy, int8_t *spins /* [n] or NULL */,
+                 int *r_out);
+/* Forget the bests: best = current state (ParallelTempering checks only on record sweeps). */
+int sga_reset_best(sga_engine *e);
+int sga_get_stats(sga_engine *e, int64_t *accepted /* [R_local] */,
+                  int64_t *attempted /* [R_local] */);
+int sga_get_slot_map(sga_engine *e, int32_t *slot_to_rep /* [R_global] */);
+int sga_get_exchange_stats(sga_engine *e, int64_t *attempts /* [R_global] */,
+                           int64_t *accepts /* [R_global] */);
+int sga_get_sweep_counter(sga_engine *e, uint32_t *sweeps_done, uint32_t *exchange_rounds);
+int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange_rounds);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* With timing enabled every sweep-kernel launch is bracketed by HIP events on the launch
+ * stream; sga_get_kernel_time returns the launches and their summed duration since the
+ * last reset (synchronises). */
+int sga_enable_timing(sga_engine *e, int on);
+int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, int reset);
+/* Describes the launch geometry chosen for the current problem (for DESIGN/bench output):
+ * writes a NUL-terminated string into buf. */
+int sga_describe(sga_engine *e, char *buf, int buflen);
+/* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
+int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGA_H */

@@ -53,12 +53,14 @@ def lib():
                                  C.c_int]
         L.sgo_sweeps.restype = C.c_int
         L.sgo_pt_exchange_round.argtypes = [C.c_int, p, p, p, C.c_int, p, C.c_uint64, C.c_uint32,
-                                            p, p]
+                                            C.c_uint32, p, p]
         L.sgo_pt_exchange_round.restype = C.c_int
         L.sgo_pt_exchange_operator.argtypes = [C.c_int, C.c_int, p, p, p, p]
         L.sgo_pt_exchange_operator.restype = C.c_int
         L.sgo_init_spins.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, p]
         L.sgo_init_spins.restype = None
+        L.sgo_set_exact_f32.argtypes = [C.c_int]
+        L.sgo_set_exact_f32.restype = None
         L.sgo_stream_site.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.sgo_stream_site.restype = C.c_uint32
         L.sgo_stream_u.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -95,6 +97,11 @@ class Problem:
     def args(self):
         return (self.n, _ptr(self.J), self.ld, _ptr(self.rowptr), _ptr(self.colidx),
                 _ptr(self.val), _ptr(self.h))
+
+
+def set_exact_f32(on):
+    """Allow fp32 SIMD accumulation (only valid for integer-valued J with exact row sums)."""
+    lib().sgo_set_exact_f32(1 if on else 0)
 
 
 def philox(ctr, key):
@@ -191,14 +198,14 @@ def sweeps(prob, spins, temps, n_sweeps, site_mode=SITE_RANDOM, arith=ARITH_F64,
 
 
 def pt_exchange_round(slot_temps, rep_energy, slot_to_rep, start=-1, u=None, seed=0, round_=0,
-                      attempts=None, accepts=None):
+                      ladder=0, attempts=None, accepts=None):
     """In place on slot_to_rep (int32), attempts/accepts (int64)."""
     t = _c(slot_temps, np.float64)
     e = _c(rep_energy, np.float64)
     assert slot_to_rep.dtype == np.int32 and slot_to_rep.flags.c_contiguous
     uu = _c(u, np.float64)
     return int(lib().sgo_pt_exchange_round(len(t), _ptr(t), _ptr(e), _ptr(slot_to_rep), int(start),
-                                           _ptr(uu), int(seed), int(round_), _ptr(attempts),
+                                           _ptr(uu), int(seed), int(round_), int(ladder), _ptr(attempts),
                                            _ptr(accepts)))
 
 

@@ -42,7 +42,8 @@ void sgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* Stream layout of the build's production RNG (DESIGN.md "Random streams"):
  *   key = (seed lo, seed hi); ctr = (block, sweep|round, replica, domain)
  *   domain 0: sweep updates, block = t>>1; update t uses words (2*(t&1), 2*(t&1)+1)
- *   domain 1: exchange decisions, block = lower slot of the pair (0xFFFFFFFF = parity)
+ *   domain 1: exchange decisions, block = lower slot of the pair within its ladder
+ *             (0xFFFFFFFF = parity draw), replica field = ladder index
  *   domain 2: initial spins, block = i>>7, bit i&127 of the 128-bit block          */
 static inline void stream_block(uint64_t seed, uint32_t block, uint32_t sweep, uint32_t replica,
                                 uint32_t domain, uint32_t out[4]) {
@@ -143,16 +144,38 @@ double sgo_exp(double x) {
 /* torch.dot(couplings[i], spins) in fp32 (ising_model.py:183): products J*(+-1) are exact;
  * the sum is formed in double and rounded once to fp32, i.e. the correctly rounded fp32 dot
  * (exactly the reference's value whenever its own fp32 summation is exact, e.g. integer J). */
+/* When the caller asserts that J is integer valued with |row sums| < 2^24 (sgo_set_exact_f32),
+ * fp32 accumulation in any order is exact and equals the double-accumulated value: the loop
+ * below then keeps 16 independent fp32 lanes (what MKL's sdot does for the reference). */
+static int g_exact_f32 = 0;
+void sgo_set_exact_f32(int on) { g_exact_f32 = on; }
+
 static inline float row_dot_f32(int n, const float *J, int64_t ld, const int32_t *rowptr,
                                 const int32_t *colidx, const float *val, const int8_t *s, int i) {
-    double acc = 0.0;
     if (J) {
         const float *row = J + (int64_t)i * ld;
-        for (int j = 0; j < n; ++j) acc += (double)row[j] * (double)s[j];
-    } else {
-        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            acc += (double)val[k] * (double)s[colidx[k]];
+        if (g_exact_f32) {
+            float lane[16] = {0};
+            int j = 0;
+            for (; j + 16 <= n; j += 16)
+                for (int q = 0; q < 16; ++q) lane[q] += row[j + q] * (float)s[j + q];
+            float acc = 0.0f;
+            for (int q = 0; q < 16; ++q) acc += lane[q];
+            for (; j < n; ++j) acc += row[j] * (float)s[j];
+            return acc;
+        }
+        double lane[8] = {0};
+        int j = 0;
+        for (; j + 8 <= n; j += 8)
+            for (int q = 0; q < 8; ++q) lane[q] += (double)(row[j + q] * (float)s[j + q]);
+        double acc = ((lane[0] + lane[1]) + (lane[2] + lane[3])) +
+                     ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+        for (; j < n; ++j) acc += (double)(row[j] * (float)s[j]);
+        return (float)acc;
     }
+    double acc = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+        acc += (double)(val[k] * (float)s[colidx[k]]);
     return (float)acc;
 }
 static inline float diag_elem(int n, const float *J, int64_t ld, const int32_t *rowptr,
@@ -336,10 +359,10 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
  * ---------------------------------------------------------------------------------- */
 int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_energy,
                           int32_t *slot_to_rep, int start, const double *u, uint64_t seed,
-                          uint32_t round, int64_t *attempts, int64_t *accepts) {
+                          uint32_t round, uint32_t ladder, int64_t *attempts, int64_t *accepts) {
     if (start < 0) { /* np.random.randint(0, 2), parallel_tempering.py:217 */
         uint32_t o[4];
-        stream_block(seed, 0xFFFFFFFFu, round, 0, 1, o);
+        stream_block(seed, 0xFFFFFFFFu, round, ladder, 1, o);
         start = (int)(o[0] & 1u);
     }
     int n_acc = 0, k = 0;
@@ -355,7 +378,7 @@ int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_ene
             uu = u[k];
         } else {
             uint32_t o[4];
-            stream_block(seed, (uint32_t)i, round, 0, 1, o);
+            stream_block(seed, (uint32_t)i, round, ladder, 1, o);
             uu = ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) * 0x1.0p-53;
         }
         if (attempts) attempts[i] += 1;

@@ -85,7 +85,7 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
  * Returns number of accepted swaps. */
 int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_energy,
                           int32_t *slot_to_rep, int start, const double *u, uint64_t seed,
-                          uint32_t round, int64_t *attempts, int64_t *accepts);
+                          uint32_t round, uint32_t ladder, int64_t *attempts, int64_t *accepts);
 
 /* CUDAKernelManager._parallel_tempering_fallback, cuda_kernels.py:415-443: sequential
  * adjacent pairs, fp32, p = exp((b2-b1)*(E1-E2)), swaps spin rows and energies. */
@@ -94,6 +94,10 @@ int sgo_pt_exchange_operator(int R, int n, int8_t *spins, float *energies, const
 
 /* Initial spins of the build's production stream: bit b of the Philox(domain 2) block. */
 void sgo_init_spins(int n, int R, uint64_t seed, uint32_t replica0, int8_t *spins);
+
+/* Performance switch for the CPU baseline: assert that J is integer valued with exact fp32
+ * row sums, so the dot may be accumulated in fp32 SIMD lanes (results unchanged). */
+void sgo_set_exact_f32(int on);
 
 /* stream helpers exposed for tests */
 uint32_t sgo_stream_site(uint64_t seed, uint32_t replica, uint32_t sweep, uint32_t t, uint32_t n);

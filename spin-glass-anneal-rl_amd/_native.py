@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI in include/sga.h (csrc/libsga.so).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the call fails
+with DeviceError.  `build()` compiles the library in-tree with hipcc (gfx950).
+"""
+import ctypes as C
+import os
+import subprocess
+
+from .exceptions import AnnealingError, DeviceError, ResourceError
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libsga.so")
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_MEMORY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+J_AUTO, J_F32, J_I8 = 0, 1, 2
+SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
+ARITH_F64, ARITH_F32 = 0, 1
+
+# every symbol include/sga.h declares: (name, restype, argtypes)
+_p, _i, _i64, _u64, _u32, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_double
+SYMBOLS = [
+    ("sga_create", _i, [_i, C.POINTER(_p)]),
+    ("sga_destroy", None, [_p]),
+    ("sga_last_error", C.c_char_p, []),
+    ("sga_version", _i, []),
+    ("sga_set_stream", _i, [_p, _p]),
+    ("sga_set_dense", _i, [_p, _p, _i64, _p, _i, _i]),
+    ("sga_set_csr", _i, [_p, _p, _p, _p, _p, _i, _i64]),
+    ("sga_init_replicas", _i, [_p, _i, _i, _i, _u64, _p]),
+    ("sga_set_temperatures", _i, [_p, _p]),
+    ("sga_set_ladder", _i, [_p, _p, _i]),
+    ("sga_sweep", _i, [_p, _i, _i, _i, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    ("sga_recompute_energies", _i, [_p]),
+    ("sga_exchange", _i, [_p, _p, _p, _p, C.POINTER(_i)]),
+    ("sga_op_pt_exchange", _i, [_i, _p, _p, _p, _p, _u64, _u32, _i, _i, C.POINTER(_i)]),
+    ("sga_get_energies", _i, [_p, _p]),
+    ("sga_get_temperatures", _i, [_p, _p]),
+    ("sga_get_spins", _i, [_p, _i, _p]),
+    ("sga_set_spins", _i, [_p, _i, _p]),
+    ("sga_get_best", _i, [_p, _i, C.POINTER(_d), _p, C.POINTER(_i)]),
+    ("sga_reset_best", _i, [_p]),
+    ("sga_get_stats", _i, [_p, _p, _p]),
+    ("sga_get_slot_map", _i, [_p, _p]),
+    ("sga_get_exchange_stats", _i, [_p, _p, _p]),
+    ("sga_get_sweep_counter", _i, [_p, C.POINTER(_u32), C.POINTER(_u32)]),
+    ("sga_set_sweep_counter", _i, [_p, _u32, _u32]),
+    ("sga_enable_timing", _i, [_p, _i]),
+    ("sga_get_kernel_time", _i, [_p, C.POINTER(_i64), C.POINTER(_d), _i]),
+    ("sga_describe", _i, [_p, C.c_char_p, _i]),
+    ("sga_set_tuning", _i, [_p, _i, _i]),
+]
+
+_lib = None
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    """Compile csrc/*.hip into libsga.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, f"-j{jobs}"] + (["-B"] if force else [])
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise DeviceError("building libsga.so failed", {"stderr": proc.stderr[-2000:]})
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise DeviceError(
+                "libsga.so is not built (run __graft_entry__.build() or `make -C "
+                f"{_CSRC}`); the engine has no CPU fallback")
+        try:
+            L = C.CDLL(_SO)
+        except OSError as exc:  # missing ROCm runtime etc.
+            raise DeviceError(f"cannot load {_SO}: {exc}") from exc
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().sga_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc == ERR_DEVICE:
+        raise DeviceError(msg, {"code": rc})
+    if rc == ERR_MEMORY:
+        raise ResourceError(msg, {"code": rc})
+    raise AnnealingError(msg, {"code": rc})

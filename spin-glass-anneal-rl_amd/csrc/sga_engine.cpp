@@ -1,0 +1,923 @@
+// sga_engine.cpp -- host side of the C ABI declared in include/sga.h: owns the HBM buffers
+// (packed couplings, replica spins / energies / bests, ladder state), picks the launch
+// geometry, and drives the HIP kernels.  No torch, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sga.h"
+#include "sga_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(_e == hipErrorOutOfMemory ? SGA_ERR_MEMORY : SGA_ERR_DEVICE,       \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                \
+    } while (0)
+
+template <typename T>
+void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof(at));
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear: plain host memory
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// A read-only view of a user buffer on the device: borrowed if it already lives there,
+// otherwise staged into a temporary allocation that dies with the object.
+template <typename T>
+struct DevIn {
+    const T *ptr = nullptr;
+    T *owned = nullptr;
+    int init(const T *user, size_t count, hipStream_t st) {
+        if (!user || count == 0) return SGA_OK;
+        if (is_device_ptr(user)) {
+            ptr = user;
+            return SGA_OK;
+        }
+        HIPCHK(hipMalloc(&owned, count * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(owned, user, count * sizeof(T), hipMemcpyHostToDevice, st));
+        ptr = owned;
+        return SGA_OK;
+    }
+    ~DevIn() { dev_free(owned); }
+};
+
+// A device scratch buffer whose contents are copied to a user buffer (host or device).
+template <typename T>
+struct DevOut {
+    T *ptr = nullptr;
+    T *user = nullptr;
+    size_t count = 0;
+    int init(T *user_, size_t count_, hipStream_t st) {
+        user = user_;
+        count = count_;
+        if (!user || count == 0) return SGA_OK;
+        HIPCHK(hipMalloc(&ptr, count * sizeof(T)));
+        HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T), st));
+        return SGA_OK;
+    }
+    int flush(hipStream_t st) {
+        if (!ptr) return SGA_OK;
+        HIPCHK(hipMemcpyAsync(user, ptr, count * sizeof(T), hipMemcpyDefault, st));
+        return SGA_OK;
+    }
+    ~DevOut() { dev_free(ptr); }
+};
+
+}  // namespace
+
+struct sga_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // problem
+    int n = 0;
+    bool csr = false;
+    float *J_raw = nullptr;  // dense fp32 [n][n], engine copy of the caller's matrix
+    bool want_i8 = false, acc64 = false;
+    void *J_packed = nullptr;  // [n][ld] float | int8
+    long long ld = 0;
+    int waves = 0, cpw = 0;
+    int packed_for_R = -1;
+    int32_t *rowptr = nullptr, *colidx = nullptr;
+    float *val = nullptr;
+    long long nnz = 0;
+    float *h = nullptr, *diag = nullptr;
+    int tune_waves = 0, tune_spl = 0;
+
+    // replicas
+    int R = 0, Rg = 0, replica0 = 0;
+    uint64_t seed = 0;
+    int sstride = 0;
+    int8_t *spins = nullptr, *best_spins = nullptr;
+    double *energy = nullptr, *best_energy = nullptr, *rep_temp = nullptr;
+    unsigned long long *n_acc = nullptr;
+    long long attempted = 0;  // per replica
+    uint32_t sweeps_done = 0, rounds = 0;
+
+    // ladder
+    int n_ladders = 0;
+    double *slot_temps = nullptr;
+    int32_t *slot_to_rep = nullptr;
+    long long *ex_attempts = nullptr, *ex_accepts = nullptr;
+    int *d_count = nullptr;
+
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+
+    void free_problem() {
+        dev_free(J_raw);
+        dev_free(J_packed);
+        dev_free(rowptr);
+        dev_free(colidx);
+        dev_free(val);
+        dev_free(h);
+        dev_free(diag);
+        n = 0;
+        ld = 0;
+        packed_for_R = -1;
+    }
+    void free_replicas() {
+        dev_free(spins);
+        dev_free(best_spins);
+        dev_free(energy);
+        dev_free(best_energy);
+        dev_free(rep_temp);
+        dev_free(n_acc);
+        dev_free(slot_temps);
+        dev_free(slot_to_rep);
+        dev_free(ex_attempts);
+        dev_free(ex_accepts);
+        R = Rg = 0;
+        n_ladders = 0;
+    }
+};
+
+namespace {
+
+int elems_per_chunk(bool i8) { return i8 ? 1024 : 256; }
+
+// Pick waves-per-replica W and chunks-per-wave CPW for a dense row of C chunks so that
+// R*W waves fill the chip (~16 waves per CU on 256 CUs) with little row padding.
+bool choose_geometry(int n, bool i8, int R, int forced_waves, int &W, int &CPW) {
+    const int epc = elems_per_chunk(i8);
+    const int C = (n + epc - 1) / epc;
+    double target = 4096.0 / std::max(R, 1);
+    target = std::min(16.0, std::max(1.0, target));
+    double best_cost = 1e30;
+    W = CPW = 0;
+    for (int w = 1; w <= sga::MAX_WAVES; ++w) {
+        if (forced_waves > 0 && w != forced_waves) continue;
+        const int cpw = (C + w - 1) / w;
+        if (cpw > sga::MAX_CPW) continue;
+        if (w > C && w > 1) continue;
+        const double pad = (double)(w * cpw - C) / C;
+        const double cost = pad + 0.05 * std::fabs(std::log2(w / target));
+        if (cost < best_cost) {
+            best_cost = cost;
+            W = w;
+            CPW = cpw;
+        }
+    }
+    return W > 0;
+}
+
+int recompute_energy_range(sga_engine *e, int r0, int count) {
+    sga::EnergyArgs a{};
+    a.J = e->J_packed;
+    a.rowptr = e->rowptr;
+    a.colidx = e->colidx;
+    a.val = e->val;
+    a.h = e->h;
+    a.spins = e->spins + (long long)r0 * e->sstride;
+    a.energy = e->energy + r0;
+    a.ld = e->ld;
+    a.n = e->n;
+    a.sstride = e->sstride;
+    a.R = count;
+    HIPCHK(e->csr ? sga::launch_energy_csr(a, e->stream)
+                  : sga::launch_energy_dense(a, e->want_i8, e->stream));
+    return SGA_OK;
+}
+
+// (Re)build the packed dense layout for the current replica count / tuning.
+int ensure_packed(sga_engine *e) {
+    if (e->csr) return SGA_OK;
+    if (!e->J_raw) return fail(SGA_ERR_INVALID, "no couplings set");
+    int W, CPW;
+    if (!choose_geometry(e->n, e->want_i8, std::max(e->R, 1), e->tune_waves, W, CPW))
+        return fail(SGA_ERR_UNSUPPORTED,
+                    "dense row too long for the register-resident sweep kernel (n=" +
+                        std::to_string(e->n) + "); use CSR or int8 couplings");
+    const long long ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
+    if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+    if (sga::sweep_dense_lds_bytes(ld, W) > 160 * 1024)
+        return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
+    dev_free(e->J_packed);
+    const size_t bytes = (size_t)e->n * ld * (e->want_i8 ? 1 : 4);
+    HIPCHK(hipMalloc(&e->J_packed, bytes));
+    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, e->n, e->J_packed, ld, e->want_i8, e->diag,
+                                    e->stream));
+    e->waves = W;
+    e->cpw = CPW;
+    e->ld = ld;
+    return SGA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sga_last_error(void) { return g_last_error.c_str(); }
+int sga_version(void) { return 100; }
+
+int sga_create(int device, sga_engine **out) {
+    if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(SGA_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (device < 0 || device >= count)
+        return fail(SGA_ERR_DEVICE, "device index " + std::to_string(device) + " out of range (" +
+                                        std::to_string(count) + " visible)");
+    HIPCHK(hipSetDevice(device));
+    sga_engine *eng = new (std::nothrow) sga_engine();
+    if (!eng) return fail(SGA_ERR_MEMORY, "host allocation failed");
+    eng->device = device;
+    e = hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete eng;
+        return fail(SGA_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    eng->stream = eng->own_stream;
+    e = hipMalloc(&eng->d_count, sizeof(int));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(eng->own_stream);
+        delete eng;
+        return fail(SGA_ERR_MEMORY, "hipMalloc failed");
+    }
+    *out = eng;
+    return SGA_OK;
+}
+
+void sga_destroy(sga_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto &p : e->events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    e->free_replicas();
+    e->free_problem();
+    dev_free(e->d_count);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int sga_set_stream(sga_engine *e, void *hip_stream) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return SGA_OK;
+}
+
+int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (waves_per_replica < 0 || waves_per_replica > sga::MAX_WAVES || sweeps_per_launch < 0)
+        return fail(SGA_ERR_INVALID, "bad tuning values");
+    e->tune_waves = waves_per_replica;
+    e->tune_spl = sweeps_per_launch;
+    return SGA_OK;
+}
+
+int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n, int storage) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (!J || !h || n <= 0 || ldJ < n) return fail(SGA_ERR_INVALID, "bad dense problem arguments");
+    if (storage != SGA_J_AUTO && storage != SGA_J_F32 && storage != SGA_J_I8)
+        return fail(SGA_ERR_INVALID, "bad storage selector");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->free_replicas();
+    e->free_problem();
+    e->csr = false;
+    e->n = n;
+    HIPCHK(hipMalloc(&e->J_raw, sizeof(float) * (size_t)n * n));
+    HIPCHK(hipMemcpy2DAsync(e->J_raw, sizeof(float) * (size_t)n, J, sizeof(float) * (size_t)ldJ,
+                            sizeof(float) * (size_t)n, (size_t)n, hipMemcpyDefault, e->stream));
+    HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)n));
+    HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
+    HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)n));
+    // value scan: can J live in int8; is fp32 accumulation exact?
+    int *flags = nullptr;
+    HIPCHK(hipMalloc(&flags, 2 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(flags, 0, 2 * sizeof(int), e->stream));
+    hipError_t le = sga::launch_scan_values(e->J_raw, n, n, n, flags, e->stream);
+    int hflags[2] = {1, 1};
+    if (le == hipSuccess)
+        le = hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
+    (void)hipFree(flags);
+    HIPCHK(le);
+    const bool fits_i8 = hflags[0] == 0;
+    if (storage == SGA_J_I8 && !fits_i8)
+        return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
+    e->want_i8 = (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
+    // fp32 partial sums are exact when every J is an integer below 2^10 and n < 2^14
+    e->acc64 = !e->want_i8 && !(hflags[1] == 0 && n <= 16384);
+    return ensure_packed(e);
+}
+
+int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                const float *h, int n, int64_t nnz) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (!rowptr || !h || n <= 0 || nnz < 0 || (nnz > 0 && (!colidx || !val)))
+        return fail(SGA_ERR_INVALID, "bad CSR problem arguments");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->free_replicas();
+    e->free_problem();
+    e->csr = true;
+    e->n = n;
+    e->nnz = nnz;
+    HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * (size_t)(n + 1)));
+    HIPCHK(hipMemcpyAsync(e->rowptr, rowptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDefault,
+                          e->stream));
+    const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
+    HIPCHK(hipMalloc(&e->colidx, sizeof(int32_t) * nz));
+    HIPCHK(hipMalloc(&e->val, sizeof(float) * nz));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(e->colidx, colidx, sizeof(int32_t) * nz, hipMemcpyDefault, e->stream));
+        HIPCHK(hipMemcpyAsync(e->val, val, sizeof(float) * nz, hipMemcpyDefault, e->stream));
+    }
+    HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)n));
+    HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
+    HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)n));
+    // validate the structure on the host copy of rowptr (cheap) -- a bad extent would fault
+    std::vector<int32_t> rp((size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(rp.data(), e->rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (rp[0] != 0 || rp[n] != nnz) {
+        e->free_problem();
+        return fail(SGA_ERR_INVALID, "CSR rowptr does not span [0, nnz]");
+    }
+    for (int i = 0; i < n; ++i)
+        if (rp[i + 1] < rp[i]) {
+            e->free_problem();
+            return fail(SGA_ERR_INVALID, "CSR rowptr is not monotone");
+        }
+    if (nnz > 0) {
+        std::vector<int32_t> ci((size_t)nnz);
+        HIPCHK(hipMemcpy(ci.data(), e->colidx, sizeof(int32_t) * ci.size(), hipMemcpyDeviceToHost));
+        for (int32_t c : ci)
+            if (c < 0 || c >= n) {
+                e->free_problem();
+                return fail(SGA_ERR_INVALID, "CSR column index out of range");
+            }
+    }
+    HIPCHK(sga::launch_gather_diag_csr(e->rowptr, e->colidx, e->val, n, e->diag, e->stream));
+    return SGA_OK;
+}
+
+int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
+                      const int8_t *s0) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->n <= 0) return fail(SGA_ERR_INVALID, "set the couplings before the replicas");
+    if (R_local <= 0 || R_global < R_local || replica0 < 0 || replica0 + R_local > R_global)
+        return fail(SGA_ERR_INVALID, "bad replica partition");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->free_replicas();
+    e->R = R_local;
+    e->Rg = R_global;
+    e->replica0 = replica0;
+    e->seed = seed;
+    e->sweeps_done = 0;
+    e->rounds = 0;
+    e->attempted = 0;
+    if (!e->csr) {
+        int rc = ensure_packed(e);  // geometry depends on the replica count
+        if (rc != SGA_OK) return rc;
+        e->sstride = (int)e->ld;
+    } else {
+        e->sstride = (e->n + 15) / 16 * 16;
+        if ((size_t)e->sstride * sga::CSR_WAVES_PER_BLOCK > 160 * 1024)
+            return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
+    }
+    const size_t sb = (size_t)R_local * e->sstride;
+    HIPCHK(hipMalloc(&e->spins, sb));
+    HIPCHK(hipMalloc(&e->best_spins, sb));
+    HIPCHK(hipMalloc(&e->energy, sizeof(double) * R_local));
+    HIPCHK(hipMalloc(&e->best_energy, sizeof(double) * R_local));
+    HIPCHK(hipMalloc(&e->rep_temp, sizeof(double) * R_local));
+    HIPCHK(hipMalloc(&e->n_acc, sizeof(unsigned long long) * R_local));
+    HIPCHK(hipMemsetAsync(e->n_acc, 0, sizeof(unsigned long long) * R_local, e->stream));
+    {
+        std::vector<double> ones((size_t)R_local, 1.0);
+        HIPCHK(hipMemcpyAsync(e->rep_temp, ones.data(), sizeof(double) * R_local,
+                              hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (s0) {
+        DevIn<int8_t> in;
+        int rc = in.init(s0, (size_t)R_local * e->n, e->stream);
+        if (rc != SGA_OK) return rc;
+        HIPCHK(sga::launch_pad_spins(in.ptr, e->n, e->spins, e->sstride, R_local, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } else {
+        HIPCHK(sga::launch_init_spins(e->spins, e->n, e->sstride, R_local, (uint32_t)seed,
+                                      (uint32_t)(seed >> 32), (uint32_t)replica0, e->stream));
+    }
+    int rc = recompute_energy_range(e, 0, R_local);
+    if (rc != SGA_OK) return rc;
+    HIPCHK(sga::launch_copy_best(e->energy, e->spins, e->best_energy, e->best_spins, e->sstride,
+                                 R_local, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_set_temperatures(sga_engine *e, const double *T) {
+    if (!e || !T) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->rep_temp, T, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_set_ladder(sga_engine *e, const double *slot_temps, int n_ladders) {
+    if (!e || !slot_temps) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    if (n_ladders <= 0 || e->Rg % n_ladders != 0)
+        return fail(SGA_ERR_INVALID, "R_global must be a multiple of n_ladders");
+    HIPCHK(hipSetDevice(e->device));
+    dev_free(e->slot_temps);
+    dev_free(e->slot_to_rep);
+    dev_free(e->ex_attempts);
+    dev_free(e->ex_accepts);
+    const size_t Rg = (size_t)e->Rg;
+    HIPCHK(hipMalloc(&e->slot_temps, sizeof(double) * Rg));
+    HIPCHK(hipMalloc(&e->slot_to_rep, sizeof(int32_t) * Rg));
+    HIPCHK(hipMalloc(&e->ex_attempts, sizeof(long long) * Rg));
+    HIPCHK(hipMalloc(&e->ex_accepts, sizeof(long long) * Rg));
+    HIPCHK(hipMemcpyAsync(e->slot_temps, slot_temps, sizeof(double) * Rg, hipMemcpyDefault,
+                          e->stream));
+    std::vector<int32_t> ident(Rg);
+    for (size_t i = 0; i < Rg; ++i) ident[i] = (int32_t)i;
+    HIPCHK(hipMemcpyAsync(e->slot_to_rep, ident.data(), sizeof(int32_t) * Rg, hipMemcpyHostToDevice,
+                          e->stream));
+    HIPCHK(hipMemsetAsync(e->ex_attempts, 0, sizeof(long long) * Rg, e->stream));
+    HIPCHK(hipMemsetAsync(e->ex_accepts, 0, sizeof(long long) * Rg, e->stream));
+    // slot i initially holds replica i: local temperatures are the matching slice
+    HIPCHK(hipMemcpyAsync(e->rep_temp, e->slot_temps + e->replica0, sizeof(double) * e->R,
+                          hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->n_ladders = n_ladders;
+    e->rounds = 0;
+    return SGA_OK;
+}
+
+int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const double *sched,
+              int64_t sched_sweep_stride, int64_t sched_replica_stride,
+              const int32_t *replay_site, const float *replay_u, double *energy_trace,
+              uint8_t *accept_trace, double *dE_trace) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas (call sga_init_replicas)");
+    if (n_sweeps < 0) return fail(SGA_ERR_INVALID, "n_sweeps < 0");
+    if (site_mode < SGA_SITE_RANDOM || site_mode > SGA_SITE_REPLAY)
+        return fail(SGA_ERR_INVALID, "bad site_mode");
+    if (arith != SGA_ARITH_F64 && arith != SGA_ARITH_F32) return fail(SGA_ERR_INVALID, "bad arith");
+    if (site_mode == SGA_SITE_REPLAY && (!replay_site || !replay_u))
+        return fail(SGA_ERR_INVALID, "SITE_REPLAY needs replay_site and replay_u");
+    if (n_sweeps == 0) return SGA_OK;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = ensure_packed(e);
+    if (rc != SGA_OK) return rc;
+    if (!e->csr && e->sstride != (int)e->ld)
+        return fail(SGA_ERR_INVALID, "tuning changed after sga_init_replicas; re-initialise");
+
+    const int n = e->n, R = e->R;
+    const long long per = (long long)n_sweeps * n;
+    hipStream_t st = e->stream;
+
+    // schedule table: find its extent from the strides
+    DevIn<double> d_sched;
+    if (sched) {
+        if (sched_sweep_stride < 0 || sched_replica_stride < 0)
+            return fail(SGA_ERR_INVALID, "negative schedule stride");
+        const size_t extent =
+            (size_t)((n_sweeps - 1) * sched_sweep_stride + (R - 1) * sched_replica_stride + 1);
+        rc = d_sched.init(sched, extent, st);
+        if (rc != SGA_OK) return rc;
+    }
+    DevIn<int32_t> d_site;
+    DevIn<float> d_u;
+    if (site_mode == SGA_SITE_REPLAY) {
+        rc = d_site.init(replay_site, (size_t)R * per, st);
+        if (rc != SGA_OK) return rc;
+    }
+    if (site_mode != SGA_SITE_RANDOM && replay_u) {
+        rc = d_u.init(replay_u, (size_t)R * per, st);
+        if (rc != SGA_OK) return rc;
+    }
+    DevOut<double> d_etrace, d_dE;
+    DevOut<uint8_t> d_acc;
+    rc = d_etrace.init(energy_trace, (size_t)n_sweeps * R, st);
+    if (rc != SGA_OK) return rc;
+    rc = d_acc.init(accept_trace, (size_t)R * per, st);
+    if (rc != SGA_OK) return rc;
+    rc = d_dE.init(dE_trace, (size_t)R * per, st);
+    if (rc != SGA_OK) return rc;
+
+    // sweeps per launch: aim for ~50 ms of estimated work per launch
+    int spl = e->tune_spl;
+    if (spl <= 0) {
+        const double row_bytes = e->csr ? 264.0 : (double)e->ld * (e->want_i8 ? 1 : 4);
+        const double per_update = std::max(row_bytes * R / 4.0e12, 1.0e-6);
+        const double per_sweep = per_update * n;
+        spl = (int)std::min<double>(n_sweeps, std::max(1.0, std::floor(0.05 / per_sweep)));
+    }
+    spl = std::max(1, std::min(spl, n_sweeps));
+
+    for (int k0 = 0; k0 < n_sweeps; k0 += spl) {
+        const int ks = std::min(spl, n_sweeps - k0);
+        sga::SweepArgs a{};
+        a.J = e->J_packed;
+        a.rowptr = e->rowptr;
+        a.colidx = e->colidx;
+        a.val = e->val;
+        a.h = e->h;
+        a.diag = e->diag;
+        a.spins = e->spins;
+        a.energy = e->energy;
+        a.best_energy = e->best_energy;
+        a.best_spins = e->best_spins;
+        a.n_accepted = e->n_acc;
+        a.rep_temp = e->rep_temp;
+        a.sched = d_sched.ptr ? d_sched.ptr + (long long)k0 * sched_sweep_stride : nullptr;
+        a.sched_ss = sched_sweep_stride;
+        a.sched_rs = sched_replica_stride;
+        const long long off = (long long)k0 * n;
+        a.replay_site = d_site.ptr ? d_site.ptr + off : nullptr;
+        a.replay_u = d_u.ptr ? d_u.ptr + off : nullptr;
+        a.replay_stride = per;
+        a.energy_trace = d_etrace.ptr ? d_etrace.ptr + (long long)k0 * R : nullptr;
+        a.accept_trace = d_acc.ptr ? d_acc.ptr + off : nullptr;
+        a.dE_trace = d_dE.ptr ? d_dE.ptr + off : nullptr;
+        a.ld = e->ld;
+        a.n = n;
+        a.sstride = e->sstride;
+        a.R = R;
+        a.n_sweeps = ks;
+        a.site_mode = site_mode;
+        a.arith = arith;
+        a.seed_lo = (uint32_t)e->seed;
+        a.seed_hi = (uint32_t)(e->seed >> 32);
+        a.sweep0 = e->sweeps_done + (uint32_t)k0;
+        a.replica0 = (uint32_t)e->replica0;
+
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (e->timing) {
+            HIPCHK(hipEventCreate(&ev0));
+            HIPCHK(hipEventCreate(&ev1));
+            HIPCHK(hipEventRecord(ev0, st));
+        }
+        hipError_t le = e->csr ? sga::launch_sweep_csr(a, st)
+                               : sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves, e->cpw, st);
+        if (e->timing) {
+            (void)hipEventRecord(ev1, st);
+            e->events.emplace_back(ev0, ev1);
+        }
+        HIPCHK(le);
+    }
+    e->sweeps_done += (uint32_t)n_sweeps;
+    e->attempted += per;
+
+    rc = d_etrace.flush(st);
+    if (rc != SGA_OK) return rc;
+    rc = d_acc.flush(st);
+    if (rc != SGA_OK) return rc;
+    rc = d_dE.flush(st);
+    if (rc != SGA_OK) return rc;
+    // staged inputs / outputs are freed on return: wait for the stream in that case only
+    if (d_sched.owned || d_site.owned || d_u.owned || d_etrace.ptr || d_acc.ptr || d_dE.ptr)
+        HIPCHK(hipStreamSynchronize(st));
+    return SGA_OK;
+}
+
+int sga_recompute_energies(sga_engine *e) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    return recompute_energy_range(e, 0, e->R);
+}
+
+int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *start,
+                 const double *u, int *n_accepted) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder (call sga_set_ladder)");
+    if (!energies_global && e->R != e->Rg)
+        return fail(SGA_ERR_INVALID, "sharded replicas need the all-gathered energies");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int L = e->Rg / e->n_ladders;
+    DevIn<double> d_e, d_u;
+    DevIn<int32_t> d_start;
+    int rc;
+    if (energies_global) {
+        rc = d_e.init(energies_global, (size_t)e->Rg, st);
+        if (rc != SGA_OK) return rc;
+    }
+    if (start) {
+        rc = d_start.init(start, (size_t)e->n_ladders, st);
+        if (rc != SGA_OK) return rc;
+    }
+    if (u) {
+        rc = d_u.init(u, (size_t)e->n_ladders * (L / 2), st);
+        if (rc != SGA_OK) return rc;
+    }
+    HIPCHK(hipMemsetAsync(e->d_count, 0, sizeof(int), st));
+    sga::ExchangeArgs a{};
+    a.energies = energies_global ? d_e.ptr : e->energy;
+    a.slot_temps = e->slot_temps;
+    a.slot_to_rep = e->slot_to_rep;
+    a.rep_temp = e->rep_temp;
+    a.attempts = e->ex_attempts;
+    a.accepts = e->ex_accepts;
+    a.start = d_start.ptr;
+    a.u = d_u.ptr;
+    a.n_accepted = e->d_count;
+    a.R_global = e->Rg;
+    a.R_local = e->R;
+    a.replica0 = e->replica0;
+    a.n_ladders = e->n_ladders;
+    a.seed_lo = (uint32_t)e->seed;
+    a.seed_hi = (uint32_t)(e->seed >> 32);
+    a.round = e->rounds;
+    HIPCHK(sga::launch_exchange_neighbor(a, st));
+    e->rounds += 1;
+    if (n_accepted) {
+        HIPCHK(hipMemcpyAsync(n_accepted, e->d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (d_e.owned || d_u.owned || d_start.owned) {
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return SGA_OK;
+}
+
+int sga_op_pt_exchange(int device, float *spins, float *energies, const float *temps,
+                       const float *u, uint64_t seed, uint32_t round, int R, int n,
+                       int *n_accepted) {
+    if (!spins || !energies || !temps || R <= 0 || n <= 0)
+        return fail(SGA_ERR_INVALID, "bad operator-exchange arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(SGA_ERR_DEVICE, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = nullptr;  // default stream: ordered with the caller's legacy-stream work
+    const size_t rows = (size_t)R * n;
+    float *d_spins = nullptr, *d_tmp = nullptr, *d_en = nullptr;
+    int32_t *d_src = nullptr;
+    int *d_cnt = nullptr;
+    DevIn<float> d_t, d_uu;
+    int rc = d_t.init(temps, (size_t)R, st);
+    if (rc != SGA_OK) return rc;
+    if (u && R > 1) {
+        rc = d_uu.init(u, (size_t)(R - 1), st);
+        if (rc != SGA_OK) return rc;
+    }
+    const bool spins_dev = is_device_ptr(spins), en_dev = is_device_ptr(energies);
+    auto cleanup = [&]() {
+        if (!spins_dev) dev_free(d_spins);
+        if (!en_dev) dev_free(d_en);
+        dev_free(d_tmp);
+        dev_free(d_src);
+        dev_free(d_cnt);
+    };
+    hipError_t he = hipSuccess;
+    auto step = [&](hipError_t x) {
+        if (he == hipSuccess) he = x;
+    };
+    if (spins_dev) d_spins = spins; else step(hipMalloc(&d_spins, rows * sizeof(float)));
+    if (en_dev) d_en = energies; else step(hipMalloc(&d_en, (size_t)R * sizeof(float)));
+    step(hipMalloc(&d_tmp, rows * sizeof(float)));
+    step(hipMalloc(&d_src, (size_t)R * sizeof(int32_t)));
+    step(hipMalloc(&d_cnt, sizeof(int)));
+    if (he == hipSuccess && !spins_dev)
+        step(hipMemcpyAsync(d_spins, spins, rows * sizeof(float), hipMemcpyHostToDevice, st));
+    if (he == hipSuccess && !en_dev)
+        step(hipMemcpyAsync(d_en, energies, (size_t)R * sizeof(float), hipMemcpyHostToDevice, st));
+    if (he == hipSuccess)
+        step(sga::launch_op_exchange(d_spins, d_tmp, d_en, d_t.ptr, d_uu.ptr, d_src, d_cnt,
+                                     (uint32_t)seed, (uint32_t)(seed >> 32), round, R, n, st));
+    if (he == hipSuccess && !spins_dev)
+        step(hipMemcpyAsync(spins, d_spins, rows * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (he == hipSuccess && !en_dev)
+        step(hipMemcpyAsync(energies, d_en, (size_t)R * sizeof(float), hipMemcpyDeviceToHost, st));
+    int cnt = 0;
+    if (he == hipSuccess) step(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (he == hipSuccess) step(hipStreamSynchronize(st));
+    cleanup();
+    HIPCHK(he);
+    if (n_accepted) *n_accepted = cnt;
+    return SGA_OK;
+}
+
+// ---- state access -------------------------------------------------------------------------
+int sga_get_energies(sga_engine *e, double *out) {
+    if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out, e->energy, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_get_temperatures(sga_engine *e, double *out) {
+    if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out, e->rep_temp, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_get_spins(sga_engine *e, int r, int8_t *out) {
+    if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0 || r >= e->R) return fail(SGA_ERR_INVALID, "bad replica index");
+    HIPCHK(hipSetDevice(e->device));
+    if (r >= 0) {
+        HIPCHK(hipMemcpyAsync(out, e->spins + (long long)r * e->sstride, (size_t)e->n,
+                              hipMemcpyDefault, e->stream));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(out, (size_t)e->n, e->spins, (size_t)e->sstride, (size_t)e->n,
+                                (size_t)e->R, hipMemcpyDefault, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_set_spins(sga_engine *e, int r, const int8_t *s) {
+    if (!e || !s) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0 || r < 0 || r >= e->R) return fail(SGA_ERR_INVALID, "bad replica index");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemsetAsync(e->spins + (long long)r * e->sstride, 0, (size_t)e->sstride, e->stream));
+    HIPCHK(hipMemcpyAsync(e->spins + (long long)r * e->sstride, s, (size_t)e->n, hipMemcpyDefault,
+                          e->stream));
+    int rc = recompute_energy_range(e, r, 1);
+    if (rc != SGA_OK) return rc;
+    HIPCHK(sga::launch_copy_best(e->energy + r, e->spins + (long long)r * e->sstride,
+                                 e->best_energy + r, e->best_spins + (long long)r * e->sstride,
+                                 e->sstride, 1, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_get_best(sga_engine *e, int r, double *energy, int8_t *spins, int *r_out) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0 || r >= e->R) return fail(SGA_ERR_INVALID, "bad replica index");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double> be((size_t)e->R);
+    HIPCHK(hipMemcpyAsync(be.data(), e->best_energy, sizeof(double) * e->R, hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (r < 0) {
+        r = 0;
+        for (int i = 1; i < e->R; ++i)
+            if (be[i] < be[r]) r = i;
+    }
+    if (energy) *energy = be[r];
+    if (r_out) *r_out = r;
+    if (spins) {
+        HIPCHK(hipMemcpyAsync(spins, e->best_spins + (long long)r * e->sstride, (size_t)e->n,
+                              hipMemcpyDefault, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return SGA_OK;
+}
+
+int sga_reset_best(sga_engine *e) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(sga::launch_copy_best(e->energy, e->spins, e->best_energy, e->best_spins, e->sstride,
+                                 e->R, e->stream));
+    return SGA_OK;
+}
+
+int sga_get_stats(sga_engine *e, int64_t *accepted, int64_t *attempted) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    if (accepted) {
+        HIPCHK(hipMemcpyAsync(accepted, e->n_acc, sizeof(int64_t) * e->R, hipMemcpyDefault,
+                              e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (attempted) {
+        if (is_device_ptr(attempted)) return fail(SGA_ERR_INVALID, "attempted must be a host buffer");
+        for (int i = 0; i < e->R; ++i) attempted[i] = e->attempted;
+    }
+    return SGA_OK;
+}
+
+int sga_get_slot_map(sga_engine *e, int32_t *slot_to_rep) {
+    if (!e || !slot_to_rep) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg, hipMemcpyDefault,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_get_exchange_stats(sga_engine *e, int64_t *attempts, int64_t *accepts) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
+    HIPCHK(hipSetDevice(e->device));
+    if (attempts)
+        HIPCHK(hipMemcpyAsync(attempts, e->ex_attempts, sizeof(int64_t) * e->Rg, hipMemcpyDefault,
+                              e->stream));
+    if (accepts)
+        HIPCHK(hipMemcpyAsync(accepts, e->ex_accepts, sizeof(int64_t) * e->Rg, hipMemcpyDefault,
+                              e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_get_sweep_counter(sga_engine *e, uint32_t *sweeps_done, uint32_t *exchange_rounds) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (sweeps_done) *sweeps_done = e->sweeps_done;
+    if (exchange_rounds) *exchange_rounds = e->rounds;
+    return SGA_OK;
+}
+
+int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange_rounds) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    e->sweeps_done = sweeps_done;
+    e->rounds = exchange_rounds;
+    return SGA_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------
+int sga_enable_timing(sga_engine *e, int on) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    e->timing = on != 0;
+    return SGA_OK;
+}
+
+int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, int reset) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (auto &p : e->events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            e->total_ms += ms;
+            e->launches += 1;
+        }
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    e->events.clear();
+    if (n_launches) *n_launches = e->launches;
+    if (total_ms) *total_ms = e->total_ms;
+    if (reset) {
+        e->launches = 0;
+        e->total_ms = 0.0;
+    }
+    return SGA_OK;
+}
+
+int sga_describe(sga_engine *e, char *buf, int buflen) {
+    if (!e || !buf || buflen <= 0) return fail(SGA_ERR_INVALID, "bad arguments");
+    char tmp[512];
+    if (e->csr)
+        std::snprintf(tmp, sizeof(tmp),
+                      "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d",
+                      e->n, e->nnz, e->R, sga::CSR_WAVES_PER_BLOCK, e->sstride);
+    else
+        std::snprintf(tmp, sizeof(tmp),
+                      "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d "
+                      "ld=%lld row_bytes=%lld",
+                      e->n, e->want_i8 ? "i8" : "f32",
+                      e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
+                      e->ld, e->ld * (e->want_i8 ? 1 : 4));
+    std::snprintf(buf, (size_t)buflen, "%s", tmp);
+    return SGA_OK;
+}
+
+}  // extern "C"

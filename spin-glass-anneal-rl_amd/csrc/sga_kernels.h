@@ -1,0 +1,105 @@
+// sga_kernels.h -- kernel argument blocks and host-callable launchers shared between the
+// kernel translation units (*.hip) and the C-ABI engine (sga_engine.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sga {
+
+constexpr int MAX_CPW = 10;       // coupling-row chunks a wave holds per buffer (dense)
+constexpr int MAX_WAVES = 16;     // waves per replica workgroup
+constexpr int CSR_WAVES_PER_BLOCK = 4;
+
+// One launch of the sweep kernels covers sweeps [0, n_sweeps) of a call; trace / replay /
+// schedule pointers are already offset to the launch's first sweep by the host.
+struct SweepArgs {
+    // couplings
+    const void *J;           // dense: [n][ld] of float | int8, zero padded rows
+    const int32_t *rowptr;   // CSR
+    const int32_t *colidx;
+    const float *val;
+    const float *h;          // [n]
+    const float *diag;       // [n] J_ii (ARITH_F32 only)
+    // replica state
+    int8_t *spins;           // [R][sstride], +-1, pad = 0
+    double *energy;          // [R]
+    double *best_energy;     // [R]
+    int8_t *best_spins;      // [R][sstride]
+    unsigned long long *n_accepted;  // [R]
+    // temperatures
+    const double *rep_temp;  // [R]
+    const double *sched;     // optional T(k, r) = sched[k*sched_ss + r*sched_rs]
+    long long sched_ss, sched_rs;
+    // replay (parity tests)
+    const int32_t *replay_site;  // [R][replay_stride], offset to this launch's first update
+    const float *replay_u;
+    long long replay_stride;
+    // optional outputs
+    double *energy_trace;        // [n_sweeps][R]
+    uint8_t *accept_trace;       // [R][replay_stride]
+    double *dE_trace;            // [R][replay_stride]
+    long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
+    int n, sstride, R, n_sweeps;
+    int site_mode, arith;
+    uint32_t seed_lo, seed_hi, sweep0, replica0;
+};
+
+struct EnergyArgs {
+    const void *J;
+    const int32_t *rowptr, *colidx;
+    const float *val;
+    const float *h;
+    const int8_t *spins;
+    double *energy;
+    long long ld;
+    int n, sstride, R;
+};
+
+struct ExchangeArgs {
+    const double *energies;   // [R_global] by global replica id
+    const double *slot_temps; // [R_global]
+    int32_t *slot_to_rep;     // [R_global]
+    double *rep_temp;         // [R_local]
+    long long *attempts, *accepts;  // [R_global] indexed by lower slot of the pair
+    const int32_t *start;     // [n_ladders] or null
+    const double *u;          // [n_ladders][L/2] or null
+    int *n_accepted;          // device counter
+    int R_global, R_local, replica0, n_ladders;
+    uint32_t seed_lo, seed_hi, round;
+};
+
+// launchers (defined in the .hip files); all return hipGetLastError() after the launch
+hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
+                              hipStream_t st);
+hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st);
+hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
+hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
+hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
+hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
+                             uint32_t seed_hi, uint32_t replica0, hipStream_t st);
+// J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded, plus diag[n]
+hipError_t launch_repack_dense(const float *J, long long ldJ, int n, void *out, long long ld,
+                               bool to_i8, float *diag, hipStream_t st);
+// flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is not
+// integer-valued or |J| >= 2^10 (fp32 row sums then may be inexact -> fp64 accumulation)
+hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
+                              int *flags, hipStream_t st);
+hipError_t launch_pad_spins(const int8_t *src, int n, int8_t *dst, int sstride, int R,
+                            hipStream_t st);
+hipError_t launch_unpad_spins(const int8_t *src, int sstride, int8_t *dst, int n, int R,
+                              hipStream_t st);
+hipError_t launch_gather_diag_csr(const int32_t *rowptr, const int32_t *colidx, const float *val,
+                                  int n, float *diag, hipStream_t st);
+hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
+                            int8_t *best_spins, int sstride, int R, hipStream_t st);
+
+// operator-form PT exchange (cuda_kernels.py:415-443): decide sequentially, then permute rows
+hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, const float *temps,
+                              const float *u, int32_t *src_of_pos, int *n_accepted,
+                              uint32_t seed_lo, uint32_t seed_hi, uint32_t round, int R, int n,
+                              hipStream_t st);
+
+// dynamic LDS bytes the dense sweep kernel needs for a given geometry
+size_t sweep_dense_lds_bytes(long long ld, int waves);
+
+}  // namespace sga

@@ -1,0 +1,406 @@
+// sga_misc.hip -- the kernels around the sweep: coupling repack, spin init, full energy
+// evaluation, replica exchange.
+#include "sweep_common.h"
+
+namespace sga {
+
+// ---------------------------------------------------------------------------------------
+// J repack: caller's fp32 [n][ldJ] -> engine layout [n][ld] (float | int8), rows zero padded
+// to a whole number of 1-KiB chunks per wave, so the sweep kernel needs no tail masking.
+// ---------------------------------------------------------------------------------------
+template <typename OT>
+__global__ void repack_dense_kernel(const float *__restrict__ J, long long ldJ, int n,
+                                    OT *__restrict__ out, long long ld, float *__restrict__ diag) {
+    const long long total = (long long)n * ld;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / ld, col = i - row * ld;
+        const float v = (col < n) ? J[row * ldJ + col] : 0.0f;
+        out[i] = (OT)v;
+        if (diag && col == row) diag[row] = v;
+    }
+}
+
+hipError_t launch_repack_dense(const float *J, long long ldJ, int n, void *out, long long ld,
+                               bool to_i8, float *diag, hipStream_t st) {
+    const long long total = (long long)n * ld;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (to_i8)
+        hipLaunchKernelGGL(repack_dense_kernel<int8_t>, dim3(blocks), dim3(256), 0, st, J, ldJ, n,
+                           (int8_t *)out, ld, diag);
+    else
+        hipLaunchKernelGGL(repack_dense_kernel<float>, dim3(blocks), dim3(256), 0, st, J, ldJ, n,
+                           (float *)out, ld, diag);
+    return hipGetLastError();
+}
+
+__global__ void scan_values_kernel(const float *__restrict__ v, long long rows, long long cols,
+                                   long long ld, int *flags) {
+    int not_i8 = 0, not_small_int = 0;
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cols, col = i - row * cols;
+        const float x = v[row * ld + col];
+        const bool is_int = (x == __builtin_rintf(x));
+        if (!is_int || !(__builtin_fabsf(x) <= 127.0f)) not_i8 = 1;
+        if (!is_int || !(__builtin_fabsf(x) < 1024.0f)) not_small_int = 1;
+    }
+    if (not_i8) atomicOr(&flags[0], 1);
+    if (not_small_int) atomicOr(&flags[1], 1);
+}
+
+hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
+                              int *flags, hipStream_t st) {
+    const long long total = rows * cols;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scan_values_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, v,
+                       rows, cols, ld, flags);
+    return hipGetLastError();
+}
+
+__global__ void gather_diag_csr_kernel(const int32_t *rowptr, const int32_t *colidx,
+                                       const float *val, int n, float *diag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d = 0.0f;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+        if (colidx[j] == i) d += val[j];
+    diag[i] = d;
+}
+hipError_t launch_gather_diag_csr(const int32_t *rowptr, const int32_t *colidx, const float *val,
+                                  int n, float *diag, hipStream_t st) {
+    hipLaunchKernelGGL(gather_diag_csr_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowptr,
+                       colidx, val, n, diag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// spins: random init (Philox domain 2), pad / unpad between [R][n] and [R][sstride]
+// ---------------------------------------------------------------------------------------
+__global__ void init_spins_kernel(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
+                                  uint32_t seed_hi, uint32_t replica0) {
+    // one thread per 128-spin block: reference core/ising_model.py:67 draws randint(0,2)*2-1
+    const int nblk = (sstride + 127) / 128;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * nblk) return;
+    const int r = (int)(idx / nblk), blk = (int)(idx - (long long)r * nblk);
+    const u32x4 w = philox4x32_10((uint32_t)blk, 0u, replica0 + (uint32_t)r, DOMAIN_INIT, seed_lo,
+                                  seed_hi);
+    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+    int8_t *dst = spins + (long long)r * sstride;
+    for (int q = 0; q < 128; ++q) {
+        const int i = blk * 128 + q;
+        if (i >= sstride) break;
+        const uint32_t bit = (words[q >> 5] >> (q & 31)) & 1u;
+        dst[i] = (i < n) ? (bit ? 1 : -1) : 0;
+    }
+}
+hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
+                             uint32_t seed_hi, uint32_t replica0, hipStream_t st) {
+    const long long total = (long long)R * ((sstride + 127) / 128);
+    hipLaunchKernelGGL(init_spins_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       spins, n, sstride, R, seed_lo, seed_hi, replica0);
+    return hipGetLastError();
+}
+
+__global__ void pad_spins_kernel(const int8_t *src, int n, int8_t *dst, int sstride, int R) {
+    const long long total = (long long)R * sstride;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / sstride, c = i - r * sstride;
+        dst[i] = (c < n) ? src[r * n + c] : (int8_t)0;
+    }
+}
+__global__ void unpad_spins_kernel(const int8_t *src, int sstride, int8_t *dst, int n, int R) {
+    const long long total = (long long)R * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / n, c = i - r * n;
+        dst[i] = src[r * sstride + c];
+    }
+}
+static int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+hipError_t launch_pad_spins(const int8_t *src, int n, int8_t *dst, int sstride, int R,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(pad_spins_kernel, dim3(grid_for((long long)R * sstride)), dim3(256), 0, st,
+                       src, n, dst, sstride, R);
+    return hipGetLastError();
+}
+hipError_t launch_unpad_spins(const int8_t *src, int sstride, int8_t *dst, int n, int R,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(unpad_spins_kernel, dim3(grid_for((long long)R * n)), dim3(256), 0, st, src,
+                       sstride, dst, n, R);
+    return hipGetLastError();
+}
+
+__global__ void copy_best_kernel(const double *energy, const int8_t *spins, double *best_energy,
+                                 int8_t *best_spins, int sstride, int R) {
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    if (threadIdx.x == 0) best_energy[r] = energy[r];
+    const int4 *src = reinterpret_cast<const int4 *>(spins + (long long)r * sstride);
+    int4 *dst = reinterpret_cast<int4 *>(best_spins + (long long)r * sstride);
+    for (int i = threadIdx.x; i < sstride / 16; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
+                            int8_t *best_spins, int sstride, int R, hipStream_t st) {
+    hipLaunchKernelGGL(copy_best_kernel, dim3(R), dim3(256), 0, st, energy, spins, best_energy,
+                       best_spins, sstride, R);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Full energy  E = -0.5 * fp32(s.(J s)) - fp32(h.s)   (core/ising_model.py:149-174;
+// operator form annealing/cuda_kernels.py:284-324, fallback :400-413).
+// One workgroup (4 waves) per replica; spins in LDS; each wave takes rows w, w+4, ...,
+// streams the row with 16-B loads, DPP-reduces J[i,:].s, rounds it to fp32 as torch.mv does.
+// ---------------------------------------------------------------------------------------
+template <typename JT>
+__global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
+    constexpr int EPL = 16 / sizeof(JT), EPC = 64 * EPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t *s = reinterpret_cast<int8_t *>(smem);
+    double *red = reinterpret_cast<double *>(smem + a.sstride);  // [2][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
+        int4 *dst = reinterpret_cast<int4 *>(s);
+        for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const JT *J = reinterpret_cast<const JT *>(a.J);
+    double e_acc = 0.0, h_acc = 0.0;
+    for (int i = w; i < a.n; i += 4) {
+        const JT *row = J + (long long)i * a.ld;
+        double acc = 0.0;
+        for (long long c = lane * EPL; c < a.ld; c += EPC) {
+            if constexpr (sizeof(JT) == 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(row + c);
+                const int sw = *reinterpret_cast<const int *>(s + c);
+                acc += (double)(x.x * (float)(int8_t)(sw));
+                acc += (double)(x.y * (float)(int8_t)(sw >> 8));
+                acc += (double)(x.z * (float)(int8_t)(sw >> 16));
+                acc += (double)(x.w * (float)(sw >> 24));
+            } else {
+                const int4 x = *reinterpret_cast<const int4 *>(row + c);
+                const int4 sv = *reinterpret_cast<const int4 *>(s + c);
+                int t = __builtin_amdgcn_sdot4(x.x, sv.x, 0, false);
+                t = __builtin_amdgcn_sdot4(x.y, sv.y, t, false);
+                t = __builtin_amdgcn_sdot4(x.z, sv.z, t, false);
+                t = __builtin_amdgcn_sdot4(x.w, sv.w, t, false);
+                acc += (double)t;
+            }
+        }
+        const float mv_i = (float)wave_sum(acc);  // torch.mv row, fp32
+        const double si = (double)s[i];
+        e_acc += (double)mv_i * si;
+        h_acc += (double)a.h[i] * si;
+    }
+    if (lane == 0) {
+        red[w] = e_acc;
+        red[4 + w] = h_acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double e = (red[0] + red[1]) + (red[2] + red[3]);
+        const double hs = (red[4] + red[5]) + (red[6] + red[7]);
+        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+    }
+}
+
+hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st) {
+    const size_t lds = (size_t)a.sstride + 64;
+    auto set = [&](const void *f) {
+        return lds > 48 * 1024
+                   ? hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                   : hipSuccess;
+    };
+    if (j_is_i8) {
+        hipError_t e = set(reinterpret_cast<const void *>(energy_dense_kernel<int8_t>));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(energy_dense_kernel<int8_t>, dim3(a.R), dim3(256), lds, st, a);
+    } else {
+        hipError_t e = set(reinterpret_cast<const void *>(energy_dense_kernel<float>));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(energy_dense_kernel<float>, dim3(a.R), dim3(256), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t *s = reinterpret_cast<int8_t *>(smem);
+    double *red = reinterpret_cast<double *>(smem + a.sstride);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
+        int4 *dst = reinterpret_cast<int4 *>(s);
+        for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    double e_acc = 0.0, h_acc = 0.0;
+    for (int i = w; i < a.n; i += 4) {
+        double acc = 0.0;
+        for (int j = a.rowptr[i] + lane; j < a.rowptr[i + 1]; j += 64)
+            acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
+        const float mv_i = (float)wave_sum(acc);
+        const double si = (double)s[i];
+        e_acc += (double)mv_i * si;
+        h_acc += (double)a.h[i] * si;
+    }
+    if (lane == 0) {
+        red[w] = e_acc;
+        red[4 + w] = h_acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double e = (red[0] + red[1]) + (red[2] + red[3]);
+        const double hs = (red[4] + red[5]) + (red[6] + red[7]);
+        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+    }
+}
+
+hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
+    const size_t lds = (size_t)a.sstride + 64;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(energy_csr_kernel, dim3(a.R), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Replica exchange, nearest neighbours (annealing/parallel_tempering.py:214-258).
+// Slots carry temperatures; slot_to_rep names the configuration in each slot.  All pairs of
+// one parity are disjoint, so one thread per pair; an accepted swap exchanges the two
+// slot_to_rep entries (== the reference swapping the spin tensors) and rewrites the two
+// replicas' temperatures.  Decisions are a pure function of (energies, seed, round): every
+// rank of a multi-GPU run evaluates the same ones on the all-gathered energies.
+// ---------------------------------------------------------------------------------------
+__global__ void exchange_neighbor_kernel(const ExchangeArgs a) {
+    const int L = a.R_global / a.n_ladders;
+    const int half = L / 2;
+    const int total = a.n_ladders * half;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += gridDim.x * blockDim.x) {
+        const int l = idx / half, q = idx - l * half;
+        int start;
+        if (a.start) {
+            start = a.start[l] & 1;
+        } else {  // np.random.randint(0, 2), parallel_tempering.py:217
+            const u32x4 w = philox4x32_10(0xFFFFFFFFu, a.round, (uint32_t)l, DOMAIN_EXCHANGE,
+                                          a.seed_lo, a.seed_hi);
+            start = (int)(w.x & 1u);
+        }
+        const int j = start + 2 * q;
+        if (j + 1 >= L) continue;
+        const int i = l * L + j;  // global lower slot of the pair
+        // _attempt_single_exchange, parallel_tempering.py:234-258
+        const double beta_i = 1.0 / a.slot_temps[i], beta_j = 1.0 / a.slot_temps[i + 1];
+        const int ri = a.slot_to_rep[i], rj = a.slot_to_rep[i + 1];
+        const double x = (beta_j - beta_i) * (a.energies[rj] - a.energies[ri]);
+        const double prob = (x >= 0.0) ? 1.0 : exp_det(x);
+        double uu;
+        if (a.u) {
+            uu = a.u[l * half + q];
+        } else {
+            const u32x4 w = philox4x32_10((uint32_t)j, a.round, (uint32_t)l, DOMAIN_EXCHANGE,
+                                          a.seed_lo, a.seed_hi);
+            uu = words_to_u53(w.x, w.y);
+        }
+        a.attempts[i] += 1;
+        int new_i = ri, new_j = rj;
+        if (uu < prob) {
+            new_i = rj;
+            new_j = ri;
+            a.slot_to_rep[i] = new_i;
+            a.slot_to_rep[i + 1] = new_j;
+            a.accepts[i] += 1;
+            atomicAdd(a.n_accepted, 1);
+        }
+        const int li = new_i - a.replica0, lj = new_j - a.replica0;
+        if (li >= 0 && li < a.R_local) a.rep_temp[li] = a.slot_temps[i];
+        if (lj >= 0 && lj < a.R_local) a.rep_temp[lj] = a.slot_temps[i + 1];
+    }
+}
+
+hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st) {
+    const int L = a.R_global / a.n_ladders;
+    const int total = a.n_ladders * (L / 2);
+    if (total <= 0) return hipSuccess;
+    const int blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(exchange_neighbor_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Operator-form exchange, annealing/cuda_kernels.py:415-443: the pairs are visited in order
+// and each decision sees the swaps before it, so the decisions are one serial chain (one
+// thread); the row permutation they compose is then applied by the whole grid.
+// ---------------------------------------------------------------------------------------
+__global__ void op_exchange_decide_kernel(float *energies, const float *temps, const float *u,
+                                          int32_t *src_of_pos, int *n_accepted, uint32_t seed_lo,
+                                          uint32_t seed_hi, uint32_t round, int R) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int i = 0; i < R; ++i) src_of_pos[i] = i;
+    int cnt = 0;
+    for (int i = 0; i + 1 < R; ++i) {
+        const float beta1 = 1.0f / temps[i], beta2 = 1.0f / temps[i + 1];
+        const float db = beta2 - beta1;
+        const float de = energies[i] - energies[i + 1];
+        const float prob = expf_det(db * de);
+        float uu;
+        if (u) {
+            uu = u[i];
+        } else {
+            const u32x4 w = philox4x32_10((uint32_t)i, round, 0u, DOMAIN_EXCHANGE, seed_lo, seed_hi);
+            uu = word_to_u(w.x);
+        }
+        if (uu < prob) {
+            const float e = energies[i];
+            energies[i] = energies[i + 1];
+            energies[i + 1] = e;
+            const int32_t t = src_of_pos[i];
+            src_of_pos[i] = src_of_pos[i + 1];
+            src_of_pos[i + 1] = t;
+            ++cnt;
+        }
+    }
+    *n_accepted = cnt;
+}
+__global__ void op_exchange_gather_kernel(const float *spins, float *tmp, const int32_t *src_of_pos,
+                                          int R, int n) {
+    const long long total = (long long)R * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pos = i / n, c = i - pos * n;
+        tmp[i] = spins[(long long)src_of_pos[pos] * n + c];
+    }
+}
+hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, const float *temps,
+                              const float *u, int32_t *src_of_pos, int *n_accepted,
+                              uint32_t seed_lo, uint32_t seed_hi, uint32_t round, int R, int n,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(op_exchange_decide_kernel, dim3(1), dim3(64), 0, st, energies, temps, u,
+                       src_of_pos, n_accepted, seed_lo, seed_hi, round, R);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(op_exchange_gather_kernel, dim3(grid_for((long long)R * n)), dim3(256), 0,
+                       st, spins, tmp_rows, src_of_pos, R, n);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(spins, tmp_rows, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice,
+                          st);
+}
+
+}  // namespace sga

@@ -1,0 +1,86 @@
+// sweep_common.h -- pieces shared by the dense and CSR sweep kernels: where the site and the
+// uniform of an update come from, and the Metropolis accept rule.
+#pragma once
+#include "sga.h"
+#include "sga_device.h"
+#include "sga_kernels.h"
+
+namespace sga {
+
+// Two consecutive updates (t = 2b, 2b+1) of one sweep: one Philox block serves both.
+struct UpdatePair {
+    int sA, sB;
+    float uA, uB;
+};
+
+// Everything here is wave-uniform (blockIdx / loop counters / kernel arguments).
+__device__ __forceinline__ UpdatePair fetch_pair(const SweepArgs &a, int r, int k, int b,
+                                                 bool valid) {
+    UpdatePair o{0, 0, 2.0f, 2.0f};
+    if (!valid) return o;
+    const int n = a.n, t0 = 2 * b, t1 = 2 * b + 1;
+    const bool hasB = t1 < n;
+    const long long base = (long long)r * a.replay_stride + (long long)k * n;
+    if (a.site_mode == SGA_SITE_REPLAY) {
+        // recorded stream of the reference: site = torch.randint(0, n, (1,)) at
+        // core/spin_dynamics.py:69, u = torch.rand(1) at :146
+        o.sA = a.replay_site[base + t0];
+        o.uA = a.replay_u[base + t0];
+        if (hasB) {
+            o.sB = a.replay_site[base + t1];
+            o.uB = a.replay_u[base + t1];
+        }
+        o.sA = min(max(o.sA, 0), n - 1);
+        o.sB = min(max(o.sB, 0), n - 1);
+        return o;
+    }
+    const u32x4 w = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)k, a.replica0 + (uint32_t)r,
+                                  DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+    if (a.site_mode == SGA_SITE_RANDOM) {
+        o.sA = (int)word_to_site(w.x, (uint32_t)n);
+        o.sB = (int)word_to_site(w.z, (uint32_t)n);
+    } else {  // SGA_SITE_SEQUENTIAL: annealing/cuda_kernels.py:381  for i in range(n_spins)
+        o.sA = t0;
+        o.sB = hasB ? t1 : 0;
+    }
+    if (a.site_mode == SGA_SITE_SEQUENTIAL && a.replay_u) {
+        o.uA = a.replay_u[base + t0];
+        if (hasB) o.uB = a.replay_u[base + t1];
+    } else {
+        o.uA = word_to_u(w.y);
+        o.uB = word_to_u(w.w);
+    }
+    return o;
+}
+
+// The accept rule.  dot = fp32 coupling dot product J[site,:].s (already rounded to fp32),
+// si = s[site] (+-1).  Returns true if the flip is accepted; dE receives the proposed
+// energy change.
+__device__ __forceinline__ bool metropolis_accept(int arith, float dot, int si, float h_site,
+                                                  float diag_site, double T, float u,
+                                                  double &dE) {
+    if (arith == SGA_ARITH_F64) {
+        // core/spin_dynamics.py:131-152 with core/ising_model.py:176-185:
+        //   local_field = float(dot) + float(h[i])          (python doubles)
+        //   delta_energy = 2.0 * s_i * local_field
+        //   accept if delta_energy <= 0 else rand < exp(float32(-delta_energy / T))
+        const double field = (double)dot + (double)h_site;
+        dE = 2.0 * (double)si * field;
+        if (dE <= 0.0) return true;
+        const float p = expf_det((float)(-dE / T));
+        return u < p;
+    }
+    // annealing/cuda_kernels.py:383-390 (fp32 tensors):
+    //   local_field = h[i] + sum(J[i] * s) - J[i,i] * s[i]
+    //   delta_energy = 2.0 * s[i] * local_field
+    //   accept if delta_energy <= 0 or rand < exp(-delta_energy / T)
+    const float sif = (float)si;
+    const float field = (h_site + dot) - diag_site * sif;
+    const float dEf = (2.0f * sif) * field;
+    dE = (double)dEf;
+    if (dEf <= 0.0f) return true;
+    const float p = expf_det(-dEf / (float)T);
+    return u < p;
+}
+
+}  // namespace sga

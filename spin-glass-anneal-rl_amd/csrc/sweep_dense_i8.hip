@@ -1,0 +1,18 @@
+// Dense sweep, int8 couplings (integer J in [-127,127]), v_dot4_i32_i8 accumulation.
+#include "sweep_dense_impl.h"
+namespace sga {
+hipError_t launch_sweep_dense_i8(const SweepArgs &a, int waves, int cpw, hipStream_t st) {
+    return launch_variant<int8_t, false>(a, waves, cpw, st);
+}
+hipError_t launch_sweep_dense_f32(const SweepArgs &, int, int, hipStream_t);
+hipError_t launch_sweep_dense_f32acc64(const SweepArgs &, int, int, hipStream_t);
+
+hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
+                              hipStream_t st) {
+    if (waves < 1 || waves > MAX_WAVES || cpw < 1 || cpw > MAX_CPW) return hipErrorInvalidValue;
+    if (j_is_i8) return launch_sweep_dense_i8(a, waves, cpw, st);
+    return acc64 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
+                 : launch_sweep_dense_f32(a, waves, cpw, st);
+}
+size_t sweep_dense_lds_bytes(long long ld, int) { return (size_t)ld + DENSE_LDS_EXTRA; }
+}  // namespace sga

@@ -1,0 +1,250 @@
+// sweep_dense_impl.h -- the dense Metropolis sweep kernel (the HBM-bound hot kernel).
+//
+// Replaces: CUDAKernelManager.metropolis_update_optimized (annealing/cuda_kernels.py:228-282,
+// fallback :371-398) and SpinDynamics.sweep (core/spin_dynamics.py:73-94) batched over the
+// replicas of ParallelTempering._parallel_sweeps (annealing/parallel_tempering.py:191-203).
+//
+// Mapping (DESIGN.md "Dense sweep kernel"):
+//   * one workgroup per replica, W waves (W chosen on the host so R*W waves fill the chip);
+//   * a coupling row J[site,:] is cut into 1-KiB chunks (64 lanes x 16 B, one
+//     global_load_dwordx4 per wave); wave w owns chunks w, w+W, w+2W, ... -- CPW of them --
+//     and keeps them in VGPRs: no LDS round trip for data that is streamed once;
+//   * the replica's spins live in LDS as int8; each wave reads only the bytes under its
+//     own chunks, and only the owning wave ever rewrites them (no cross-wave hazard);
+//   * the single-spin Markov chain is serial, but the SITE sequence is known ahead of
+//     time from the counter RNG, so row t+1 is prefetched into a second register buffer
+//     while row t is reduced: CPW KiB per wave stay in flight across the per-update
+//     barrier (plain loads survive s_barrier);
+//   * per update: lane partial -> DPP wave sum -> W partials through LDS (one barrier,
+//     double-buffered slots) -> every thread evaluates the same accept rule.
+#pragma once
+#include "sweep_common.h"
+
+namespace sga {
+
+template <typename JT>
+struct JTraits;
+template <>
+struct JTraits<float> {
+    using vec_t = float4;
+    static constexpr int EPL = 4;  // elements per lane per chunk (16 B)
+};
+template <>
+struct JTraits<int8_t> {
+    using vec_t = int4;
+    static constexpr int EPL = 16;
+};
+
+template <typename JT, bool ACC64>
+struct AccType {
+    using type = float;
+};
+template <>
+struct AccType<float, true> {
+    using type = double;
+};
+template <bool ACC64>
+struct AccType<int8_t, ACC64> {
+    using type = int;
+};
+
+constexpr int PART_SLOT_BYTES = 8;
+constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * PART_SLOT_BYTES + 16;
+
+template <typename JT, int CPW, bool ACC64>
+__global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
+    using TR = JTraits<JT>;
+    using vec_t = typename TR::vec_t;
+    using acc_t = typename AccType<JT, ACC64>::type;
+    constexpr int EPL = TR::EPL, EPC = 64 * EPL;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t *s_lds = reinterpret_cast<int8_t *>(smem);                      // [ld]
+    unsigned char *part_raw = smem + a.ld;                                 // [2][MAX_WAVES] 8-B slots
+    int *sislot = reinterpret_cast<int *>(smem + a.ld + 2 * MAX_WAVES * PART_SLOT_BYTES);  // [2]
+
+    const int tid = threadIdx.x;
+    const int W = blockDim.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = blockIdx.x;
+    const int n = a.n;
+
+    {  // replica spins -> LDS (pad bytes are zero in HBM)
+        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
+        int4 *dst = reinterpret_cast<int4 *>(s_lds);
+        for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const long long kstride = (long long)W * EPC;  // elements between a wave's chunks
+    const JT *Jlane = reinterpret_cast<const JT *>(a.J) + (w * EPC + lane * EPL);
+    const int8_t *slane = s_lds + (w * EPC + lane * EPL);
+    const bool arith32 = a.arith == SGA_ARITH_F32;
+
+    auto load_row = [&](vec_t(&buf)[CPW], int site) {
+        const JT *p = Jlane + (long long)site * a.ld;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) buf[k] = *reinterpret_cast<const vec_t *>(p + k * kstride);
+    };
+
+    auto dot_row = [&](const vec_t(&buf)[CPW]) -> acc_t {
+        acc_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            if constexpr (sizeof(JT) == 4) {
+                const int sw = *reinterpret_cast<const int *>(slane + k * kstride);
+                const float s0 = (float)(int8_t)(sw), s1 = (float)(int8_t)(sw >> 8),
+                            s2 = (float)(int8_t)(sw >> 16), s3 = (float)(sw >> 24);
+                // J * (+-1) is exact in fp32
+                if constexpr (ACC64) {
+                    acc += (double)(buf[k].x * s0);
+                    acc += (double)(buf[k].y * s1);
+                    acc += (double)(buf[k].z * s2);
+                    acc += (double)(buf[k].w * s3);
+                } else {
+                    acc = __builtin_fmaf(buf[k].x, s0, acc);
+                    acc = __builtin_fmaf(buf[k].y, s1, acc);
+                    acc = __builtin_fmaf(buf[k].z, s2, acc);
+                    acc = __builtin_fmaf(buf[k].w, s3, acc);
+                }
+            } else {
+                const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstride);
+                acc = __builtin_amdgcn_sdot4(buf[k].x, sv.x, acc, false);
+                acc = __builtin_amdgcn_sdot4(buf[k].y, sv.y, acc, false);
+                acc = __builtin_amdgcn_sdot4(buf[k].z, sv.z, acc, false);
+                acc = __builtin_amdgcn_sdot4(buf[k].w, sv.w, acc, false);
+            }
+        }
+        return acc;
+    };
+
+    double E = a.energy[r];
+    double bestE = a.best_energy[r];
+    unsigned long long nacc = 0;
+    int pp = 0;
+    double T = 1.0;
+
+    // one Metropolis update at `site` using the row held in `buf`
+    auto step = [&](const vec_t(&buf)[CPW], int site, float u, float h_site, float d_site,
+                    long long upd) {
+        acc_t tot = wave_sum(dot_row(buf));
+        const int owner = (site / EPC) % W;
+        int si;
+        if (W > 1) {
+            acc_t *part = reinterpret_cast<acc_t *>(part_raw + pp * MAX_WAVES * PART_SLOT_BYTES);
+            if (lane == 0) {
+                *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
+                                           w * PART_SLOT_BYTES) = tot;
+                if (w == owner) sislot[pp] = s_lds[site];
+            }
+            __syncthreads();
+            acc_t s = *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part));
+            for (int i = 1; i < W; ++i)
+                s += *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
+                                                i * PART_SLOT_BYTES);
+            tot = s;
+            si = sislot[pp];
+            pp ^= 1;
+        } else {
+            si = s_lds[site];
+        }
+        double dE;
+        const bool acc = metropolis_accept(a.arith, (float)tot, si, h_site, d_site, T, u, dE);
+        if (acc) {
+            E += dE;
+            ++nacc;
+            if (w == owner && lane == 0) s_lds[site] = (int8_t)(-si);
+        }
+        if (tid == 0) {
+            if (a.accept_trace) a.accept_trace[(long long)r * a.replay_stride + upd] = acc ? 1 : 0;
+            if (a.dE_trace) a.dE_trace[(long long)r * a.replay_stride + upd] = acc ? dE : 0.0;
+        }
+    };
+
+    const int nb = (n + 1) >> 1;
+    vec_t X[CPW], Y[CPW];
+    UpdatePair cur = fetch_pair(a, r, 0, 0, a.n_sweeps > 0);
+    load_row(X, cur.sA);
+    float hX = a.h[cur.sA], dX = arith32 ? a.diag[cur.sA] : 0.0f;
+
+    for (int k = 0; k < a.n_sweeps; ++k) {
+        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        for (int b = 0; b < nb; ++b) {
+            const bool last = (b + 1 == nb);
+            const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
+            const UpdatePair nxt = fetch_pair(a, r, kn, bn, kn < a.n_sweeps);
+            const bool hasB = (2 * b + 1) < n;
+            const int sY = hasB ? cur.sB : nxt.sA;
+            load_row(Y, sY);  // in flight while X is reduced
+            float hY = a.h[sY], dY = arith32 ? a.diag[sY] : 0.0f;
+            step(X, cur.sA, cur.uA, hX, dX, (long long)k * n + 2 * b);
+            if (hasB) {
+                load_row(X, nxt.sA);
+                hX = a.h[nxt.sA];
+                dX = arith32 ? a.diag[nxt.sA] : 0.0f;
+                step(Y, cur.sB, cur.uB, hY, dY, (long long)k * n + 2 * b + 1);
+            } else {  // odd n: the prefetched row is the next sweep's first
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) X[q] = Y[q];
+                hX = hY;
+                dX = dY;
+            }
+            cur = nxt;
+        }
+        // sweep boundary: energy record and best tracking (annealing/gpu_annealer.py:151-153)
+        if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+        if (E < bestE) {
+            bestE = E;
+            __syncthreads();
+            int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
+            const int4 *src = reinterpret_cast<const int4 *>(s_lds);
+            for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+            __syncthreads();
+        }
+    }
+
+    __syncthreads();
+    {
+        int4 *dst = reinterpret_cast<int4 *>(a.spins + (long long)r * a.sstride);
+        const int4 *src = reinterpret_cast<const int4 *>(s_lds);
+        for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    if (tid == 0) {
+        a.energy[r] = E;
+        a.best_energy[r] = bestE;
+        a.n_accepted[r] += nacc;
+    }
+}
+
+template <typename JT, bool ACC64, int CPW>
+static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
+    const size_t lds = (size_t)a.ld + DENSE_LDS_EXTRA;
+    auto kern = sweep_dense_kernel<JT, CPW, ACC64>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
+    return hipGetLastError();
+}
+
+template <typename JT, bool ACC64>
+static hipError_t launch_variant(const SweepArgs &a, int waves, int cpw, hipStream_t st) {
+    switch (cpw) {
+        case 1: return launch_one<JT, ACC64, 1>(a, waves, st);
+        case 2: return launch_one<JT, ACC64, 2>(a, waves, st);
+        case 3: return launch_one<JT, ACC64, 3>(a, waves, st);
+        case 4: return launch_one<JT, ACC64, 4>(a, waves, st);
+        case 5: return launch_one<JT, ACC64, 5>(a, waves, st);
+        case 6: return launch_one<JT, ACC64, 6>(a, waves, st);
+        case 7: return launch_one<JT, ACC64, 7>(a, waves, st);
+        case 8: return launch_one<JT, ACC64, 8>(a, waves, st);
+        case 9: return launch_one<JT, ACC64, 9>(a, waves, st);
+        case 10: return launch_one<JT, ACC64, 10>(a, waves, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sga

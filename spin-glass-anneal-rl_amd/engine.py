@@ -1,0 +1,296 @@
+"""AnnealEngine: thin object wrapper over the C ABI handle (include/sga.h).
+
+All arithmetic happens in the HIP kernels behind the handle; this class only marshals
+buffers (numpy arrays, or torch tensors whose `data_ptr()` is handed over) and turns status
+codes into exceptions.  PyTorch is used for device memory only.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+from .exceptions import AnnealingError
+
+try:  # torch is plumbing here: device buffers and streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _buf(x, np_dtype, torch_dtype_name):
+    """Return (pointer, keepalive) for a numpy array / torch tensor / None."""
+    if x is None:
+        return None, None
+    if _is_tensor(x):
+        want = getattr(torch, torch_dtype_name)
+        t = x.detach()
+        if t.dtype != want or not t.is_contiguous():
+            t = t.to(want).contiguous()
+        return C.c_void_p(t.data_ptr()), t
+    a = np.ascontiguousarray(x, dtype=np_dtype)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
+class AnnealEngine:
+    """One engine per GPU: packed couplings + R replicas resident in HBM."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        self._lib = N.lib()
+        N.check(self._lib.sga_create(int(device), C.byref(self._h)), "sga_create")
+        self.device = int(device)
+        self.n = 0
+        self.R = 0
+        self.R_global = 0
+        self.replica0 = 0
+        self.n_ladders = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sga_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def use_stream(self, stream_handle: Optional[int]):
+        N.check(self._lib.sga_set_stream(self._h, C.c_void_p(stream_handle or 0)), "sga_set_stream")
+
+    def set_tuning(self, waves_per_replica: int = 0, sweeps_per_launch: int = 0):
+        N.check(self._lib.sga_set_tuning(self._h, int(waves_per_replica), int(sweeps_per_launch)),
+                "sga_set_tuning")
+
+    # ------------------------------------------------------------------ problem
+    def set_dense(self, J, h, storage: str = "auto"):
+        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8}[storage]
+        if _is_tensor(J):
+            if J.dim() != 2 or J.shape[0] != J.shape[1]:
+                raise AnnealingError("couplings must be a square matrix")
+            Jt = J.detach()
+            if Jt.dtype != torch.float32:
+                Jt = Jt.float()
+            if Jt.stride(1) != 1:
+                Jt = Jt.contiguous()
+            n, ld, jp, keep = Jt.shape[0], Jt.stride(0), C.c_void_p(Jt.data_ptr()), Jt
+        else:
+            Ja = np.ascontiguousarray(J, dtype=np.float32)
+            if Ja.ndim != 2 or Ja.shape[0] != Ja.shape[1]:
+                raise AnnealingError("couplings must be a square matrix")
+            n, ld, jp, keep = Ja.shape[0], Ja.shape[1], Ja.ctypes.data_as(C.c_void_p), Ja
+        hp, hk = _buf(h, np.float32, "float32")
+        if (hk.numel() if _is_tensor(hk) else hk.size) != n:
+            raise AnnealingError("external fields must have n entries")
+        N.check(self._lib.sga_set_dense(self._h, jp, int(ld), hp, int(n), sel), "sga_set_dense")
+        del keep
+        self.n, self.R = n, 0
+
+    def set_csr(self, rowptr, colidx, val, h):
+        rp, k1 = _buf(rowptr, np.int32, "int32")
+        ci, k2 = _buf(colidx, np.int32, "int32")
+        vp, k3 = _buf(val, np.float32, "float32")
+        hp, k4 = _buf(h, np.float32, "float32")
+        n = (k1.numel() if _is_tensor(k1) else k1.size) - 1
+        nnz = k2.numel() if _is_tensor(k2) else k2.size
+        N.check(self._lib.sga_set_csr(self._h, rp, ci, vp, hp, int(n), int(nnz)), "sga_set_csr")
+        self.n, self.R = n, 0
+
+    # ------------------------------------------------------------------ replicas
+    def init_replicas(self, R: int, seed: int = 0, s0=None, R_global: Optional[int] = None,
+                      replica0: int = 0):
+        Rg = R if R_global is None else int(R_global)
+        sp, keep = _buf(s0, np.int8, "int8")
+        if keep is not None:
+            cnt = keep.numel() if _is_tensor(keep) else keep.size
+            if cnt != R * self.n:
+                raise AnnealingError("s0 must be [R, n] int8")
+        N.check(self._lib.sga_init_replicas(self._h, int(R), Rg, int(replica0),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, sp),
+                "sga_init_replicas")
+        self.R, self.R_global, self.replica0, self.n_ladders = int(R), Rg, int(replica0), 0
+
+    def set_temperatures(self, T):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(T, np.float64), (self.R,)))
+        N.check(self._lib.sga_set_temperatures(self._h, t.ctypes.data_as(C.c_void_p)),
+                "sga_set_temperatures")
+
+    def set_ladder(self, slot_temps, n_ladders: int = 1):
+        t = np.ascontiguousarray(slot_temps, dtype=np.float64)
+        if t.size != self.R_global:
+            raise AnnealingError("slot_temps must have R_global entries")
+        N.check(self._lib.sga_set_ladder(self._h, t.ctypes.data_as(C.c_void_p), int(n_ladders)),
+                "sga_set_ladder")
+        self.n_ladders = int(n_ladders)
+
+    # ------------------------------------------------------------------ hot path
+    def sweep(self, n_sweeps: int = 1, site_mode: int = N.SITE_RANDOM, arith: int = N.ARITH_F64,
+              sched=None, replay_site=None, replay_u=None, energy_trace: bool = False,
+              trace: bool = False):
+        """n_sweeps Metropolis sweeps of every replica.
+
+        sched: None | [n_sweeps] (shared by all replicas) | [n_sweeps, R] temperatures.
+        Returns {"energy_trace": [n_sweeps, R] | None, "accept_trace", "dE_trace"}.
+        """
+        n_sweeps = int(n_sweeps)
+        sp, ss, rs, keep_s = None, 0, 0, None
+        if sched is not None:
+            keep_s = np.ascontiguousarray(sched, dtype=np.float64)
+            if keep_s.ndim == 1 and keep_s.shape[0] == n_sweeps:
+                ss, rs = 1, 0
+            elif keep_s.shape == (n_sweeps, self.R):
+                ss, rs = self.R, 1
+            else:
+                raise AnnealingError("sched must be [n_sweeps] or [n_sweeps, R]")
+            sp = keep_s.ctypes.data_as(C.c_void_p)
+        per = n_sweeps * self.n
+        rsp, k1 = _buf(replay_site, np.int32, "int32")
+        rup, k2 = _buf(replay_u, np.float32, "float32")
+        for k in (k1, k2):
+            if k is not None and (k.numel() if _is_tensor(k) else k.size) != self.R * per:
+                raise AnnealingError("replay arrays must be [R, n_sweeps*n]")
+        et = np.zeros((n_sweeps, self.R), np.float64) if energy_trace else None
+        at = np.zeros((self.R, per), np.uint8) if trace else None
+        dt = np.zeros((self.R, per), np.float64) if trace else None
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        N.check(self._lib.sga_sweep(self._h, n_sweeps, int(site_mode), int(arith), sp, ss, rs, rsp,
+                                    rup, ptr(et), ptr(at), ptr(dt)), "sga_sweep")
+        return {"energy_trace": et, "accept_trace": at, "dE_trace": dt}
+
+    def recompute_energies(self):
+        N.check(self._lib.sga_recompute_energies(self._h), "sga_recompute_energies")
+
+    def exchange(self, energies_global=None, start=None, u=None) -> int:
+        ep, k1 = _buf(energies_global, np.float64, "float64")
+        stp, k2 = _buf(None if start is None else np.atleast_1d(start), np.int32, "int32")
+        up, k3 = _buf(u, np.float64, "float64")
+        out = C.c_int(0)
+        N.check(self._lib.sga_exchange(self._h, ep, stp, up, C.byref(out)), "sga_exchange")
+        return int(out.value)
+
+    # ------------------------------------------------------------------ state access
+    def energies(self) -> np.ndarray:
+        out = np.zeros(self.R, np.float64)
+        N.check(self._lib.sga_get_energies(self._h, out.ctypes.data_as(C.c_void_p)),
+                "sga_get_energies")
+        return out
+
+    def energies_into(self, tensor):
+        """Copy the local energies into a float64 torch tensor (device-to-device on the GPU)."""
+        if tensor.dtype != torch.float64 or tensor.numel() != self.R or not tensor.is_contiguous():
+            raise AnnealingError("need a contiguous float64 tensor of R entries")
+        N.check(self._lib.sga_get_energies(self._h, C.c_void_p(tensor.data_ptr())),
+                "sga_get_energies")
+        return tensor
+
+    def temperatures(self) -> np.ndarray:
+        out = np.zeros(self.R, np.float64)
+        N.check(self._lib.sga_get_temperatures(self._h, out.ctypes.data_as(C.c_void_p)),
+                "sga_get_temperatures")
+        return out
+
+    def spins(self, r: Optional[int] = None) -> np.ndarray:
+        if r is None:
+            out = np.zeros((self.R, self.n), np.int8)
+            N.check(self._lib.sga_get_spins(self._h, -1, out.ctypes.data_as(C.c_void_p)),
+                    "sga_get_spins")
+            return out
+        out = np.zeros(self.n, np.int8)
+        N.check(self._lib.sga_get_spins(self._h, int(r), out.ctypes.data_as(C.c_void_p)),
+                "sga_get_spins")
+        return out
+
+    def set_spins(self, r: int, s):
+        a = np.ascontiguousarray(s, dtype=np.int8)
+        if a.size != self.n:
+            raise AnnealingError("spins must have n entries")
+        N.check(self._lib.sga_set_spins(self._h, int(r), a.ctypes.data_as(C.c_void_p)),
+                "sga_set_spins")
+
+    def best(self, r: Optional[int] = None, with_spins: bool = True):
+        """(energy, spins int8 [n] | None, local replica index)."""
+        e, idx = C.c_double(0.0), C.c_int(0)
+        s = np.zeros(self.n, np.int8) if with_spins else None
+        N.check(self._lib.sga_get_best(self._h, -1 if r is None else int(r), C.byref(e),
+                                       None if s is None else s.ctypes.data_as(C.c_void_p),
+                                       C.byref(idx)), "sga_get_best")
+        return float(e.value), s, int(idx.value)
+
+    def reset_best(self):
+        N.check(self._lib.sga_reset_best(self._h), "sga_reset_best")
+
+    def stats(self):
+        acc, att = np.zeros(self.R, np.int64), np.zeros(self.R, np.int64)
+        N.check(self._lib.sga_get_stats(self._h, acc.ctypes.data_as(C.c_void_p),
+                                        att.ctypes.data_as(C.c_void_p)), "sga_get_stats")
+        return acc, att
+
+    def slot_map(self) -> np.ndarray:
+        out = np.zeros(self.R_global, np.int32)
+        N.check(self._lib.sga_get_slot_map(self._h, out.ctypes.data_as(C.c_void_p)),
+                "sga_get_slot_map")
+        return out
+
+    def exchange_stats(self):
+        a, b = np.zeros(self.R_global, np.int64), np.zeros(self.R_global, np.int64)
+        N.check(self._lib.sga_get_exchange_stats(self._h, a.ctypes.data_as(C.c_void_p),
+                                                 b.ctypes.data_as(C.c_void_p)),
+                "sga_get_exchange_stats")
+        return a, b
+
+    def counters(self):
+        s, r = C.c_uint32(0), C.c_uint32(0)
+        N.check(self._lib.sga_get_sweep_counter(self._h, C.byref(s), C.byref(r)))
+        return int(s.value), int(r.value)
+
+    def set_counters(self, sweeps_done: int, exchange_rounds: int):
+        N.check(self._lib.sga_set_sweep_counter(self._h, int(sweeps_done), int(exchange_rounds)))
+
+    # ------------------------------------------------------------------ measurement
+    def enable_timing(self, on: bool = True):
+        N.check(self._lib.sga_enable_timing(self._h, 1 if on else 0))
+
+    def kernel_time(self, reset: bool = True):
+        """(launches, total_ms) of the sweep-kernel launches since the last reset."""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        N.check(self._lib.sga_get_kernel_time(self._h, C.byref(n), C.byref(ms), 1 if reset else 0))
+        return int(n.value), float(ms.value)
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(512)
+        N.check(self._lib.sga_describe(self._h, buf, 512))
+        return buf.value.decode()
+
+
+def op_pt_exchange(device: int, spins, energies, temps, u=None, seed: int = 0, round_: int = 0):
+    """Operator-form PT exchange on fp32 buffers, in place (reference cuda_kernels.py:415-443)."""
+    lib = N.lib()
+    sp, k1 = _buf(spins, np.float32, "float32")
+    ep, k2 = _buf(energies, np.float32, "float32")
+    tp, k3 = _buf(temps, np.float32, "float32")
+    up, k4 = _buf(u, np.float32, "float32")
+    if _is_tensor(spins):
+        if k1.data_ptr() != spins.data_ptr() or k2.data_ptr() != energies.data_ptr():
+            raise AnnealingError("spins/energies must be contiguous float32 (updated in place)")
+        R, n = spins.shape
+    else:
+        if k1 is not spins or k2 is not energies:
+            raise AnnealingError("spins/energies must be contiguous float32 (updated in place)")
+        R, n = k1.shape
+    out = C.c_int(0)
+    N.check(lib.sga_op_pt_exchange(int(device), sp, ep, tp, up, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                   int(round_), int(R), int(n), C.byref(out)), "sga_op_pt_exchange")
+    return int(out.value)

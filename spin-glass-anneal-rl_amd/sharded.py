@@ -1,0 +1,88 @@
+"""Replica sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference has no communication backend at all (`communication_backend`
+is a validated string, annealing/multi_gpu.py:26,41-43; "multi-GPU" is a thread pool,
+:148,201,264).  This is the MI355X design for its `replica_exchange` strategy
+(multi_gpu.py:110-132, 233-308):
+
+* replicas are independent between exchange steps, so rank k owns global replicas
+  [k*R_local, (k+1)*R_local) and a full copy of the couplings -- no data-path collective
+  inside a sweep;
+* an exchange round needs only the R_global energies: one all-gather of R_local doubles per
+  rank (RCCL over xGMI; 8 KiB per rank at 1024 replicas -- latency bound, link bandwidth is
+  irrelevant).  Every rank then evaluates the same Philox-seeded decisions on the gathered
+  vector and swaps temperature *labels*; spins never cross a link;
+* at the end the global best is found with one all-gather of the per-rank best energies and
+  one broadcast of the winner's configuration.
+
+The engine argument only needs the small surface used below, which lets the coordination
+logic be exercised on CPU with a stand-in engine (tests/test_sharded_gloo.py).
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+class ShardedTempering:
+    def __init__(self, engine, R_local: int, rank: int = 0, world: int = 1, seed: int = 0,
+                 slot_temps=None, n_ladders: int = 1, dist=None, device=None, s0=None):
+        self.engine = engine
+        self.R_local, self.rank, self.world = int(R_local), int(rank), int(world)
+        self.R_global = self.R_local * self.world
+        self.replica0 = self.rank * self.R_local
+        self.dist = dist if world > 1 else None
+        self.device = device if device is not None else torch.device("cpu")
+        engine.init_replicas(self.R_local, seed=seed, s0=s0, R_global=self.R_global,
+                             replica0=self.replica0)
+        if slot_temps is not None:
+            t = np.asarray(slot_temps, np.float64)
+            if t.size != self.R_global:
+                raise ValueError("slot_temps must cover the global replica set")
+            engine.set_ladder(t, n_ladders)
+        self._local_E = torch.zeros(self.R_local, dtype=torch.float64, device=self.device)
+        self._all_E = torch.zeros(self.R_global, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ hot path
+    def sweep(self, n_sweeps: int = 1, **kw):
+        return self.engine.sweep(n_sweeps, **kw)
+
+    def gather_energies(self) -> torch.Tensor:
+        """All ranks' energies, indexed by global replica id."""
+        self.engine.energies_into(self._local_E)
+        if self.dist is None:
+            self._all_E.copy_(self._local_E)
+            return self._all_E
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_gather_into_tensor(self._all_E, self._local_E)
+        else:
+            parts = list(self._all_E.chunk(self.world))
+            self.dist.all_gather(parts, self._local_E)
+        return self._all_E
+
+    def exchange(self) -> int:
+        """One replica-exchange round over the global ladder(s); identical on every rank."""
+        if self.dist is None:
+            return self.engine.exchange()
+        return self.engine.exchange(energies_global=self.gather_energies())
+
+    # ------------------------------------------------------------------ results
+    def global_best(self):
+        """(energy, spins int8 [n], global replica id) of the best configuration seen."""
+        e, s, idx = self.engine.best()
+        if self.dist is None:
+            return e, s, self.replica0 + idx
+        mine = torch.tensor([e], dtype=torch.float64, device=self.device)
+        allb = torch.zeros(self.world, dtype=torch.float64, device=self.device)
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_gather_into_tensor(allb, mine)
+        else:
+            self.dist.all_gather(list(allb.chunk(self.world)), mine)
+        winner = int(torch.argmin(allb).item())  # first minimum: lowest rank wins ties
+        payload = torch.zeros(s.size + 1, dtype=torch.int32, device=self.device)
+        if self.rank == winner:
+            payload[:-1] = torch.from_numpy(s.astype(np.int32)).to(self.device)
+            payload[-1] = self.replica0 + idx
+        self.dist.broadcast(payload, src=winner)
+        out = payload.cpu().numpy()
+        return float(allb[winner].item()), out[:-1].astype(np.int8), int(out[-1])
