@@ -50,9 +50,30 @@ def make_sk_instance(n, seed, device):
     return J
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=4, sweeps=1):
-    import oracle
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" | "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                cores = min(cores, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get("SGA_CPU_THREADS", cores))
+
+
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=1):
+    import oracle
+    cores = host_cores()
     R = max(cores * budget_replicas_per_core, 1)
     prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
     oracle.set_exact_f32(True)  # +-1 couplings: fp32 SIMD accumulation is exact

@@ -167,12 +167,14 @@ namespace {
 
 int elems_per_chunk(bool i8) { return i8 ? 1024 : 256; }
 
-// Pick waves-per-replica W and chunks-per-wave CPW for a dense row of C chunks so that
-// R*W waves fill the chip (~16 waves per CU on 256 CUs) with little row padding.
+// Pick waves-per-replica W and chunks-per-wave CPW for a dense row of C chunks.  Measured on
+// MI355X at n = 10^4, R = 1024 (profiles/r01_geometry_sweep.md): full occupancy (R*W ~ 32
+// waves per CU) is best as long as every wave keeps >= 4 KiB of the row in flight and W
+// balances the four SIMDs; row padding is paid on every read, so it dominates the cost.
 bool choose_geometry(int n, bool i8, int R, int forced_waves, int &W, int &CPW) {
     const int epc = elems_per_chunk(i8);
     const int C = (n + epc - 1) / epc;
-    double target = 4096.0 / std::max(R, 1);
+    double target = 8192.0 / std::max(R, 1);
     target = std::min(16.0, std::max(1.0, target));
     double best_cost = 1e30;
     W = CPW = 0;
@@ -182,7 +184,9 @@ bool choose_geometry(int n, bool i8, int R, int forced_waves, int &W, int &CPW) 
         if (cpw > sga::MAX_CPW) continue;
         if (w > C && w > 1) continue;
         const double pad = (double)(w * cpw - C) / C;
-        const double cost = pad + 0.05 * std::fabs(std::log2(w / target));
+        double cost = 4.0 * pad + 0.05 * std::fabs(std::log2(w / target));
+        if (cpw < 4 && w > 1) cost += 0.5 * (4 - cpw);   // too little in flight per wave
+        if (w > 2 && (w % 4) != 0) cost += 0.03;          // uneven over the 4 SIMDs
         if (cost < best_cost) {
             best_cost = cost;
             W = w;
