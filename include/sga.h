@@ -21,6 +21,10 @@
  *                                 annealing/cuda_kernels.py:326-369 (+ fallback :415-443) and
  *                                 ParallelTempering._nearest_neighbor_exchange /
  *                                 _attempt_single_exchange, annealing/parallel_tempering.py:214-258
+ *   sga_local_fields              IsingModel.get_local_field, core/ising_model.py:176-185
+ *   sga_flip                      IsingModel.flip_spin, core/ising_model.py:125-147
+ *   sga_update                    SpinDynamics.single_spin_update / _metropolis_update,
+ *                                 core/spin_dynamics.py:61-71,131-152
  *   sga_get_best                  best tracking in GPUAnnealer.anneal, gpu_annealer.py:151-153,
  *                                 and ParallelTempering._find_best_solution, :303-313
  *   sga_get_stats                 SpinDynamics.n_accepted / n_rejected, spin_dynamics.py:44-45
@@ -108,6 +112,15 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
               const int32_t *replay_site, const float *replay_u, double *energy_trace,
               uint8_t *accept_trace, double *dE_trace);
 
+/* Single-site operators on local replica r (the reference's per-spin API).
+ * sga_local_fields: out[k] = fp32(J[sites[k],:].s) + h[sites[k]] as a double.
+ * sga_flip: unconditional flip of `site`; *dE = 2 s_i field; the tracked energy follows.
+ * sga_update: one Metropolis update at `site` with uniform u at temperature T. */
+int sga_local_fields(sga_engine *e, int r, const int32_t *sites, int count, double *out);
+int sga_flip(sga_engine *e, int r, int site, double *dE);
+int sga_update(sga_engine *e, int r, int site, double T, float u, int arith, int *accepted,
+               double *dE);
+
 /* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s */
 int sga_recompute_energies(sga_engine *e);
 
@@ -146,6 +159,8 @@ int sga_get_stats(sga_engine *e, int64_t *accepted /* [R_local] */,
 int sga_get_slot_map(sga_engine *e, int32_t *slot_to_rep /* [R_global] */);
 int sga_get_exchange_stats(sga_engine *e, int64_t *attempts /* [R_global] */,
                            int64_t *accepts /* [R_global] */);
+/* Philox key of all later draws (sweeps, exchanges); the counters are unchanged. */
+int sga_set_seed(sga_engine *e, uint64_t seed);
 int sga_get_sweep_counter(sga_engine *e, uint32_t *sweeps_done, uint32_t *exchange_rounds);
 int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange_rounds);
 

@@ -8,6 +8,24 @@ from . import _native
 from .exceptions import (AnnealingError, ConfigurationError, DeviceError, ModelError,
                          ResourceError, SpinGlassError, ValidationError)
 from .engine import AnnealEngine, op_pt_exchange
+from .temperature_scheduler import (ScheduleConfig, ScheduleType, TemperatureScheduler,
+                                    temperature_ladder)
+from .result import AnnealingResult
+from .ising_model import IsingModel, IsingModelConfig
+from .spin_dynamics import SpinDynamics, UpdateRule
+from .gpu_annealer import GPUAnnealer, GPUAnnealerConfig
+from .parallel_tempering import ParallelTempering, ParallelTemperingConfig
+from .kernel_manager import CUDAKernelManager, GPUMemoryOptimizer, HIPKernelManager
+from .scheduler import SpinGlassScheduler
+from .sharded import LocalShardedTempering, ShardedTempering
+from .multi_gpu import MultiGPUAnnealer, MultiGPUConfig
 
-__all__ = ["_native", "AnnealEngine", "op_pt_exchange", "SpinGlassError", "AnnealingError",
-           "DeviceError", "ModelError", "ValidationError", "ConfigurationError", "ResourceError"]
+__all__ = [
+    "_native", "AnnealEngine", "op_pt_exchange", "SpinGlassError", "AnnealingError",
+    "DeviceError", "ModelError", "ValidationError", "ConfigurationError", "ResourceError",
+    "ScheduleType", "ScheduleConfig", "TemperatureScheduler", "temperature_ladder",
+    "AnnealingResult", "IsingModel", "IsingModelConfig", "SpinDynamics", "UpdateRule",
+    "GPUAnnealer", "GPUAnnealerConfig", "ParallelTempering", "ParallelTemperingConfig",
+    "HIPKernelManager", "CUDAKernelManager", "GPUMemoryOptimizer", "SpinGlassScheduler",
+    "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig",
+]

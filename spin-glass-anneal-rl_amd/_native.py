@@ -31,6 +31,9 @@ SYMBOLS = [
     ("sga_set_temperatures", _i, [_p, _p]),
     ("sga_set_ladder", _i, [_p, _p, _i]),
     ("sga_sweep", _i, [_p, _i, _i, _i, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    ("sga_local_fields", _i, [_p, _i, _p, _i, _p]),
+    ("sga_flip", _i, [_p, _i, _i, C.POINTER(_d)]),
+    ("sga_update", _i, [_p, _i, _i, _d, C.c_float, _i, C.POINTER(_i), C.POINTER(_d)]),
     ("sga_recompute_energies", _i, [_p]),
     ("sga_exchange", _i, [_p, _p, _p, _p, C.POINTER(_i)]),
     ("sga_op_pt_exchange", _i, [_i, _p, _p, _p, _p, _u64, _u32, _i, _i, C.POINTER(_i)]),
@@ -43,6 +46,7 @@ SYMBOLS = [
     ("sga_get_stats", _i, [_p, _p, _p]),
     ("sga_get_slot_map", _i, [_p, _p]),
     ("sga_get_exchange_stats", _i, [_p, _p, _p]),
+    ("sga_set_seed", _i, [_p, _u64]),
     ("sga_get_sweep_counter", _i, [_p, C.POINTER(_u32), C.POINTER(_u32)]),
     ("sga_set_sweep_counter", _i, [_p, _u32, _u32]),
     ("sga_enable_timing", _i, [_p, _i]),

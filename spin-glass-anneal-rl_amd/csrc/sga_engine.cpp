@@ -629,6 +629,84 @@ int sga_recompute_energies(sga_engine *e) {
     return recompute_energy_range(e, 0, e->R);
 }
 
+static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int op, double T,
+                    float u, int arith, double *out_host, int out_count) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0 || r < 0 || r >= e->R) return fail(SGA_ERR_INVALID, "bad replica index");
+    if (!sites || count <= 0) return fail(SGA_ERR_INVALID, "no sites");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    std::vector<int32_t> hs((size_t)count);
+    if (is_device_ptr(sites))
+        HIPCHK(hipMemcpy(hs.data(), sites, sizeof(int32_t) * hs.size(), hipMemcpyDeviceToHost));
+    else
+        std::memcpy(hs.data(), sites, sizeof(int32_t) * hs.size());
+    for (int32_t v : hs)
+        if (v < 0 || v >= e->n) return fail(SGA_ERR_INVALID, "site index out of range");
+    int32_t *d_sites = nullptr;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_sites, sizeof(int32_t) * hs.size()));
+    hipError_t he = hipMalloc(&d_out, sizeof(double) * (size_t)std::max(out_count, 2));
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(d_sites, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        sga::PointArgs a{};
+        a.J = e->J_packed;
+        a.rowptr = e->rowptr;
+        a.colidx = e->colidx;
+        a.val = e->val;
+        a.h = e->h;
+        a.diag = e->diag;
+        a.spins = e->spins + (long long)r * e->sstride;
+        a.energy = e->energy + r;
+        a.n_accepted = e->n_acc + r;
+        a.sites = d_sites;
+        a.out = d_out;
+        a.ld = e->ld;
+        a.n = e->n;
+        a.count = count;
+        a.op = op;
+        a.arith = arith;
+        a.T = T;
+        a.u = u;
+        he = sga::launch_point_op(a, e->csr, e->want_i8, st);
+    }
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(out_host, d_out, sizeof(double) * (size_t)out_count, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    (void)hipFree(d_sites);
+    (void)hipFree(d_out);
+    HIPCHK(he);
+    return SGA_OK;
+}
+
+int sga_local_fields(sga_engine *e, int r, const int32_t *sites, int count, double *out) {
+    if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
+    if (is_device_ptr(out)) return fail(SGA_ERR_INVALID, "out must be a host buffer");
+    return point_op(e, r, sites, count, 0, 1.0, 0.0f, SGA_ARITH_F64, out, count);
+}
+
+int sga_flip(sga_engine *e, int r, int site, double *dE) {
+    double o[2] = {0.0, 0.0};
+    const int32_t s = site;
+    int rc = point_op(e, r, &s, 1, 1, 1.0, 0.0f, SGA_ARITH_F64, o, 2);
+    if (rc == SGA_OK && dE) *dE = o[0];
+    return rc;
+}
+
+int sga_update(sga_engine *e, int r, int site, double T, float u, int arith, int *accepted,
+               double *dE) {
+    if (arith != SGA_ARITH_F64 && arith != SGA_ARITH_F32) return fail(SGA_ERR_INVALID, "bad arith");
+    double o[2] = {0.0, 0.0};
+    const int32_t s = site;
+    int rc = point_op(e, r, &s, 1, 2, T, u, arith, o, 2);
+    if (rc == SGA_OK) {
+        if (accepted) *accepted = o[1] != 0.0;
+        if (dE) *dE = o[0];
+    }
+    return rc;
+}
+
 int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *start,
                  const double *u, int *n_accepted) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
@@ -859,6 +937,12 @@ int sga_get_exchange_stats(sga_engine *e, int64_t *attempts, int64_t *accepts) {
         HIPCHK(hipMemcpyAsync(accepts, e->ex_accepts, sizeof(int64_t) * e->Rg, hipMemcpyDefault,
                               e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
+int sga_set_seed(sga_engine *e, uint64_t seed) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    e->seed = seed;
     return SGA_OK;
 }
 

@@ -93,6 +93,25 @@ hipError_t launch_gather_diag_csr(const int32_t *rowptr, const int32_t *colidx, 
 hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
                             int8_t *best_spins, int sstride, int R, hipStream_t st);
 
+// single-site operators (IsingModel.get_local_field / flip_spin, SpinDynamics.single_spin_update)
+struct PointArgs {
+    const void *J;
+    const int32_t *rowptr, *colidx;
+    const float *val;
+    const float *h, *diag;
+    int8_t *spins;       // the replica's row [sstride]
+    double *energy;      // the replica's tracked energy
+    unsigned long long *n_accepted;
+    const int32_t *sites;  // [count]
+    double *out;           // [count] fields (op 0) | out[0] = dE, out[1] = accepted (ops 1, 2)
+    long long ld;
+    int n, count, op;      // op 0: fields, 1: flip, 2: metropolis
+    int arith;
+    double T;
+    float u;
+};
+hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st);
+
 // operator-form PT exchange (cuda_kernels.py:415-443): decide sequentially, then permute rows
 hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, const float *temps,
                               const float *u, int32_t *src_of_pos, int *n_accepted,

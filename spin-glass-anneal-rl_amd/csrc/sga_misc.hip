@@ -344,6 +344,83 @@ hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Single-site operators: one workgroup, one coupling row per site, spins read from HBM.
+// ---------------------------------------------------------------------------------------
+template <typename JT, bool CSR>
+__global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
+    constexpr int EPL = 16 / sizeof(JT), EPC = 64 * EPL;
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = 0; k < a.count; ++k) {
+        const int site = a.sites[k];
+        double acc = 0.0;
+        if constexpr (CSR) {
+            for (int j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
+                acc += (double)(a.val[j] * (float)a.spins[a.colidx[j]]);
+        } else {
+            const JT *row = reinterpret_cast<const JT *>(a.J) + (long long)site * a.ld;
+            for (long long c = (long long)tid * EPL; c < a.ld; c += 4 * EPC) {
+                if constexpr (sizeof(JT) == 4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(row + c);
+                    const int sw = *reinterpret_cast<const int *>(a.spins + c);
+                    acc += (double)(x.x * (float)(int8_t)(sw));
+                    acc += (double)(x.y * (float)(int8_t)(sw >> 8));
+                    acc += (double)(x.z * (float)(int8_t)(sw >> 16));
+                    acc += (double)(x.w * (float)(sw >> 24));
+                } else {
+                    const int4 x = *reinterpret_cast<const int4 *>(row + c);
+                    const int4 sv = *reinterpret_cast<const int4 *>(a.spins + c);
+                    int t = __builtin_amdgcn_sdot4(x.x, sv.x, 0, false);
+                    t = __builtin_amdgcn_sdot4(x.y, sv.y, t, false);
+                    t = __builtin_amdgcn_sdot4(x.z, sv.z, t, false);
+                    t = __builtin_amdgcn_sdot4(x.w, sv.w, t, false);
+                    acc += (double)t;
+                }
+            }
+        }
+        const double ws = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) red[w] = ws;
+        __syncthreads();
+        const float dot = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        if (a.op == 0) {
+            if (tid == 0) a.out[k] = (double)dot + (double)a.h[site];  // ising_model.py:176-185
+            continue;
+        }
+        const int si = a.spins[site];
+        double dE;
+        bool flip;
+        if (a.op == 1) {  // IsingModel.flip_spin, ising_model.py:125-147
+            dE = 2.0 * (double)si * ((double)dot + (double)a.h[site]);
+            flip = true;
+        } else {
+            flip = metropolis_accept(a.arith, dot, si, a.h[site], a.diag[site], a.T, a.u, dE);
+        }
+        __syncthreads();  // every thread has read s[site]
+        if (tid == 0) {
+            if (flip) {
+                a.spins[site] = (int8_t)(-si);
+                *a.energy += dE;
+                if (a.op == 2) *a.n_accepted += 1;
+            }
+            a.out[0] = dE;
+            a.out[1] = flip ? 1.0 : 0.0;
+        }
+    }
+}
+
+hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st) {
+    if (csr)
+        hipLaunchKernelGGL((point_op_kernel<float, true>), dim3(1), dim3(256), 0, st, a);
+    else if (j_is_i8)
+        hipLaunchKernelGGL((point_op_kernel<int8_t, false>), dim3(1), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((point_op_kernel<float, false>), dim3(1), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Operator-form exchange, annealing/cuda_kernels.py:415-443: the pairs are visited in order
 // and each decision sees the swaps before it, so the decisions are one serial chain (one
 // thread); the row permutation they compose is then applied by the whole grid.

@@ -170,6 +170,26 @@ class AnnealEngine:
                                     rup, ptr(et), ptr(at), ptr(dt)), "sga_sweep")
         return {"energy_trace": et, "accept_trace": at, "dE_trace": dt}
 
+    # single-site operators (the reference's per-spin API)
+    def local_fields(self, r: int, sites) -> np.ndarray:
+        idx = np.ascontiguousarray(np.atleast_1d(sites), dtype=np.int32)
+        out = np.zeros(idx.size, np.float64)
+        N.check(self._lib.sga_local_fields(self._h, int(r), idx.ctypes.data_as(C.c_void_p),
+                                           int(idx.size), out.ctypes.data_as(C.c_void_p)),
+                "sga_local_fields")
+        return out
+
+    def flip(self, r: int, site: int) -> float:
+        d = C.c_double(0.0)
+        N.check(self._lib.sga_flip(self._h, int(r), int(site), C.byref(d)), "sga_flip")
+        return float(d.value)
+
+    def update(self, r: int, site: int, T: float, u: float, arith: int = N.ARITH_F64):
+        acc, d = C.c_int(0), C.c_double(0.0)
+        N.check(self._lib.sga_update(self._h, int(r), int(site), float(T), float(u), int(arith),
+                                     C.byref(acc), C.byref(d)), "sga_update")
+        return bool(acc.value), float(d.value)
+
     def recompute_energies(self):
         N.check(self._lib.sga_recompute_energies(self._h), "sga_recompute_energies")
 
@@ -255,6 +275,9 @@ class AnnealEngine:
         s, r = C.c_uint32(0), C.c_uint32(0)
         N.check(self._lib.sga_get_sweep_counter(self._h, C.byref(s), C.byref(r)))
         return int(s.value), int(r.value)
+
+    def set_seed(self, seed: int):
+        N.check(self._lib.sga_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def set_counters(self, sweeps_done: int, exchange_rounds: int):
         N.check(self._lib.sga_set_sweep_counter(self._h, int(sweeps_done), int(exchange_rounds)))

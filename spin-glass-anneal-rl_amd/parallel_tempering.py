@@ -1,0 +1,161 @@
+"""ParallelTempering: replica exchange Monte Carlo with every replica resident on the GPU.
+
+Host loop of the reference's spin_glass_rl/annealing/parallel_tempering.py:16-313: geometric /
+linear / exponential ladder with index 0 the hottest, one Metropolis sweep of every replica per
+step, nearest-neighbour exchanges every `exchange_interval` sweeps (skipping sweep 0) with a
+random even/odd start, statistics and best-over-replicas on record sweeps only.  All replicas
+advance in one kernel call between two events; an exchange swaps temperature labels on the
+device instead of moving spin tensors (same Markov chain, no copies).
+"""
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .engine import AnnealEngine
+from .exceptions import AnnealingError, ConfigurationError
+from .gpu_annealer import fresh_seed
+from .ising_model import IsingModel, _device_index
+from .result import AnnealingResult
+from .spin_dynamics import UpdateRule, require_metropolis
+from .temperature_scheduler import temperature_ladder
+
+
+@dataclass
+class ParallelTemperingConfig:
+    n_replicas: int = 8
+    n_sweeps: int = 1000
+    temp_min: float = 0.1
+    temp_max: float = 10.0
+    temp_distribution: str = "geometric"
+    exchange_interval: int = 10
+    exchange_method: str = "nearest_neighbor"
+    n_threads: Optional[int] = None  # accepted for compatibility; replicas run on the GPU
+    record_interval: int = 10
+    random_seed: Optional[int] = None
+    # build-specific
+    coupling_storage: str = "auto"
+    device_index: Optional[int] = None
+
+
+class ParallelTempering:
+    def __init__(self, config: ParallelTemperingConfig):
+        if config.n_replicas < 2:
+            raise ConfigurationError("parallel tempering needs at least 2 replicas")
+        if config.exchange_interval <= 0 or config.record_interval <= 0 or config.n_sweeps <= 0:
+            raise ConfigurationError("intervals and n_sweeps must be positive")
+        self.config = config
+        self.temperatures = temperature_ladder(config.n_replicas, config.temp_min,
+                                               config.temp_max, config.temp_distribution)
+        R = config.n_replicas
+        self.exchange_attempts = np.zeros((R - 1,))
+        self.exchange_accepts = np.zeros((R - 1,))
+        self.energy_histories: List[List[float]] = [[] for _ in range(R)]
+        self.temp_histories: List[List[float]] = [[] for _ in range(R)]
+        self.slot_acceptance = np.zeros(R)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.use_cuda = self.device.type == "cuda"
+
+    def run(self, model: IsingModel, update_rule: UpdateRule = UpdateRule.METROPOLIS,
+            _replay=None) -> AnnealingResult:
+        """`_replay`: parity-test hook, dict(s0, site[ns,R,n], u[ns,R,n], exch_start, exch_u)
+        recorded from the reference, replacing every Philox draw."""
+        require_metropolis(update_rule)
+        cfg = self.config
+        if cfg.exchange_method != "nearest_neighbor":
+            raise AnnealingError("only exchange_method='nearest_neighbor' runs on the HIP engine")
+        t_start = time.time()
+        R, n = cfg.n_replicas, model.n_spins
+        temps = np.asarray(self.temperatures, np.float64)
+        dev_idx = cfg.device_index if cfg.device_index is not None else _device_index(model.device)
+        best_energy, best_configuration = float("inf"), None
+        acc_slot, att_slot = np.zeros(R, np.int64), np.zeros(R, np.int64)
+        with AnnealEngine(dev_idx) as eng:
+            model.load_into(eng, storage=cfg.coupling_storage)
+            eng.init_replicas(R, seed=fresh_seed(cfg.random_seed),
+                              s0=None if _replay is None else _replay["s0"])
+            eng.set_ladder(temps, 1)
+            slot_to_rep = np.arange(R, dtype=np.int32)
+            acc_prev = np.zeros(R, np.int64)
+            rnd = ucur = 0
+            sweep = 0
+            while sweep < cfg.n_sweeps:
+                # advance to the next sweep index that carries an event
+                stop = sweep
+                while stop < cfg.n_sweeps - 1 and not self._event(stop):
+                    stop += 1
+                count = stop - sweep + 1
+                if _replay is None:
+                    eng.sweep(count)
+                else:
+                    inv = np.argsort(slot_to_rep)
+                    site = _replay["site"][sweep:stop + 1][:, inv].transpose(1, 0, 2).reshape(R, -1)
+                    u = _replay["u"][sweep:stop + 1][:, inv].transpose(1, 0, 2).reshape(R, -1)
+                    eng.sweep(count, site_mode=N.SITE_REPLAY, replay_site=site, replay_u=u)
+                # per-slot acceptance bookkeeping (the reference's SpinDynamics stay with slots)
+                acc_now = eng.stats()[0]
+                acc_slot += (acc_now - acc_prev)[slot_to_rep]
+                att_slot += count * n
+                acc_prev = acc_now
+                if stop % cfg.exchange_interval == 0 and stop > 0:  # reference :113
+                    if _replay is None:
+                        eng.exchange()
+                    else:
+                        start = int(_replay["exch_start"][rnd])
+                        npairs = len(range(start, R - 1, 2))
+                        uu = np.zeros(R // 2)
+                        uu[:npairs] = _replay["exch_u"][ucur:ucur + npairs]
+                        eng.exchange(start=[start], u=uu)
+                        ucur += npairs
+                    rnd += 1
+                    slot_to_rep = eng.slot_map()
+                if stop % cfg.record_interval == 0:  # reference :117-125
+                    en = eng.energies()[slot_to_rep]
+                    for i in range(R):
+                        self.energy_histories[i].append(float(en[i]))
+                        self.temp_histories[i].append(float(temps[i]))
+                    i_best = int(np.argmin(en))
+                    if en[i_best] < best_energy:
+                        best_energy = float(en[i_best])
+                        best_configuration = eng.spins(int(slot_to_rep[i_best]))
+                sweep = stop + 1
+            att, acc = eng.exchange_stats()
+            self.exchange_attempts = att[:R - 1].astype(np.float64)
+            self.exchange_accepts = acc[:R - 1].astype(np.float64)
+            self.final_spins = eng.spins()[slot_to_rep]
+        self.slot_acceptance = acc_slot / np.maximum(att_slot, 1)
+        total_time = time.time() - t_start
+        return AnnealingResult(
+            best_configuration=torch.from_numpy(best_configuration.astype(np.float32)),
+            best_energy=best_energy, energy_history=self.energy_histories[0],
+            temperature_history=self.temp_histories[0],
+            acceptance_rate_history=[float(x) for x in self.slot_acceptance],
+            total_time=total_time, n_sweeps=cfg.n_sweeps, algorithm="parallel_tempering",
+            device=f"cuda:{dev_idx}", random_seed=cfg.random_seed)
+
+    def _event(self, sweep: int) -> bool:
+        c = self.config
+        return (sweep % c.exchange_interval == 0 and sweep > 0) or sweep % c.record_interval == 0
+
+    def get_exchange_rates(self) -> np.ndarray:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = np.where(self.exchange_attempts > 0, self.exchange_accepts / self.exchange_attempts, 0.0)
+        return r
+
+    def get_statistics(self) -> Dict:
+        rates = self.get_exchange_rates()
+        finals = [h[-1] if h else float("inf") for h in self.energy_histories]
+        return {"n_replicas": self.config.n_replicas, "temperatures": self.temperatures,
+                "exchange_rates": rates.tolist(), "mean_exchange_rate": float(np.mean(rates)),
+                "final_energies": finals, "best_energy": min(finals),
+                "energy_range": max(finals) - min(finals),
+                "total_exchanges_attempted": self.exchange_attempts.sum(),
+                "total_exchanges_accepted": self.exchange_accepts.sum()}
+
+    def __repr__(self) -> str:
+        c = self.config
+        return (f"ParallelTempering(n_replicas={c.n_replicas}, "
+                f"temp_range=[{c.temp_min:.2f}, {c.temp_max:.2f}], n_sweeps={c.n_sweeps})")

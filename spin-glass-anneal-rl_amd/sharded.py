@@ -86,3 +86,46 @@ class ShardedTempering:
         self.dist.broadcast(payload, src=winner)
         out = payload.cpu().numpy()
         return float(allb[winner].item()), out[:-1].astype(np.int8), int(out[-1])
+
+
+class LocalShardedTempering:
+    """The same replica sharding driven from ONE process that owns several GPUs.
+
+    Used when the caller is not running under torchrun (e.g. MultiGPUAnnealer constructed in
+    a plain script): one engine per GPU, launches are asynchronous so all GPUs sweep
+    concurrently, and the exchange step gathers the R_global energies through the host
+    (a few KiB) instead of RCCL.  Decisions and results are identical to ShardedTempering.
+    """
+
+    def __init__(self, engines, R_local: int, seed: int = 0, slot_temps=None, n_ladders: int = 1,
+                 s0=None):
+        self.engines = list(engines)
+        self.world = len(self.engines)
+        self.R_local = int(R_local)
+        self.R_global = self.R_local * self.world
+        for k, e in enumerate(self.engines):
+            part = None if s0 is None else s0[k * R_local:(k + 1) * R_local]
+            e.init_replicas(self.R_local, seed=seed, s0=part, R_global=self.R_global,
+                            replica0=k * self.R_local)
+            if slot_temps is not None:
+                e.set_ladder(np.asarray(slot_temps, np.float64), n_ladders)
+
+    def sweep(self, n_sweeps: int = 1):
+        for e in self.engines:  # launches return immediately: the GPUs overlap
+            e.sweep(n_sweeps)
+
+    def gather_energies(self) -> np.ndarray:
+        return np.concatenate([e.energies() for e in self.engines])
+
+    def exchange(self) -> int:
+        if self.world == 1:
+            return self.engines[0].exchange()
+        all_e = self.gather_energies()
+        counts = [e.exchange(energies_global=all_e) for e in self.engines]
+        assert len(set(counts)) == 1, "ranks disagree on the exchange decisions"
+        return counts[0]
+
+    def global_best(self):
+        bests = [e.best() for e in self.engines]
+        k = int(np.argmin([b[0] for b in bests]))
+        return bests[k][0], bests[k][1], k * self.R_local + bests[k][2]

@@ -1,0 +1,130 @@
+"""SpinDynamics: single-replica Monte-Carlo driver over the HIP engine.
+
+API of the reference's spin_glass_rl/core/spin_dynamics.py:11-429 for the Metropolis rule
+(`sweep`, `single_spin_update`, acceptance statistics, histories).  A sweep is one kernel
+launch (n random-site updates, Philox stream); the reference's Glauber / heat-bath / Wolff
+rules are not on the accelerated path yet and raise.
+"""
+from enum import Enum
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .exceptions import AnnealingError
+from .ising_model import IsingModel
+
+
+class UpdateRule(Enum):
+    METROPOLIS = "metropolis"
+    GLAUBER = "glauber"
+    HEAT_BATH = "heat_bath"
+    WOLFF = "wolff"
+
+
+def require_metropolis(rule: UpdateRule) -> None:
+    if rule != UpdateRule.METROPOLIS:
+        raise AnnealingError(
+            f"update rule '{rule.value}' is not implemented in the HIP engine (Metropolis only)")
+
+
+class SpinDynamics:
+    def __init__(self, model: IsingModel, temperature: float = 1.0,
+                 update_rule: UpdateRule = UpdateRule.METROPOLIS,
+                 random_seed: Optional[int] = None):
+        require_metropolis(update_rule)
+        self.model = model
+        self.temperature = temperature
+        self.update_rule = update_rule
+        self._rng = np.random.default_rng(random_seed)
+        self._seed = int(self._rng.integers(0, 2 ** 63))
+        self._sweeps = 0
+        self.n_accepted = 0
+        self.n_rejected = 0
+        self.energy_history = []
+        self.magnetization_history = []
+
+    def set_temperature(self, temperature: float) -> None:
+        self.temperature = max(temperature, 1e-10)  # reference :57-59
+
+    def _engine(self):
+        return self.model._sync()
+
+    def single_spin_update(self, site: Optional[int] = None) -> Tuple[bool, float]:
+        """One Metropolis update; returns (accepted, dE) with dE = 0 on rejection."""
+        if site is None:
+            site = int(self._rng.integers(0, self.model.n_spins))
+        u = float(np.float32(self._rng.random(dtype=np.float32)))
+        accepted, dE = self._engine().update(0, site, self.temperature, u)
+        if accepted:
+            self.model.spins[site] *= -1
+            self.model._mark_spins_synced()
+            self.model._invalidate_cache()
+            self.n_accepted += 1
+            return True, dE
+        self.n_rejected += 1
+        return False, 0.0
+
+    def sweep(self) -> float:
+        """n single-spin updates at random sites (with replacement); returns the energy."""
+        e = self._engine()
+        n = self.model.n_spins
+        e.set_counters(self._sweeps, 0)
+        before = int(e.stats()[0][0])
+        e.set_seed(self._seed)  # the model's engine is shared: carry our own stream key
+        e.set_temperatures([self.temperature])
+        e.sweep(1, site_mode=N.SITE_RANDOM)
+        self._sweeps += 1
+        acc = int(e.stats()[0][0]) - before
+        self.n_accepted += acc
+        self.n_rejected += n - acc
+        spins = e.spins(0)
+        self.model.spins.copy_(self.model.spins.new_tensor(spins.astype(np.float32)))
+        self.model._mark_spins_synced()
+        energy = float(e.energies()[0])
+        self.model._energy_cache, self.model._cache_valid = energy, True
+        self.energy_history.append(energy)
+        self.magnetization_history.append(float(spins.sum()))
+        return energy
+
+    def run_dynamics(self, n_sweeps: int, record_interval: int = 1) -> dict:
+        initial = self.model.compute_energy()
+        for k in range(n_sweeps):
+            self.sweep()
+        final = self.model.compute_energy()
+        return {"initial_energy": initial, "final_energy": final,
+                "energy_history": list(self.energy_history),
+                "acceptance_rate": self.get_acceptance_rate(), "n_sweeps": n_sweeps,
+                "temperature": self.temperature}
+
+    def get_acceptance_rate(self) -> float:
+        total = self.n_accepted + self.n_rejected
+        return self.n_accepted / total if total else 0.0
+
+    @property
+    def accepted_flips(self) -> int:
+        return self.n_accepted
+
+    @accepted_flips.setter
+    def accepted_flips(self, value: int) -> None:
+        self.n_accepted = value
+
+    @property
+    def total_flips(self) -> int:
+        return self.n_accepted + self.n_rejected
+
+    @total_flips.setter
+    def total_flips(self, value: int) -> None:
+        if value < self.n_accepted:
+            raise ValueError("Total flips cannot be less than accepted flips")
+        self.n_rejected = value - self.n_accepted
+
+    def reset_statistics(self) -> None:
+        self.n_accepted = 0
+        self.n_rejected = 0
+        self.energy_history = []
+
+    def __repr__(self) -> str:
+        return (f"SpinDynamics(temperature={self.temperature:.4f}, "
+                f"update_rule={self.update_rule.value}, "
+                f"acceptance_rate={self.get_acceptance_rate():.4f})")

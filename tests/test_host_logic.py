@@ -1,0 +1,192 @@
+"""CPU tests of the host layer: schedules, result record, configs, model container, and the
+C-ABI contract (libsga.so loads and exports every symbol include/sga.h declares; without a GPU
+the product fails loudly instead of falling back)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import spin_glass_anneal_rl_amd as sg
+from spin_glass_anneal_rl_amd.gpu_annealer import check_convergence
+from spin_glass_anneal_rl_amd.ising_model import coo_to_csr
+from spin_glass_anneal_rl_amd.scheduler import beta_ladder
+from conftest import ROOT, load_golden
+
+
+# ----------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sga.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sga_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(sg._native.library_path())
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sga.h but not exported"
+    bound = sorted(n for n, _, _ in sg._native.SYMBOLS)
+    assert bound == declared, "ctypes binding table and header disagree"
+    assert sg._native.lib().sga_version() >= 100
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_device_error_not_fallback():
+    with pytest.raises(sg.DeviceError):
+        sg.AnnealEngine(0)
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=4, use_sparse=False))
+    with pytest.raises(sg.DeviceError):
+        m.compute_energy()
+    with pytest.raises(sg.DeviceError):
+        sg.GPUAnnealer(sg.GPUAnnealerConfig(n_sweeps=2)).anneal(m)
+    with pytest.raises(sg.DeviceError):
+        sg.ParallelTempering(sg.ParallelTemperingConfig(n_sweeps=2)).run(m)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "spin-glass-anneal-rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "sg_oracle" not in src, f
+
+
+# ----------------------------------------------------------------------------- schedules
+PLAIN = ["linear", "exponential", "geometric", "logarithmic", "power_law", "fast", "boltzmann"]
+
+
+@pytest.mark.parametrize("kind", PLAIN)
+def test_schedule_tables_equal_reference(kind):
+    g = load_golden("schedules")
+    s = sg.TemperatureScheduler.create_schedule(sg.ScheduleType(kind), 10.0, 0.01, 1000)
+    got = np.asarray([s.get_temperature(k) for k in range(1200)])
+    assert np.array_equal(got, g[kind])
+    assert np.array_equal(s.table(5, 7), g[kind][5:12])
+
+
+def test_adaptive_schedule_equals_reference():
+    g = load_golden("schedules")
+    s = sg.TemperatureScheduler.create_schedule(sg.ScheduleType.ADAPTIVE, 10.0, 0.01, 1000)
+    got = [s.update(k, acceptance_rate=float(g["adaptive_acc"][k])) for k in range(400)]
+    assert np.array_equal(np.asarray(got), g["adaptive"])
+    assert len(s.temperature_history) == 401
+
+
+def test_custom_schedule_and_factory_errors():
+    s = sg.TemperatureScheduler.create_schedule(sg.ScheduleType.CUSTOM, 5.0, 0.5, 10,
+                                                custom_func=lambda k: 5.0 - k)
+    assert [s.get_temperature(k) for k in (0, 4, 9)] == [5.0, 1.0, 0.5]
+    with pytest.raises(ValueError):
+        sg.TemperatureScheduler.create_schedule(sg.ScheduleType.CUSTOM, 5.0, 0.5, 10)
+    assert "geometric" in sg.TemperatureScheduler.get_available_schedules()
+    assert sg.TemperatureScheduler.recommend_schedule(100, 1000)[0] == sg.ScheduleType.GEOMETRIC
+
+
+def test_ladders():
+    g = load_golden("pt_c1_n64_r8")
+    assert np.array_equal(np.asarray(sg.temperature_ladder(8, 0.1, 10.0)), g["temperatures"])
+    g2 = load_golden("pt_small_n16_r4")
+    assert np.array_equal(np.asarray(sg.temperature_ladder(4, 0.5, 5.0, "linear")),
+                          g2["temperatures"])
+    assert np.allclose(sg.temperature_ladder(5, 0.1, 10.0, "exponential"),
+                       sg.temperature_ladder(5, 0.1, 10.0, "geometric"))
+    with pytest.raises(ValueError):
+        sg.temperature_ladder(4, 0.1, 1.0, "bogus")
+    b = beta_ladder(6, 0.1, 10.0, "geometric")
+    assert b[0] == pytest.approx(0.1) and b[-1] == pytest.approx(10.0) and np.all(np.diff(b) > 0)
+
+
+# ----------------------------------------------------------------------------- result / configs
+def _result(**kw):
+    base = dict(best_configuration=torch.ones(4), best_energy=-3.0,
+                energy_history=[1.0, -1.0, -3.0], temperature_history=[2.0, 1.0, 0.5],
+                acceptance_rate_history=[0.0, 0.5, 0.25], total_time=0.1, n_sweeps=3)
+    base.update(kw)
+    return sg.AnnealingResult(**base)
+
+
+def test_result_derived_fields_and_validation(tmp_path):
+    r = _result()
+    assert r.final_temperature == 0.5 and r.final_acceptance_rate == 0.25
+    assert r.energy_std == pytest.approx(np.std([1.0, -1.0, -3.0]))
+    assert r.get_summary()["best_energy"] == -3.0
+    for bad in (dict(best_energy=float("nan")), dict(n_sweeps=0), dict(total_time=-1.0),
+                dict(energy_history=[0.0, float("inf")])):
+        with pytest.raises(ValueError):
+            _result(**bad)
+    with pytest.raises(TypeError):
+        _result(best_configuration=[1, 2])
+    flat = _result(energy_history=[-3.0] * 40, temperature_history=[1.0] * 40,
+                   acceptance_rate_history=[0.1] * 40)
+    assert flat.convergence_sweep == 0
+    path = str(tmp_path / "res.npz")
+    r2 = _result(random_seed=7)
+    r2.save(path)
+    back = sg.AnnealingResult.load(path)
+    assert back.best_energy == r2.best_energy and back.energy_history == r2.energy_history
+    assert torch.equal(back.best_configuration, r2.best_configuration) and back.random_seed == 7
+
+
+def test_convergence_rule_matches_reference_run():
+    g = load_golden("sa_default_n64")  # the reference stopped exactly at its 50th record
+    hist = list(g["energy_history"])
+    assert check_convergence(hist, 1e-8)
+    assert not check_convergence(hist[:-1], 1e-8)
+    assert not check_convergence([1.0] * 49, 1e-8)
+
+
+def test_config_validation():
+    assert sg.GPUAnnealerConfig().schedule_params == {"alpha": 0.95}
+    with pytest.raises(sg.ConfigurationError):
+        sg.GPUAnnealerConfig(n_sweeps=0)
+    with pytest.raises(sg.ConfigurationError):
+        sg.GPUAnnealerConfig(site_order="zigzag")
+    with pytest.raises(sg.ConfigurationError):
+        sg.ParallelTempering(sg.ParallelTemperingConfig(n_replicas=1))
+    with pytest.raises(ValueError):
+        sg.MultiGPUConfig(gpu_ids=[])
+    with pytest.raises(ValueError):
+        sg.MultiGPUConfig(gpu_ids=[0], strategy="pipeline")
+    with pytest.raises(ValueError):
+        sg.MultiGPUConfig(gpu_ids=[0], communication_backend="smoke-signals")
+    with pytest.raises(sg.AnnealingError):
+        sg.SpinDynamics(sg.IsingModel(sg.IsingModelConfig(n_spins=3)), update_rule=sg.UpdateRule.WOLFF)
+
+
+# ----------------------------------------------------------------------------- model container
+@pytest.mark.parametrize("sparse", [False, True])
+def test_model_container_edits(sparse):
+    torch.manual_seed(0)
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=6, use_sparse=sparse))
+    assert set(m.spins.tolist()) <= {-1.0, 1.0} and m.spins.dtype == torch.float32
+    m.set_coupling(0, 3, 2.5)
+    m.set_coupling(3, 5, -1.0)
+    m.set_coupling(0, 3, 1.5)  # overwrite, both triangles
+    J = m.dense_couplings()
+    assert J[0, 3] == 1.5 and J[3, 0] == 1.5 and J[5, 3] == -1.0 and torch.equal(J, J.T)
+    with pytest.raises(ValueError):
+        m.set_coupling(0, 6, 1.0)
+    m.set_external_field(2, 0.75)
+    m.set_external_fields(torch.arange(6, dtype=torch.float32))
+    assert m.external_fields[2] == 2.0
+    c = m.copy()
+    c.set_spins(-m.get_spins())
+    assert torch.equal(c.spins, -m.spins) and torch.equal(c.dense_couplings(), J)
+    back = sg.IsingModel.from_dict(m.to_dict())
+    assert torch.equal(back.dense_couplings(), J) and torch.equal(back.spins, m.spins)
+    assert -1.0 <= m.get_magnetization() <= 1.0
+    m.reset_to_random()
+    assert m.spins.shape == (6,)
+
+
+def test_coo_to_csr_sums_duplicates_and_sorts():
+    idx = torch.tensor([[2, 0, 2, 1, 2], [1, 2, 0, 2, 1]])
+    val = torch.tensor([1.0, 4.0, 3.0, -2.0, 0.5])
+    rowptr, col, v = coo_to_csr(torch.sparse_coo_tensor(idx, val, (3, 3)))
+    assert rowptr.tolist() == [0, 1, 2, 4] and col.tolist() == [2, 2, 0, 1]
+    assert v.tolist() == [4.0, -2.0, 3.0, 1.5]

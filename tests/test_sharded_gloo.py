@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: two ranks over gloo, each holding half of the replicas of one ladder,
+must reproduce the single-rank run bit for bit (decisions are a pure function of the gathered
+energies and the shared Philox key; spins never move between ranks)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle_engine import OracleEngine
+
+N_SPINS, R_GLOBAL, ROUNDS, SEED = 48, 12, 9, 777
+
+
+def _instance():
+    rng = np.random.RandomState(5)
+    J = np.triu(rng.randint(0, 2, (N_SPINS, N_SPINS)) * 2 - 1, 1).astype(np.float32)
+    return J + J.T, rng.randint(-1, 2, N_SPINS).astype(np.float32)
+
+
+def _ladder(R, n_ladders):
+    L = R // n_ladders
+    one = [6.0 * (0.3 / 6.0) ** (i / (L - 1)) for i in range(L)]
+    return np.asarray(one * n_ladders)
+
+
+def _run(rank, world, n_ladders, sink, dist_mod):
+    import spin_glass_anneal_rl_amd as sg
+    J, h = _instance()
+    pt = sg.ShardedTempering(OracleEngine(J=J, h=h), R_GLOBAL // world, rank, world, SEED,
+                             _ladder(R_GLOBAL, n_ladders), n_ladders, dist_mod,
+                             torch.device("cpu"))
+    swaps = []
+    for _ in range(ROUNDS):
+        pt.sweep(2)
+        swaps.append(pt.exchange())
+    e, s, idx = pt.global_best()
+    sink.update(swaps=swaps, energies=pt.gather_energies().numpy().copy(), best=(e, s, idx),
+                spins=pt.engine.spins(), temps=pt.engine.temperatures(),
+                slot_map=pt.engine.slot_map())
+
+
+def _worker(rank, world, port, n_ladders, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    _run(rank, world, n_ladders, out, dist)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _two_ranks(n_ladders):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ladders, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def _check(n_ladders):
+    single = {}
+    _run(0, 1, n_ladders, single, None)
+    assert sum(single["swaps"]) > 0
+    got = _two_ranks(n_ladders)
+    half = R_GLOBAL // 2
+    for rank in (0, 1):
+        o = got[rank]
+        assert o["swaps"] == single["swaps"]
+        assert np.array_equal(o["energies"], single["energies"])
+        assert np.array_equal(o["slot_map"], single["slot_map"])
+        sl = slice(rank * half, (rank + 1) * half)
+        assert np.array_equal(o["spins"], single["spins"][sl])
+        assert np.array_equal(o["temps"], single["temps"][sl])
+        assert o["best"][0] == single["best"][0] and o["best"][2] == single["best"][2]
+        assert np.array_equal(o["best"][1], single["best"][1])
+
+
+def test_two_rank_run_equals_single_rank_one_ladder():
+    _check(1)
+
+
+def test_two_rank_run_equals_single_rank_three_ladders():
+    _check(3)
