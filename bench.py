@@ -71,7 +71,7 @@ def host_cores():
     return int(os.environ.get("SGA_CPU_THREADS", cores))
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=1):
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8):
     import oracle
     cores = host_cores()
     R = max(cores * budget_replicas_per_core, 1)
@@ -88,6 +88,25 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=1):
             "kind": "port",
             "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin dense instance, "
                       f"OpenMP over replicas, fp32 SIMD row dot, {dt:.2f} s"}
+
+
+def pmc_traffic(storage, n, R):
+    """HBM bytes per sweep-kernel launch from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json, written by profiles/summarize_rocprof.py), or None."""
+    import glob
+    tag = f"c2a_{storage}"
+    if (n, R) != (10000, 1024):
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for name, e in d["kernels"].items():
+                if "sweep_dense_kernel" in name and "hbm_bytes" in e:
+                    return e["hbm_bytes"], os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def main():
@@ -174,6 +193,7 @@ def main():
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
     achieved = per_launch_attempts * n * elem / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
+    traffic, traffic_src = pmc_traffic(a.storage, n, R)
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -195,7 +215,11 @@ def main():
                    "coupling_storage": a.storage, "geometry": geometry,
                    "best_energy_rank0": best_e},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + "
+                                     "WRITE_SIZE, separate --pmc passes)",
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": per_launch_attempts * n * elem,
                      "kernel": "sweep_dense_kernel", "launches": launches,
                      "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_attempt": n * elem},

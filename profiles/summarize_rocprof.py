@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--extra", action="append", default=[],
+                    help="further --pmc output dirs; every counter is averaged per launch")
     ap.add_argument("--tag", required=True)
     ap.add_argument("--note", default="")
     a = ap.parse_args()
@@ -62,11 +64,23 @@ def main():
             e[label + "_raw_KiB"] = raw
             e[label.split("_")[0].lower() + "_bytes"] = raw * 1024.0 * scale
             e["launches_" + label] = len(v)
+    for d in a.extra:
+        src = one(os.path.join(d, "**", "*_counter_collection.csv"))
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(src)):
+            if "sga::" in r["Kernel_Name"]:
+                agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            pmc["kernels"].setdefault(k, {})[c] = sum(v) / len(v)
+    for e in pmc["kernels"].values():
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
     if a.fetch or a.write:
         pmc["corrections"] = ("fetch_bytes = FETCH_SIZE x 1024 x 2 (gfx950 wide-read under-count), "
                               "write_bytes = WRITE_SIZE x 1024")
         for e in pmc["kernels"].values():
             e["hbm_bytes"] = e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
+    if a.fetch or a.write or a.extra:
         with open(os.path.join(HERE, f"{a.tag}_pmc.json"), "w") as f:
             json.dump(pmc, f, indent=1)
         print(f"wrote {a.tag}_pmc.json")
