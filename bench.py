@@ -50,6 +50,22 @@ def make_sk_instance(n, seed, device):
     return J
 
 
+def make_sparse_instance(n, half_degree, seed):
+    """C3: random ~2*half_degree-regular symmetric graph, +-1 couplings, CSR."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    rows = np.repeat(np.arange(n), half_degree)
+    cols = rng.randint(0, n, rows.size)
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    up = sp.coo_matrix((np.ones(lo.size, np.float32), (lo, hi)), shape=(n, n)).tocsr()
+    up.data[:] = rng.randint(0, 2, up.nnz).astype(np.float32) * 2 - 1  # duplicates merged first
+    A = (up + up.T).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
 def host_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
@@ -71,11 +87,15 @@ def host_cores():
     return int(os.environ.get("SGA_CPU_THREADS", cores))
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8):
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None):
     import oracle
     cores = host_cores()
     R = max(cores * budget_replicas_per_core, 1)
-    prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
+    if csr is not None:
+        sweeps *= 40  # a sparse sweep is ~100x cheaper: keep the sample at seconds of CPU work
+        prob = oracle.Problem(csr=csr, h=np.zeros(n, np.float32))
+    else:
+        prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
     oracle.set_exact_f32(True)  # +-1 couplings: fp32 SIMD accumulation is exact
     s = oracle.init_spins(n, R, seed)
     e0 = np.zeros(R)
@@ -86,8 +106,9 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8):
     oracle.set_exact_f32(False)
     return {"value": R * n * sweeps / dt, "unit": "spin-flip attempts/s", "cores": cores,
             "kind": "port",
-            "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin dense instance, "
-                      f"OpenMP over replicas, fp32 SIMD row dot, {dt:.2f} s"}
+            "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin "
+                      f"{'CSR' if csr is not None else 'dense'} instance, OpenMP over replicas"
+                      f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
 
 
 def pmc_traffic(storage, n, R):
@@ -114,8 +135,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2a", choices=["c2a", "c3"],
+                    help="c2a: dense SK instance (headline); c3: CSR, degree ~32, 4096 replicas")
     ap.add_argument("--spins", type=int, default=10000)
-    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0 = workload default)")
     ap.add_argument("--storage", default="f32", choices=["f32", "i8"])
     ap.add_argument("--exchange-interval", type=int, default=10)
     ap.add_argument("--waves", type=int, default=0)
@@ -141,14 +164,20 @@ def main():
     import spin_glass_anneal_rl_amd as sg
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
 
-    n, R = a.spins, a.replicas
+    n = a.spins
+    R = a.replicas or (1024 if a.workload == "c2a" else 4096)
     Rg = R * world
-    J = make_sk_instance(n, 2, dev)
     h = torch.zeros(n, device=dev)
     eng = sg.AnnealEngine(local_rank)
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(waves_per_replica=a.waves, sweeps_per_launch=1)
-    eng.set_dense(J, h, storage=a.storage)
+    J = csr = None
+    if a.workload == "c2a":
+        J = make_sk_instance(n, 2, dev)
+        eng.set_dense(J, h, storage=a.storage)
+    else:
+        csr = make_sparse_instance(n, 16, 3)
+        eng.set_csr(*csr, h)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
                           slot_temps=geometric_ladder(Rg), n_ladders=1,
                           dist=dist, device=dev)
@@ -191,9 +220,13 @@ def main():
     elem = 4 if a.storage == "f32" else 1
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
-    achieved = per_launch_attempts * n * elem / avg_launch_s / 1e9 if launches else 0.0
+    if csr is None:
+        bytes_per_attempt = float(n * elem)          # one coupling row
+    else:
+        bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
+    achieved = per_launch_attempts * bytes_per_attempt / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
-    traffic, traffic_src = pmc_traffic(a.storage, n, R)
+    traffic, traffic_src = pmc_traffic(a.storage, n, R) if csr is None else (None, None)
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -206,26 +239,27 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if a.storage == "f32" else "i8",
+        "dtype": "f32" if (a.storage == "f32" or csr is not None) else "i8",
         "data": "synthetic",
-        "config": {"workload": f"C2a: {n}-spin dense +-1 SK Ising, {R} replicas/GPU, geometric "
-                               f"ladder T 10->0.1, random-site Metropolis sweeps, exchange "
-                               f"every {a.exchange_interval}",
+        "config": {"workload": (f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
+                                f"C3: {n}-spin CSR +-1 Ising, mean degree {len(csr[1]) / n:.1f}") +
+                               f", {R} replicas/GPU, geometric ladder T 10->0.1, random-site "
+                               f"Metropolis sweeps, exchange every {a.exchange_interval}",
                    "spins": n, "replicas_per_gpu": R, "replicas_total": Rg,
-                   "coupling_storage": a.storage, "geometry": geometry,
+                   "coupling_storage": a.storage if csr is None else "csr", "geometry": geometry,
                    "best_energy_rank0": best_e},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + "
                                      "WRITE_SIZE, separate --pmc passes)",
                      "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": per_launch_attempts * n * elem,
-                     "kernel": "sweep_dense_kernel", "launches": launches,
-                     "avg_launch_ms": avg_launch_s * 1e3,
-                     "algorithmic_bytes_per_attempt": n * elem},
+                     "algorithmic_bytes_per_launch": per_launch_attempts * bytes_per_attempt,
+                     "kernel": "sweep_dense_kernel" if csr is None else "sweep_csr_kernel",
+                     "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                     "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(J.cpu().numpy(), n, 42)
+        out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr)
     else:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -67,6 +67,11 @@ typedef struct sga_engine sga_engine;
 #define SGA_ARITH_F64 0 /* spin_dynamics.py:131-152 (double dE, fp32 exp)                     */
 #define SGA_ARITH_F32 1 /* cuda_kernels.py:383-390 (fp32 throughout, minus J_ii s_i)          */
 
+/* single-site update rule (core/spin_dynamics.py:11-16) used by sga_sweep / sga_update */
+#define SGA_RULE_METROPOLIS 0 /* spin_dynamics.py:131-152                                      */
+#define SGA_RULE_GLAUBER 1    /* spin_dynamics.py:154-171: s_i = +1 w.p. 1/(1+exp(-2 f/T))     */
+#define SGA_RULE_HEAT_BATH 2  /* spin_dynamics.py:173-191: same with beta = 1/T formed first   */
+
 /* ---- lifetime ------------------------------------------------------------------------- */
 int sga_create(int device, sga_engine **out);
 void sga_destroy(sga_engine *e);
@@ -120,6 +125,11 @@ int sga_local_fields(sga_engine *e, int r, const int32_t *sites, int count, doub
 int sga_flip(sga_engine *e, int r, int site, double *dE);
 int sga_update(sga_engine *e, int r, int site, double T, float u, int arith, int *accepted,
                double *dE);
+
+/* Rule applied by later sga_sweep / sga_update calls (default METROPOLIS).  GLAUBER and
+ * HEAT_BATH always consume the uniform and require SGA_ARITH_F64; the per-update dE record of
+ * HEAT_BATH is minus the energy change, as the reference returns it (spin_dynamics.py:188). */
+int sga_set_update_rule(sga_engine *e, int rule);
 
 /* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s */
 int sga_recompute_energies(sga_engine *e);

@@ -14,6 +14,7 @@ _SO = os.path.join(_HERE, "libsg_oracle.so")
 
 SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
+RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH = 0, 1, 2
 
 
 def build(force=False):
@@ -45,10 +46,10 @@ def lib():
         L.sgo_energy.argtypes = [C.c_int, p, C.c_int64, p, p, p, p, p]
         L.sgo_energy.restype = C.c_double
         L.sgo_metropolis_update.argtypes = [C.c_int, p, C.c_int64, p, p, p, p, p, C.c_int,
-                                            C.c_double, C.c_float, C.c_int, p]
+                                            C.c_double, C.c_float, C.c_int, C.c_int, p]
         L.sgo_metropolis_update.restype = C.c_int
         L.sgo_sweeps.argtypes = [C.c_int, p, C.c_int64, p, p, p, p, C.c_int, p, p, p, C.c_int64,
-                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
+                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
                                  C.c_uint32, p, p, C.c_int, C.c_int64, p, p, p, p, p, p, C.c_int,
                                  C.c_int]
         L.sgo_sweeps.restype = C.c_int
@@ -132,16 +133,17 @@ def energy(prob, s):
                        for r in s])
 
 
-def metropolis_update(prob, s, site, T, u, arith=ARITH_F64):
+def metropolis_update(prob, s, site, T, u, arith=ARITH_F64, rule=RULE_METROPOLIS):
     """In-place on s (int8 contiguous). Returns (accepted, dE)."""
     assert s.dtype == np.int8 and s.flags.c_contiguous
     d = C.c_double(0.0)
     a = lib().sgo_metropolis_update(*prob.args(), _ptr(s), int(site), float(T), float(u),
-                                    int(arith), C.byref(d))
+                                    int(arith), int(rule), C.byref(d))
     return bool(a), d.value
 
 
-def sweeps(prob, spins, temps, n_sweeps, site_mode=SITE_RANDOM, arith=ARITH_F64, seed=0, sweep0=0,
+def sweeps(prob, spins, temps, n_sweeps, site_mode=SITE_RANDOM, arith=ARITH_F64,
+           rule=RULE_METROPOLIS, seed=0, sweep0=0,
            replica0=0, replay_site=None, replay_u=None, u_compact=False, energy=None,
            best_energy=None, recompute_energy=False, trace=False, n_threads=1):
     """Run R replicas x n_sweeps sweeps.  spins [R,n] int8 is updated in place.
@@ -187,7 +189,7 @@ def sweeps(prob, spins, temps, n_sweeps, site_mode=SITE_RANDOM, arith=ARITH_F64,
         else:
             assert ru_.size == R * per
     rc = lib().sgo_sweeps(*prob.args(), R, _ptr(spins2), _ptr(energy), _ptr(t), ss, rs,
-                          int(n_sweeps), int(site_mode), int(arith), int(seed), int(sweep0),
+                          int(n_sweeps), int(site_mode), int(arith), int(rule), int(seed), int(sweep0),
                           int(replica0), _ptr(rs_), _ptr(ru_), int(bool(u_compact)), int(ucap),
                           _ptr(e_trace), _ptr(n_acc), _ptr(best_energy), _ptr(best_spins),
                           _ptr(acc_tr), _ptr(dE_tr), int(bool(recompute_energy)), int(n_threads))

@@ -225,8 +225,28 @@ typedef struct {
 
 static inline upd_t metropolis_core(int n, const float *J, int64_t ld, const int32_t *rowptr,
                                     const int32_t *colidx, const float *val, const float *h,
-                                    int8_t *s, int site, double T, float u, int arith) {
+                                    int8_t *s, int site, double T, float u, int arith, int rule) {
     upd_t o = {0, 0, 0.0};
+    if (rule != SGO_RULE_METROPOLIS) {
+        /* SpinDynamics._glauber_update, spin_dynamics.py:154-171:
+         *   prob_up = 1.0 / (1.0 + torch.exp(torch.tensor(-2.0 * local_field / T)))
+         * SpinDynamics._heat_bath_update, :173-191:
+         *   beta = 1.0 / T;  prob_up = 1.0 / (1.0 + torch.exp(torch.tensor(-2.0 * beta * field)))
+         * (double argument rounded to fp32, fp32 exp / add / divide), then
+         *   new_spin = 1 if torch.rand(1).item() < prob_up else -1;  flip iff it differs.   */
+        double field = sgo_local_field(n, J, ld, rowptr, colidx, val, h, s, site);
+        float x = (rule == SGO_RULE_GLAUBER) ? (float)(-2.0 * field / T)
+                                             : (float)((-2.0 * (1.0 / T)) * field);
+        float prob_up = 1.0f / (1.0f + sgo_expf(x));
+        int new_spin = (u < prob_up) ? 1 : -1;
+        o.used_u = 1;
+        o.dE = 2.0 * (double)s[site] * field; /* the true energy change of a flip */
+        if (new_spin != (int)s[site]) {
+            s[site] = (int8_t)new_spin;
+            o.accepted = 1;
+        }
+        return o;
+    }
     if (arith == SGO_ARITH_F64) {
         /* SpinDynamics._metropolis_update, spin_dynamics.py:131-152 */
         double field = sgo_local_field(n, J, ld, rowptr, colidx, val, h, s, site); /* :134 */
@@ -272,9 +292,10 @@ static inline upd_t metropolis_core(int n, const float *J, int64_t ld, const int
 
 int sgo_metropolis_update(int n, const float *J, int64_t ld, const int32_t *rowptr,
                           const int32_t *colidx, const float *val, const float *h, int8_t *s,
-                          int site, double T, float u, int arith, double *dE_out) {
-    upd_t o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, u, arith);
-    if (dE_out) *dE_out = o.accepted ? o.dE : 0.0; /* spin_dynamics.py:142,149,152 */
+                          int site, double T, float u, int arith, int rule, double *dE_out) {
+    upd_t o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, u, arith, rule);
+    /* spin_dynamics.py:142,149,152,167,188 (heat bath returns -delta_energy) */
+    if (dE_out) *dE_out = o.accepted ? (rule == SGO_RULE_HEAT_BATH ? -o.dE : o.dE) : 0.0;
     return o.accepted;
 }
 
@@ -284,7 +305,7 @@ int sgo_metropolis_update(int n, const float *J, int64_t ld, const int32_t *rowp
 int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const int32_t *colidx,
                const float *val, const float *h, int R, int8_t *spins, double *energy,
                const double *temps, int64_t t_sweep_stride, int64_t t_replica_stride,
-               int n_sweeps, int site_mode, int arith, uint64_t seed, uint32_t sweep0,
+               int n_sweeps, int site_mode, int arith, int rule, uint64_t seed, uint32_t sweep0,
                uint32_t replica0, const int32_t *replay_site, const float *replay_u,
                int u_compact, int64_t u_capacity, double *energy_trace, int64_t *n_accepted,
                double *best_energy, int8_t *best_spins, uint8_t *accept_trace,
@@ -328,17 +349,19 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
                 if (site_mode != SGO_SITE_RANDOM && u_compact) {
                     /* consume the recorded uniform only where the reference draws one */
                     float cand = (ucur < u_capacity) ? ru[ucur] : 2.0f;
-                    o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, cand, arith);
+                    o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, cand, arith, rule);
                     if (o.used_u) {
                         if (ucur >= u_capacity) err = 2;
                         ++ucur;
                     }
                 } else {
-                    o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, u, arith);
+                    o = metropolis_core(n, J, ld, rowptr, colidx, val, h, s, site, T, u, arith, rule);
                 }
                 if (o.accepted) { E += o.dE; ++acc; }
                 if (accept_trace) accept_trace[r * per_rep + idx] = (uint8_t)o.accepted;
-                if (dE_trace) dE_trace[r * per_rep + idx] = o.accepted ? o.dE : 0.0;
+                if (dE_trace)
+                    dE_trace[r * per_rep + idx] =
+                        o.accepted ? (rule == SGO_RULE_HEAT_BATH ? -o.dE : o.dE) : 0.0;
             }
             if (recompute_energy) /* spin_dynamics.py:87 */
                 E = sgo_energy(n, J, ld, rowptr, colidx, val, h, s);

@@ -30,6 +30,11 @@ extern "C" {
 #define SGO_ARITH_F64 0 /* spin_dynamics.py:131-152: python doubles, fp32 exp             */
 #define SGO_ARITH_F32 1 /* cuda_kernels.py:383-390: fp32 tensors throughout               */
 
+/* single-site update rule (core/spin_dynamics.py:11-16); Wolff is not on the accelerated path */
+#define SGO_RULE_METROPOLIS 0 /* spin_dynamics.py:131-152 */
+#define SGO_RULE_GLAUBER 1    /* spin_dynamics.py:154-171 */
+#define SGO_RULE_HEAT_BATH 2  /* spin_dynamics.py:173-191 */
+
 /* Philox4x32-10 (Salmon et al. 2011); pinned by the Random123 known-answer vectors. */
 void sgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
@@ -54,7 +59,7 @@ double sgo_energy(int n, const float *J, int64_t ld, const int32_t *rowptr,
  * as the reference returns). */
 int sgo_metropolis_update(int n, const float *J, int64_t ld, const int32_t *rowptr,
                           const int32_t *colidx, const float *val, const float *h, int8_t *s,
-                          int site, double T, float u, int arith, double *dE_out);
+                          int site, double T, float u, int arith, int rule, double *dE_out);
 
 /* R replicas x n_sweeps sweeps of n updates each: SpinDynamics.sweep, spin_dynamics.py:73-94
  * (random sites), CUDAKernelManager._metropolis_update_fallback, cuda_kernels.py:371-398
@@ -70,7 +75,7 @@ int sgo_metropolis_update(int n, const float *J, int64_t ld, const int32_t *rowp
 int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const int32_t *colidx,
                const float *val, const float *h, int R, int8_t *spins, double *energy,
                const double *temps, int64_t t_sweep_stride, int64_t t_replica_stride,
-               int n_sweeps, int site_mode, int arith, uint64_t seed, uint32_t sweep0,
+               int n_sweeps, int site_mode, int arith, int rule, uint64_t seed, uint32_t sweep0,
                uint32_t replica0, const int32_t *replay_site, const float *replay_u,
                int u_compact, int64_t u_capacity, double *energy_trace, int64_t *n_accepted,
                double *best_energy, int8_t *best_spins, uint8_t *accept_trace,

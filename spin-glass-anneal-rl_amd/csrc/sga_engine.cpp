@@ -111,6 +111,7 @@ struct sga_engine {
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
     int tune_waves = 0, tune_spl = 0;
+    int rule = SGA_RULE_METROPOLIS;
 
     // replicas
     int R = 0, Rg = 0, replica0 = 0;
@@ -504,6 +505,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     if (site_mode < SGA_SITE_RANDOM || site_mode > SGA_SITE_REPLAY)
         return fail(SGA_ERR_INVALID, "bad site_mode");
     if (arith != SGA_ARITH_F64 && arith != SGA_ARITH_F32) return fail(SGA_ERR_INVALID, "bad arith");
+    if (e->rule != SGA_RULE_METROPOLIS && arith != SGA_ARITH_F64)
+        return fail(SGA_ERR_INVALID, "Glauber / heat-bath rules need SGA_ARITH_F64");
     if (site_mode == SGA_SITE_REPLAY && (!replay_site || !replay_u))
         return fail(SGA_ERR_INVALID, "SITE_REPLAY needs replay_site and replay_u");
     if (n_sweeps == 0) return SGA_OK;
@@ -588,6 +591,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.n_sweeps = ks;
         a.site_mode = site_mode;
         a.arith = arith;
+        a.rule = e->rule;
         a.seed_lo = (uint32_t)e->seed;
         a.seed_hi = (uint32_t)(e->seed >> 32);
         a.sweep0 = e->sweeps_done + (uint32_t)k0;
@@ -619,6 +623,14 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // staged inputs / outputs are freed on return: wait for the stream in that case only
     if (d_sched.owned || d_site.owned || d_u.owned || d_etrace.ptr || d_acc.ptr || d_dE.ptr)
         HIPCHK(hipStreamSynchronize(st));
+    return SGA_OK;
+}
+
+int sga_set_update_rule(sga_engine *e, int rule) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (rule < SGA_RULE_METROPOLIS || rule > SGA_RULE_HEAT_BATH)
+        return fail(SGA_ERR_UNSUPPORTED, "update rule not implemented by the engine");
+    e->rule = rule;
     return SGA_OK;
 }
 
@@ -667,6 +679,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         a.count = count;
         a.op = op;
         a.arith = arith;
+        a.rule = e->rule;
         a.T = T;
         a.u = u;
         he = sga::launch_point_op(a, e->csr, e->want_i8, st);

@@ -40,7 +40,7 @@ struct SweepArgs {
     double *dE_trace;            // [R][replay_stride]
     long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
     int n, sstride, R, n_sweeps;
-    int site_mode, arith;
+    int site_mode, arith, rule;
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -106,7 +106,7 @@ struct PointArgs {
     double *out;           // [count] fields (op 0) | out[0] = dE, out[1] = accepted (ops 1, 2)
     long long ld;
     int n, count, op;      // op 0: fields, 1: flip, 2: metropolis
-    int arith;
+    int arith, rule;
     double T;
     float u;
 };

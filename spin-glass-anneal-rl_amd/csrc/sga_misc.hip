@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
             dE = 2.0 * (double)si * ((double)dot + (double)a.h[site]);
             flip = true;
         } else {
-            flip = metropolis_accept(a.arith, dot, si, a.h[site], a.diag[site], a.T, a.u, dE);
+            flip = metropolis_accept(a.rule, a.arith, dot, si, a.h[site], a.diag[site], a.T, a.u, dE);
         }
         __syncthreads();  // every thread has read s[site]
         if (tid == 0) {
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
                 *a.energy += dE;
                 if (a.op == 2) *a.n_accepted += 1;
             }
-            a.out[0] = dE;
+            a.out[0] = (a.op == 2 && a.rule == SGA_RULE_HEAT_BATH) ? -dE : dE;
             a.out[1] = flip ? 1.0 : 0.0;
         }
     }

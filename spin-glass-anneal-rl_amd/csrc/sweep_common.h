@@ -54,11 +54,23 @@ __device__ __forceinline__ UpdatePair fetch_pair(const SweepArgs &a, int r, int 
 }
 
 // The accept rule.  dot = fp32 coupling dot product J[site,:].s (already rounded to fp32),
-// si = s[site] (+-1).  Returns true if the flip is accepted; dE receives the proposed
-// energy change.
-__device__ __forceinline__ bool metropolis_accept(int arith, float dot, int si, float h_site,
-                                                  float diag_site, double T, float u,
-                                                  double &dE) {
+// si = s[site] (+-1).  Returns true if the spin flips; dE receives the energy change of the
+// flip.
+__device__ __forceinline__ bool metropolis_accept(int rule, int arith, float dot, int si,
+                                                  float h_site, float diag_site, double T,
+                                                  float u, double &dE) {
+    if (rule != SGA_RULE_METROPOLIS) {
+        // core/spin_dynamics.py:154-171 (Glauber) and :173-191 (heat bath):
+        //   prob_up = 1.0 / (1.0 + exp(float32(x))),  x = -2.0*field/T  |  (-2.0*(1.0/T))*field
+        //   new_spin = +1 if rand < prob_up else -1;  flip iff new_spin != s_i
+        const double field = (double)dot + (double)h_site;
+        const float x = (rule == SGA_RULE_GLAUBER) ? (float)(-2.0 * field / T)
+                                                   : (float)((-2.0 * (1.0 / T)) * field);
+        const float prob_up = 1.0f / (1.0f + expf_det(x));
+        const int new_spin = (u < prob_up) ? 1 : -1;
+        dE = 2.0 * (double)si * field;
+        return new_spin != si;
+    }
     if (arith == SGA_ARITH_F64) {
         // core/spin_dynamics.py:131-152 with core/ising_model.py:176-185:
         //   local_field = float(dot) + float(h[i])          (python doubles)

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
                 const float dot = (float)wave_sum(acc);
                 const int si = s[site];
                 double dE;
-                const bool acc_flip = metropolis_accept(a.arith, dot, si, head.h, head.d, T, u, dE);
+                const bool acc_flip = metropolis_accept(a.rule, a.arith, dot, si, head.h, head.d, T, u, dE);
                 if (acc_flip) {
                     E += dE;
                     ++nacc;
@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
                     if (a.accept_trace)
                         a.accept_trace[(long long)r * a.replay_stride + upd] = acc_flip ? 1 : 0;
                     if (a.dE_trace)
-                        a.dE_trace[(long long)r * a.replay_stride + upd] = acc_flip ? dE : 0.0;
+                        a.dE_trace[(long long)r * a.replay_stride + upd] =
+                            acc_flip ? (a.rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
                 }
                 head = nh;
             }

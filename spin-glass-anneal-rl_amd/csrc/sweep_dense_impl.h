@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             si = s_lds[site];
         }
         double dE;
-        const bool acc = metropolis_accept(a.arith, (float)tot, si, h_site, d_site, T, u, dE);
+        const bool acc = metropolis_accept(a.rule, a.arith, (float)tot, si, h_site, d_site, T, u, dE);
         if (acc) {
             E += dE;
             ++nacc;
@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         }
         if (tid == 0) {
             if (a.accept_trace) a.accept_trace[(long long)r * a.replay_stride + upd] = acc ? 1 : 0;
-            if (a.dE_trace) a.dE_trace[(long long)r * a.replay_stride + upd] = acc ? dE : 0.0;
+            if (a.dE_trace)
+                a.dE_trace[(long long)r * a.replay_stride + upd] =
+                    acc ? (a.rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
         }
     };
 

@@ -190,6 +190,9 @@ class AnnealEngine:
                                      C.byref(acc), C.byref(d)), "sga_update")
         return bool(acc.value), float(d.value)
 
+    def set_update_rule(self, rule: int):
+        N.check(self._lib.sga_set_update_rule(self._h, int(rule)), "sga_set_update_rule")
+
     def recompute_energies(self):
         N.check(self._lib.sga_recompute_energies(self._h), "sga_recompute_energies")
 

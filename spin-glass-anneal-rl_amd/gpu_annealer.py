@@ -85,7 +85,7 @@ class GPUAnnealer:
         `_replay=(sites, uniforms)`: parity-test hook -- per-update arrays recorded from the
         reference's RNG replace the Philox stream (tests/test_host_api_gpu.py).
         """
-        require_metropolis(update_rule)
+        rule = require_metropolis(update_rule)
         cfg = self.config
         t_start = time.time()
         dev_idx = cfg.device_index if cfg.device_index is not None else _device_index(model.device)
@@ -94,10 +94,12 @@ class GPUAnnealer:
             **cfg.schedule_params)
         adaptive = cfg.schedule_type == ScheduleType.ADAPTIVE
         site_mode = N.SITE_RANDOM if cfg.site_order == "random" else N.SITE_SEQUENTIAL
-        arith = N.ARITH_F64 if cfg.site_order == "random" else N.ARITH_F32
+        arith = N.ARITH_F64 if (cfg.site_order == "random" or rule != N.RULE_METROPOLIS) \
+            else N.ARITH_F32
         n = model.n_spins
         with AnnealEngine(dev_idx) as eng:
             model.load_into(eng, storage=cfg.coupling_storage)
+            eng.set_update_rule(rule)
             eng.init_replicas(1, seed=fresh_seed(cfg.random_seed), s0=model.spins_int8()[None, :])
             energy_history = [float(eng.energies()[0])]
             temperature_history = [cfg.initial_temp]

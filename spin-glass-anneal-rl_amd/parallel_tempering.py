@@ -63,7 +63,7 @@ class ParallelTempering:
             _replay=None) -> AnnealingResult:
         """`_replay`: parity-test hook, dict(s0, site[ns,R,n], u[ns,R,n], exch_start, exch_u)
         recorded from the reference, replacing every Philox draw."""
-        require_metropolis(update_rule)
+        rule = require_metropolis(update_rule)
         cfg = self.config
         if cfg.exchange_method != "nearest_neighbor":
             raise AnnealingError("only exchange_method='nearest_neighbor' runs on the HIP engine")
@@ -75,6 +75,7 @@ class ParallelTempering:
         acc_slot, att_slot = np.zeros(R, np.int64), np.zeros(R, np.int64)
         with AnnealEngine(dev_idx) as eng:
             model.load_into(eng, storage=cfg.coupling_storage)
+            eng.set_update_rule(rule)
             eng.init_replicas(R, seed=fresh_seed(cfg.random_seed),
                               s0=None if _replay is None else _replay["s0"])
             eng.set_ladder(temps, 1)

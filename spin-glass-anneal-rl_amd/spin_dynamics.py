@@ -2,8 +2,8 @@
 
 API of the reference's spin_glass_rl/core/spin_dynamics.py:11-429 for the Metropolis rule
 (`sweep`, `single_spin_update`, acceptance statistics, histories).  A sweep is one kernel
-launch (n random-site updates, Philox stream); the reference's Glauber / heat-bath / Wolff
-rules are not on the accelerated path yet and raise.
+launch (n random-site updates, Philox stream).  Metropolis, Glauber and heat-bath run in the
+kernels; the Wolff cluster rule is not on the accelerated path and raises.
 """
 from enum import Enum
 from typing import Optional, Tuple
@@ -22,10 +22,22 @@ class UpdateRule(Enum):
     WOLFF = "wolff"
 
 
-def require_metropolis(rule: UpdateRule) -> None:
-    if rule != UpdateRule.METROPOLIS:
+_RULE_CODE = {UpdateRule.METROPOLIS: N.RULE_METROPOLIS, UpdateRule.GLAUBER: N.RULE_GLAUBER,
+              UpdateRule.HEAT_BATH: N.RULE_HEAT_BATH}
+
+
+def rule_code(rule: UpdateRule) -> int:
+    """Engine code of a single-site rule; the Wolff cluster move (reference :193-323) does not
+    fit the one-site kernels and is not provided."""
+    if rule not in _RULE_CODE:
         raise AnnealingError(
-            f"update rule '{rule.value}' is not implemented in the HIP engine (Metropolis only)")
+            f"update rule '{rule.value}' is not implemented in the HIP engine "
+            "(metropolis, glauber and heat_bath are)")
+    return _RULE_CODE[rule]
+
+
+def require_metropolis(rule: UpdateRule) -> int:  # kept name: validates and returns the code
+    return rule_code(rule)
 
 
 class SpinDynamics:
@@ -48,7 +60,9 @@ class SpinDynamics:
         self.temperature = max(temperature, 1e-10)  # reference :57-59
 
     def _engine(self):
-        return self.model._sync()
+        e = self.model._sync()
+        e.set_update_rule(rule_code(self.update_rule))
+        return e
 
     def single_spin_update(self, site: Optional[int] = None) -> Tuple[bool, float]:
         """One Metropolis update; returns (accepted, dE) with dE = 0 on rejection."""

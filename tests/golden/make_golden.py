@@ -54,6 +54,8 @@ class Recorder:
         self._orig["np_randint"] = np.random.randint
         self._orig["np_rand"] = np.random.rand
         self._orig["metro"] = SpinDynamics._metropolis_update
+        self._orig["glauber"] = SpinDynamics._glauber_update
+        self._orig["heat"] = SpinDynamics._heat_bath_update
         rec = self
 
         def randint(*a, **k):
@@ -78,19 +80,25 @@ class Recorder:
             rec.np_log.append(("rand", float(v)))
             return v
 
-        def metro(self_dyn, site):
-            rec._pending_u = None
-            accepted, d = rec._orig["metro"](self_dyn, site)
-            rec.us.append(np.nan if rec._pending_u is None else rec._pending_u)
-            rec.acc.append(bool(accepted))
-            rec.dE.append(float(d))
-            return accepted, d
+        def wrap(key):
+            def rule(self_dyn, site):
+                rec._pending_u = None
+                accepted, d = rec._orig[key](self_dyn, site)
+                rec.us.append(np.nan if rec._pending_u is None else rec._pending_u)
+                rec.acc.append(bool(accepted))
+                rec.dE.append(float(d))
+                return accepted, d
+            return rule
+
+        metro = wrap("metro")
 
         torch.randint = randint
         torch.rand = rand
         np.random.randint = np_randint
         np.random.rand = np_rand
         SpinDynamics._metropolis_update = metro
+        SpinDynamics._glauber_update = wrap("glauber")
+        SpinDynamics._heat_bath_update = wrap("heat")
         return self
 
     def __exit__(self, *exc):
@@ -99,6 +107,8 @@ class Recorder:
         np.random.randint = self._orig["np_randint"]
         np.random.rand = self._orig["np_rand"]
         SpinDynamics._metropolis_update = self._orig["metro"]
+        SpinDynamics._glauber_update = self._orig["glauber"]
+        SpinDynamics._heat_bath_update = self._orig["heat"]
 
     def stream(self):
         assert len(self.sites) == len(self.us) == len(self.acc)
@@ -136,7 +146,7 @@ def i8(t):
 
 
 # --------------------------------------------------------------------------- cases
-def case_sweeps(name, J, h, T, n_sweeps, seed, out):
+def case_sweeps(name, J, h, T, n_sweeps, seed, out, rule=UpdateRule.METROPOLIS):
     """SpinDynamics.sweep() at fixed temperature (spin_dynamics.py:73-94)."""
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -145,12 +155,12 @@ def case_sweeps(name, J, h, T, n_sweeps, seed, out):
     e0 = m.compute_energy()
     energies = []
     with Recorder() as rec:
-        dyn = SpinDynamics(m, T, UpdateRule.METROPOLIS)  # binds the wrapped update
+        dyn = SpinDynamics(m, T, rule)  # binds the wrapped update
         for _ in range(n_sweeps):
             energies.append(dyn.sweep())
     st = rec.stream()
     np.savez_compressed(
-        os.path.join(out, name + ".npz"), kind="sweeps", J=J.numpy(),
+        os.path.join(out, name + ".npz"), kind="sweeps", rule=rule.value, J=J.numpy(),
         h=m.external_fields.numpy(), s0=s0, e0=np.float64(e0), T=np.float64(T),
         n_sweeps=np.int32(n_sweeps), sweep_energy=np.asarray(energies, np.float64),
         s_final=i8(m.spins), n_accepted=np.int64(dyn.n_accepted),
@@ -346,6 +356,17 @@ def main():
     if want("sweeps_pm1_n300"):
         # N not a multiple of 4/64/256: ragged row tail for the kernels
         case_sweeps("sweeps_pm1_n300", pm1_couplings(300, 3), z(300), 4.0, 8, 11, a.out)
+    if want("sweeps_glauber_n64"):
+        g = torch.Generator().manual_seed(9)
+        h = (torch.randint(-2, 3, (64,), generator=g)).float()
+        case_sweeps("sweeps_glauber_n64", pm1_couplings(64, 1), h, 2.5, 40, 21, a.out,
+                    rule=UpdateRule.GLAUBER)
+    if want("sweeps_heatbath_n64"):
+        case_sweeps("sweeps_heatbath_n64", pm1_couplings(64, 1), z(64), 1.7, 40, 22, a.out,
+                    rule=UpdateRule.HEAT_BATH)
+    if want("sweeps_glauber_gauss_n32"):
+        case_sweeps("sweeps_glauber_gauss_n32", gaussian_couplings(32, 8), z(32), 0.9, 30, 23,
+                    a.out, rule=UpdateRule.GLAUBER)
     if want("sa_default_n64"):
         # defaults: geometric alpha=.95 floors at sweep 135, early stop at sweep 480
         case_sa("sa_default_n64", pm1_couplings(64, 1), z(64), dict(random_seed=42), 123, a.out)

@@ -133,6 +133,67 @@ def test_reference_gaussian_sweeps_replayed_on_gpu(sg):
         assert e.energies()[0] == pytest.approx(g["sweep_energy"][-1], rel=1e-5)
 
 
+RULE_CASES = [("sweeps_glauber_n64", 1), ("sweeps_heatbath_n64", 2), ("sweeps_glauber_gauss_n32", 1)]
+
+
+@pytest.mark.parametrize("storage", ["dense", "csr"])
+@pytest.mark.parametrize("name,rule", RULE_CASES)
+def test_reference_glauber_heatbath_replayed_on_gpu(sg, name, rule, storage):
+    """Reference core/spin_dynamics.py:154-191 replayed update by update."""
+    g = load_golden(name)
+    exact = "gauss" not in name
+    ns = int(g["n_sweeps"])
+    with sg.AnnealEngine(0) as e:
+        if storage == "csr":
+            e.set_csr(*csr_of(g["J"]), g["h"])
+        else:
+            e.set_dense(g["J"], g["h"])
+        e.set_update_rule(rule)
+        e.init_replicas(1, seed=0, s0=g["s0"][None, :])
+        e.set_temperatures([float(g["T"])])
+        out = e.sweep(ns, site_mode=sg._native.SITE_REPLAY, replay_site=g["site"][None, :],
+                      replay_u=g["u"][None, :], energy_trace=True, trace=True)
+        assert np.array_equal(out["accept_trace"][0].astype(bool), g["accepted"])
+        assert np.array_equal(e.spins(0), g["s_final"])
+        assert e.stats()[0][0] == int(g["n_accepted"])
+        if exact:
+            assert np.array_equal(out["dE_trace"][0], g["dE"])  # heat bath: minus the change
+            assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+        else:
+            assert np.allclose(out["dE_trace"][0], g["dE"], rtol=1e-5, atol=1e-5)
+        with pytest.raises(sg.AnnealingError):
+            e.sweep(1, arith=sg._native.ARITH_F32)
+
+
+@pytest.mark.parametrize("rule", [1, 2])
+@pytest.mark.parametrize("n,R,storage,waves", [(64, 6, "f32", 0), (1100, 4, "f32", 5),
+                                               (2500, 3, "i8", 3), (700, 5, "csr", 0)])
+def test_philox_glauber_heatbath_match_oracle(sg, n, R, storage, waves, rule):
+    J = pm1(n, 40 + n)
+    if storage == "csr":
+        J = J * (np.random.RandomState(n).rand(n, n) < 0.03)
+        J = np.triu(J, 1) + np.triu(J, 1).T
+    h = np.random.RandomState(n).randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    ns, seed = 6, 8080 + n
+    temps = ladder(R, 5.0, 0.4)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, rule=rule, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=waves)
+        if storage == "csr":
+            e.set_csr(*csr_of(J), h)
+        else:
+            e.set_dense(J, h, storage=storage)
+        e.set_update_rule(rule)
+        e.init_replicas(R, seed=seed)
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"])
+
+
 @pytest.mark.parametrize("name", ["sa_default_n64", "sa_linear_n20"])
 def test_reference_sa_run_replayed_on_gpu(sg, name):
     g = load_golden(name)

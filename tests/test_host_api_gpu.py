@@ -77,6 +77,26 @@ def test_spin_dynamics_mirror(sg):
     assert [d2.sweep() for _ in range(5)] == energies
 
 
+def test_update_rules_through_the_public_classes(sg):
+    g = load_golden("sweeps_glauber_n64")
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    for rule in (sg.UpdateRule.GLAUBER, sg.UpdateRule.HEAT_BATH):
+        m = model_from(sg, g["J"], g["h"], g["s0"])
+        dyn = sg.SpinDynamics(m, temperature=1.5, update_rule=rule, random_seed=2)
+        e = [dyn.sweep() for _ in range(4)]
+        assert e[-1] == oracle.energy(prob, m.spins.numpy().astype(np.int8))
+        r = sg.GPUAnnealer(sg.GPUAnnealerConfig(n_sweeps=50, random_seed=4)).anneal(
+            model_from(sg, g["J"], g["h"], g["s0"]), update_rule=rule)
+        assert oracle.energy(prob, r.best_configuration.numpy().astype(np.int8)) == r.best_energy
+        p = sg.ParallelTempering(sg.ParallelTemperingConfig(n_replicas=6, n_sweeps=40,
+                                                            random_seed=4))
+        r2 = p.run(model_from(sg, g["J"], g["h"]), update_rule=rule)
+        assert oracle.energy(prob, r2.best_configuration.numpy().astype(np.int8)) == r2.best_energy
+    with pytest.raises(sg.AnnealingError):
+        sg.GPUAnnealer(sg.GPUAnnealerConfig(n_sweeps=5)).anneal(
+            model_from(sg, g["J"], g["h"]), update_rule=sg.UpdateRule.WOLFF)
+
+
 # ----------------------------------------------------------------------------- GPUAnnealer
 @pytest.mark.parametrize("name", ["sa_default_n64", "sa_linear_n20"])
 def test_gpu_annealer_reproduces_reference_run(sg, name):

@@ -91,6 +91,32 @@ def test_sweeps_replay_matches_reference(name):
     assert np.array_equal(drew, (g["dE"] > 0) | (~g["accepted"]))
 
 
+@pytest.mark.parametrize("name,rule", [("sweeps_glauber_n64", oracle.RULE_GLAUBER),
+                                       ("sweeps_heatbath_n64", oracle.RULE_HEAT_BATH),
+                                       ("sweeps_glauber_gauss_n32", oracle.RULE_GLAUBER)])
+def test_other_update_rules_replay_matches_reference(name, rule):
+    g = load_golden(name)
+    exact = "gauss" not in name
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    s = g["s0"].copy()[None, :]
+    assert not np.isnan(g["u"]).any()  # these rules always draw (spin_dynamics.py:162,183)
+    out = oracle.sweeps(prob, s, float(g["T"]), int(g["n_sweeps"]), site_mode=oracle.SITE_REPLAY,
+                        rule=rule, replay_site=g["site"], replay_u=g["u"], recompute_energy=True,
+                        trace=True)
+    assert np.array_equal(out["accept_trace"][0].astype(bool), g["accepted"])
+    assert np.array_equal(s[0], g["s_final"])
+    assert int(out["n_accepted"][0]) == int(g["n_accepted"])
+    if exact:
+        assert np.array_equal(out["dE_trace"][0], g["dE"])
+        assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+        s2 = g["s0"].copy()[None, :]  # incremental tracking uses the true dE for heat bath too
+        inc = oracle.sweeps(prob, s2, float(g["T"]), int(g["n_sweeps"]), rule=rule,
+                            site_mode=oracle.SITE_REPLAY, replay_site=g["site"], replay_u=g["u"])
+        assert np.array_equal(inc["energy_trace"][:, 0], g["sweep_energy"])
+    else:
+        assert np.allclose(out["dE_trace"][0], g["dE"], rtol=1e-5, atol=1e-5)
+
+
 def test_incremental_energy_equals_recompute_for_integer_couplings():
     g = load_golden("sweeps_field_n64")
     prob = oracle.Problem(J=g["J"], h=g["h"])
