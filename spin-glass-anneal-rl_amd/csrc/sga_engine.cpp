@@ -112,6 +112,7 @@ struct sga_engine {
     float *h = nullptr, *diag = nullptr;
     int tune_waves = 0, tune_spl = 0;
     int rule = SGA_RULE_METROPOLIS;
+    int table_m = 0;  // integer problems: largest possible |dE| / 2 (0 = not integer / too big)
 
     // replicas
     int R = 0, Rg = 0, replica0 = 0;
@@ -318,6 +319,7 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     e->free_replicas();
     e->free_problem();
     e->csr = false;
+    e->table_m = 0;
     e->n = n;
     HIPCHK(hipMalloc(&e->J_raw, sizeof(float) * (size_t)n * n));
     HIPCHK(hipMemcpy2DAsync(e->J_raw, sizeof(float) * (size_t)n, J, sizeof(float) * (size_t)ldJ,
@@ -394,6 +396,25 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
             }
     }
     HIPCHK(sga::launch_gather_diag_csr(e->rowptr, e->colidx, e->val, n, e->diag, e->stream));
+    // integer-valued problem?  then dE takes at most M = max_i(sum_j |J_ij| + |h_i|) even values
+    e->table_m = 0;
+    {
+        std::vector<float> hv((size_t)nnz), hh((size_t)n);
+        if (nnz > 0) HIPCHK(hipMemcpy(hv.data(), e->val, sizeof(float) * hv.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hh.data(), e->h, sizeof(float) * hh.size(), hipMemcpyDeviceToHost));
+        bool integral = true;
+        double m = 0.0;
+        for (int i = 0; i < n && integral; ++i) {
+            double row = std::fabs((double)hh[i]);
+            if (hh[i] != std::rint(hh[i])) integral = false;
+            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+                if (hv[k] != std::rint(hv[k])) { integral = false; break; }
+                row += std::fabs((double)hv[k]);
+            }
+            m = std::max(m, row);
+        }
+        if (integral && m >= 1.0 && m <= 2048.0) e->table_m = (int)m;
+    }
     return SGA_OK;
 }
 
@@ -421,6 +442,8 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         e->sstride = (e->n + 15) / 16 * 16;
         if ((size_t)e->sstride * sga::CSR_WAVES_PER_BLOCK > 160 * 1024)
             return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
+        if (((size_t)e->sstride + 4 * (size_t)(e->table_m + 1)) * sga::CSR_WAVES_PER_BLOCK > 160 * 1024)
+            e->table_m = 0;  // no room for the probability tables: general path
     }
     const size_t sb = (size_t)R_local * e->sstride;
     HIPCHK(hipMalloc(&e->spins, sb));
@@ -592,6 +615,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.site_mode = site_mode;
         a.arith = arith;
         a.rule = e->rule;
+        a.table_m = e->table_m;
         a.seed_lo = (uint32_t)e->seed;
         a.seed_hi = (uint32_t)(e->seed >> 32);
         a.sweep0 = e->sweeps_done + (uint32_t)k0;
@@ -1008,8 +1032,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     char tmp[512];
     if (e->csr)
         std::snprintf(tmp, sizeof(tmp),
-                      "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d",
-                      e->n, e->nnz, e->R, sga::CSR_WAVES_PER_BLOCK, e->sstride);
+                      "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d "
+                      "path=%s table_m=%d",
+                      e->n, e->nnz, e->R, sga::CSR_WAVES_PER_BLOCK, e->sstride,
+                      e->table_m > 0 ? "integer-fast" : "general", e->table_m);
     else
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d "

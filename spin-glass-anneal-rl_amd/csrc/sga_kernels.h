@@ -41,6 +41,7 @@ struct SweepArgs {
     long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
     int n, sstride, R, n_sweeps;
     int site_mode, arith, rule;
+    int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 

@@ -1,6 +1,8 @@
 // sweep_common.h -- pieces shared by the dense and CSR sweep kernels: where the site and the
 // uniform of an update come from, and the Metropolis accept rule.
 #pragma once
+#include <cstdlib>
+
 #include "sga.h"
 #include "sga_device.h"
 #include "sga_kernels.h"
@@ -13,13 +15,33 @@ struct UpdatePair {
     float uA, uB;
 };
 
+// Kernels are compiled twice: LEAN = the production configuration (Philox random sites,
+// Metropolis rule in the reference's fp64/fp32 arithmetic, no per-update traces) with every
+// mode test folded away at compile time -- fewer live scalars, no SGPR spills -- and the
+// general variant that also serves the replay / sequential / other-rule / traced modes.
+inline bool sweep_args_are_lean(const SweepArgs &a) {
+    static const bool force_general = std::getenv("SGA_FORCE_GENERAL") != nullptr;  // A/B switch
+    return !force_general && a.site_mode == SGA_SITE_RANDOM && a.arith == SGA_ARITH_F64 &&
+           a.rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
+}
+
 // Everything here is wave-uniform (blockIdx / loop counters / kernel arguments).
+template <bool LEAN>
 __device__ __forceinline__ UpdatePair fetch_pair(const SweepArgs &a, int r, int k, int b,
                                                  bool valid) {
     UpdatePair o{0, 0, 2.0f, 2.0f};
     if (!valid) return o;
     const int n = a.n, t0 = 2 * b, t1 = 2 * b + 1;
     const bool hasB = t1 < n;
+    if constexpr (LEAN) {
+        const u32x4 w = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)k,
+                                      a.replica0 + (uint32_t)r, DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+        o.sA = (int)word_to_site(w.x, (uint32_t)n);
+        o.sB = (int)word_to_site(w.z, (uint32_t)n);
+        o.uA = word_to_u(w.y);
+        o.uB = word_to_u(w.w);
+        return o;
+    }
     const long long base = (long long)r * a.replay_stride + (long long)k * n;
     if (a.site_mode == SGA_SITE_REPLAY) {
         // recorded stream of the reference: site = torch.randint(0, n, (1,)) at
@@ -52,6 +74,44 @@ __device__ __forceinline__ UpdatePair fetch_pair(const SweepArgs &a, int r, int 
     }
     return o;
 }
+
+// Supplier of consecutive update pairs (k, b), b = 0, 1, 2, ... within a sweep.
+//
+// General variant: one scalar Philox block per pair (fetch_pair).  LEAN variant: the Philox
+// counter is VECTORISED ACROSS THE WAVE -- lane l evaluates block (b & ~63) + l, so a single
+// pass of the 10 rounds through the VALU yields the next 64 blocks = 128 updates, and each
+// pair is then broadcast out of its lane with v_readlane.  Same counter -> output map as the
+// scalar form (bit-identical streams), but ~55 SALU instructions per update become ~2: the
+// CSR and small-dense kernels are issue-bound on exactly those.
+template <bool LEAN>
+struct PairSource {
+    uint32_t vsa, vua, vsb, vub;  // this lane's block: site A, u-bits A, site B, u-bits B
+
+    __device__ __forceinline__ UpdatePair get(const SweepArgs &a, int r, int k, int b, bool valid,
+                                              int lane) {
+        if constexpr (!LEAN) {
+            return fetch_pair<false>(a, r, k, b, valid);
+        } else {
+            UpdatePair o{0, 0, 2.0f, 2.0f};
+            if (!valid) return o;
+            if ((b & 63) == 0) {  // wave-uniform: a new batch starts here
+                const u32x4 w = philox4x32_10((uint32_t)(b + lane), a.sweep0 + (uint32_t)k,
+                                              a.replica0 + (uint32_t)r, DOMAIN_SWEEP, a.seed_lo,
+                                              a.seed_hi);
+                vsa = word_to_site(w.x, (uint32_t)a.n);
+                vua = w.y;
+                vsb = word_to_site(w.z, (uint32_t)a.n);
+                vub = w.w;
+            }
+            const int l = b & 63;
+            o.sA = __builtin_amdgcn_readlane((int)vsa, l);
+            o.sB = __builtin_amdgcn_readlane((int)vsb, l);
+            o.uA = word_to_u((uint32_t)__builtin_amdgcn_readlane((int)vua, l));
+            o.uB = word_to_u((uint32_t)__builtin_amdgcn_readlane((int)vub, l));
+            return o;
+        }
+    }
+};
 
 // The accept rule.  dot = fp32 coupling dot product J[site,:].s (already rounded to fp32),
 // si = s[site] (+-1).  Returns true if the spin flips; dE receives the energy change of the

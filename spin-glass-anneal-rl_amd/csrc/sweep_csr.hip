@@ -1,4 +1,4 @@
-// sweep_csr.hip -- Metropolis sweep over CSR couplings (BASELINE config 3: N = 10k, degree
+// sweep_csr.hip -- single-spin sweep over CSR couplings (BASELINE config 3: N = 10k, degree
 // ~32, 4096 replicas).
 //
 // Replaces the same reference functions as the dense kernel (core/spin_dynamics.py:73-94,
@@ -9,14 +9,25 @@
 // Mapping: one replica per wavefront, CSR_WAVES_PER_BLOCK independent replicas per
 // workgroup (no workgroup barrier anywhere: each wave owns a private LDS slice holding its
 // replica's spins).  A row has ~32 entries, i.e. one (colidx, val) wave-load each; the spin
-// gather goes through LDS; the dot is a DPP wave sum.  The site sequence is known ahead of
-// time (counter RNG), so the next update's row extent and entries are loaded while the
-// current one is reduced.
+// gather goes through LDS; the dot is a DPP wave sum.  The structure (2.6 MB at C3) is
+// L2-resident, so the kernel is bound by instruction issue and the dependent-load chain,
+// not by HBM; hence:
+//   * the site sequence is known ahead of time (counter RNG): row extents are loaded one
+//     PAIR of updates ahead and row entries one update ahead, so no update waits on a
+//     rowptr -> colidx dependent load;
+//   * FAST variant (integer-valued J and h, sum_j |J_ij| + |h_i| <= M small): the row sum is
+//     accumulated in fp32 (exact), and the Metropolis probability exp(float32(-dE/T)) of the
+//     M possible uphill moves dE = 2k is tabulated in LDS once per sweep -- the same function
+//     of the same arguments, so decisions are bit-identical to the general path -- which
+//     removes the fp64 divide and the exp from the per-update chain.
 #include "sweep_common.h"
 
 namespace sga {
 
+template <bool FAST, bool LEAN>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(const SweepArgs a) {
+    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
+    const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -25,76 +36,111 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
     if (r >= a.R) return;  // wave-uniform; no barriers below
     const int n = a.n;
     int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)w * a.sstride;
+    float *ptab = reinterpret_cast<float *>(smem + (long long)CSR_WAVES_PER_BLOCK * a.sstride) +
+                  (long long)w * (a.table_m + 1);
     {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
         int4 *dst = reinterpret_cast<int4 *>(s);
         for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
     }
-    const bool arith32 = a.arith == SGA_ARITH_F32;
+    const bool arith32 = arith == SGA_ARITH_F32;
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
 
-    // prefetched head of a row: extent, and its first 64 entries (one per lane)
-    struct RowHead {
-        int beg, end, col;
-        float val, h, d;
+    struct Extent {  // what is indexed by the site alone
+        int beg, end;
+        float h, d;
     };
-    auto load_head = [&](int site) {
-        RowHead o;
+    struct Head {  // first 64 stored entries of the row, one per lane
+        int col;
+        float val;
+    };
+    auto load_extent = [&](int site) {
+        Extent o;
         o.beg = a.rowptr[site];
         o.end = a.rowptr[site + 1];
-        const int j = o.beg + lane;
-        const bool in = j < o.end;
-        o.col = in ? a.colidx[j] : 0;
-        o.val = in ? a.val[j] : 0.0f;
         o.h = a.h[site];
         o.d = arith32 ? a.diag[site] : 0.0f;
         return o;
     };
+    auto load_head = [&](const Extent &x) {
+        Head o;
+        const int j = x.beg + lane;
+        const bool in = j < x.end;
+        o.col = in ? a.colidx[j] : 0;
+        o.val = in ? a.val[j] : 0.0f;
+        return o;
+    };
+
+    double T = 1.0;
+    auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
+        // J[site,:].s over the stored entries; products val * (+-1) are exact
+        float dot;
+        if constexpr (FAST) {
+            float acc = hd.val * (float)s[hd.col];
+            for (int j = x.beg + 64 + lane; j < x.end; j += 64)
+                acc += a.val[j] * (float)s[a.colidx[j]];
+            dot = wave_sum(acc);
+        } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
+            double acc = (double)(hd.val * (float)s[hd.col]);
+            for (int j = x.beg + 64 + lane; j < x.end; j += 64)
+                acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
+            dot = (float)wave_sum(acc);
+        }
+        const int si = s[site];
+        double dE;
+        bool flip;
+        if (FAST && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
+            // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2k exactly
+            const float fk = (float)si * (dot + x.h);
+            dE = (double)(2.0f * fk);
+            flip = fk <= 0.0f || u < ptab[(int)fk];
+        } else {
+            flip = metropolis_accept(rule, arith, dot, si, x.h, x.d, T, u, dE);
+        }
+        if (flip) {
+            E += dE;
+            ++nacc;
+            if (lane == 0) s[site] = (int8_t)(-si);
+        }
+        if constexpr (!LEAN) {
+            if (lane == 0) {
+                if (a.accept_trace)
+                    a.accept_trace[(long long)r * a.replay_stride + upd] = flip ? 1 : 0;
+                if (a.dE_trace)
+                    a.dE_trace[(long long)r * a.replay_stride + upd] =
+                        flip ? (rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
+            }
+        }
+    };
 
     const int nb = (n + 1) >> 1;
-    UpdatePair cur = fetch_pair(a, r, 0, 0, a.n_sweeps > 0);
-    RowHead head = load_head(cur.sA);
+    PairSource<LEAN> rng;
+    UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
+    Extent xA = load_extent(cur.sA), xB = load_extent(cur.sB);
+    Head hA = load_head(xA);
 
     for (int k = 0; k < a.n_sweeps; ++k) {
-        const double T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        if constexpr (FAST) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
+            for (int q = lane; q <= a.table_m; q += 64)
+                ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+        }
         for (int b = 0; b < nb; ++b) {
             const bool last = (b + 1 == nb);
             const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
-            const UpdatePair nxt = fetch_pair(a, r, kn, bn, kn < a.n_sweeps);
+            const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
             const bool hasB = (2 * b + 1) < n;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half == 1 && !hasB) break;
-                const int site = half ? cur.sB : cur.sA;
-                const float u = half ? cur.uB : cur.uA;
-                const int site_next = (half == 0 && hasB) ? cur.sB : nxt.sA;
-                const RowHead nh = load_head(site_next);  // in flight during the reduction
-                // J[site,:].s over the stored entries: products are exact (val * +-1), the
-                // sum is formed in fp64 and rounded to fp32 once (core/ising_model.py:183)
-                double acc = (double)(head.val * (float)s[head.col]);
-                for (int j = head.beg + 64 + lane; j < head.end; j += 64)
-                    acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
-                const float dot = (float)wave_sum(acc);
-                const int si = s[site];
-                double dE;
-                const bool acc_flip = metropolis_accept(a.rule, a.arith, dot, si, head.h, head.d, T, u, dE);
-                if (acc_flip) {
-                    E += dE;
-                    ++nacc;
-                    if (lane == 0) s[site] = (int8_t)(-si);
-                }
-                if (lane == 0) {
-                    const long long upd = (long long)k * n + 2 * b + half;
-                    if (a.accept_trace)
-                        a.accept_trace[(long long)r * a.replay_stride + upd] = acc_flip ? 1 : 0;
-                    if (a.dE_trace)
-                        a.dE_trace[(long long)r * a.replay_stride + upd] =
-                            acc_flip ? (a.rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
-                }
-                head = nh;
-            }
+            const Extent nA = load_extent(nxt.sA), nB = load_extent(nxt.sB);  // a pair ahead
+            Head hB{0, 0.0f};
+            if (hasB) hB = load_head(xB);  // in flight while A is reduced
+            update(cur.sA, cur.uA, xA, hA, (long long)k * n + 2 * b);
+            const Head hN = load_head(nA);  // in flight while B is reduced
+            if (hasB) update(cur.sB, cur.uB, xB, hB, (long long)k * n + 2 * b + 1);
             cur = nxt;
+            xA = nA;
+            xB = nB;
+            hA = hN;
         }
         if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE) {  // annealing/gpu_annealer.py:151-153
@@ -117,15 +163,20 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
 }
 
 hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)a.sstride * CSR_WAVES_PER_BLOCK;
+    const bool fast = a.table_m > 0;
+    const size_t lds = (size_t)a.sstride * CSR_WAVES_PER_BLOCK +
+                       (fast ? sizeof(float) * (size_t)(a.table_m + 1) * CSR_WAVES_PER_BLOCK : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const bool lean = sweep_args_are_lean(a);
+    auto kern = fast ? (lean ? sweep_csr_kernel<true, true> : sweep_csr_kernel<true, false>)
+                     : (lean ? sweep_csr_kernel<false, true> : sweep_csr_kernel<false, false>);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_csr_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int blocks = (a.R + CSR_WAVES_PER_BLOCK - 1) / CSR_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(sweep_csr_kernel, dim3(blocks), dim3(64 * CSR_WAVES_PER_BLOCK), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * CSR_WAVES_PER_BLOCK), lds, st, a);
     return hipGetLastError();
 }
 

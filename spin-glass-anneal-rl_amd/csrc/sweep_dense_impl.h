@@ -51,8 +51,10 @@ struct AccType<int8_t, ACC64> {
 constexpr int PART_SLOT_BYTES = 8;
 constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * PART_SLOT_BYTES + 16;
 
-template <typename JT, int CPW, bool ACC64>
+template <typename JT, int CPW, bool ACC64, bool LEAN>
 __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
+    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
+    const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     using TR = JTraits<JT>;
     using vec_t = typename TR::vec_t;
     using acc_t = typename AccType<JT, ACC64>::type;
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     const long long kstride = (long long)W * EPC;  // elements between a wave's chunks
     const JT *Jlane = reinterpret_cast<const JT *>(a.J) + (w * EPC + lane * EPL);
     const int8_t *slane = s_lds + (w * EPC + lane * EPL);
-    const bool arith32 = a.arith == SGA_ARITH_F32;
+    const bool arith32 = arith == SGA_ARITH_F32;
 
     auto load_row = [&](vec_t(&buf)[CPW], int site) {
         const JT *p = Jlane + (long long)site * a.ld;
@@ -150,23 +152,27 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             si = s_lds[site];
         }
         double dE;
-        const bool acc = metropolis_accept(a.rule, a.arith, (float)tot, si, h_site, d_site, T, u, dE);
+        const bool acc = metropolis_accept(rule, arith, (float)tot, si, h_site, d_site, T, u, dE);
         if (acc) {
             E += dE;
             ++nacc;
             if (w == owner && lane == 0) s_lds[site] = (int8_t)(-si);
         }
-        if (tid == 0) {
-            if (a.accept_trace) a.accept_trace[(long long)r * a.replay_stride + upd] = acc ? 1 : 0;
-            if (a.dE_trace)
-                a.dE_trace[(long long)r * a.replay_stride + upd] =
-                    acc ? (a.rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
+        if constexpr (!LEAN) {
+            if (tid == 0) {
+                if (a.accept_trace)
+                    a.accept_trace[(long long)r * a.replay_stride + upd] = acc ? 1 : 0;
+                if (a.dE_trace)
+                    a.dE_trace[(long long)r * a.replay_stride + upd] =
+                        acc ? (rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
+            }
         }
     };
 
     const int nb = (n + 1) >> 1;
     vec_t X[CPW], Y[CPW];
-    UpdatePair cur = fetch_pair(a, r, 0, 0, a.n_sweeps > 0);
+    PairSource<LEAN> rng;
+    UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
     load_row(X, cur.sA);
     float hX = a.h[cur.sA], dX = arith32 ? a.diag[cur.sA] : 0.0f;
 
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         for (int b = 0; b < nb; ++b) {
             const bool last = (b + 1 == nb);
             const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
-            const UpdatePair nxt = fetch_pair(a, r, kn, bn, kn < a.n_sweeps);
+            const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
             const bool hasB = (2 * b + 1) < n;
             const int sY = hasB ? cur.sB : nxt.sA;
             load_row(Y, sY);  // in flight while X is reduced
@@ -222,7 +228,8 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 template <typename JT, bool ACC64, int CPW>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     const size_t lds = (size_t)a.ld + DENSE_LDS_EXTRA;
-    auto kern = sweep_dense_kernel<JT, CPW, ACC64>;
+    auto kern = sweep_args_are_lean(a) ? sweep_dense_kernel<JT, CPW, ACC64, true>
+                                       : sweep_dense_kernel<JT, CPW, ACC64, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
