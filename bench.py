@@ -143,6 +143,11 @@ def main():
     ap.add_argument("--exchange-interval", type=int, default=10)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-rank path on one GPU together with --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,14 +157,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if a.backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import spin_glass_anneal_rl_amd as sg
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
@@ -180,7 +191,7 @@ def main():
         eng.set_csr(*csr, h)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
                           slot_temps=geometric_ladder(Rg), n_ladders=1,
-                          dist=dist, device=dev)
+                          dist=dist, device=comm_dev)
     geometry = eng.describe()
 
     def barrier():
@@ -210,7 +221,7 @@ def main():
     launches, kernel_ms = eng.kernel_time(reset=True)
     eng.enable_timing(False)
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

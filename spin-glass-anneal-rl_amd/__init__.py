@@ -19,6 +19,8 @@ from .kernel_manager import CUDAKernelManager, GPUMemoryOptimizer, HIPKernelMana
 from .scheduler import SpinGlassScheduler
 from .sharded import LocalShardedTempering, ShardedTempering
 from .multi_gpu import MultiGPUAnnealer, MultiGPUConfig
+from . import encoders
+from .encoders import IsingBuilder
 
 __all__ = [
     "_native", "AnnealEngine", "op_pt_exchange", "SpinGlassError", "AnnealingError",
@@ -28,4 +30,5 @@ __all__ = [
     "GPUAnnealer", "GPUAnnealerConfig", "ParallelTempering", "ParallelTemperingConfig",
     "HIPKernelManager", "CUDAKernelManager", "GPUMemoryOptimizer", "SpinGlassScheduler",
     "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig",
+    "encoders", "IsingBuilder",
 ]

@@ -311,6 +311,75 @@ def case_operator(name, J, h, T, seed, out):
     print(f"{name}: accepted={accepted} E={energy} pt_exchanges={n_ex} n_u={len(us)}")
 
 
+def case_encoders(out):
+    """What the reference's encoders write into J and h (core/constraints.py:51-158,360-377;
+    problems/routing.py:250-328; problems/scheduling.py:67-285), on dense models (the mode in
+    which its per-element accumulation works) and on its default sparse model (where
+    constraints.py:376 overwrites instead of accumulating)."""
+    from spin_glass_rl.core.constraints import ConstraintEncoder
+    from spin_glass_rl.problems.routing import TSPProblem, Location
+    from spin_glass_rl.problems.scheduling import SchedulingProblem, Task, Agent
+    from spin_glass_rl.problems import base as pbase
+    d = {}
+
+    def apply_all(model):
+        enc = ConstraintEncoder(model)
+        enc.add_cardinality_constraint(list(range(0, 6)), k=2, penalty_weight=8.0)
+        enc.add_equality_constraint([3, 4, 7, 9], [1.0, -2.0, 0.5, 3.0], 1.5, penalty_weight=2.0)
+        enc.add_cardinality_constraint(list(range(6, 12)), k=1, penalty_weight=100.0)
+        enc.add_inequality_constraint([0, 11], [1.0, 1.0], 0.0, penalty_weight=3.0)
+        return enc
+
+    md = IsingModel(IsingModelConfig(n_spins=12, use_sparse=False))
+    enc = apply_all(md)
+    d["con_dense_J"], d["con_dense_h"] = md.couplings.numpy().copy(), md.external_fields.numpy().copy()
+    g = torch.Generator().manual_seed(4)
+    probe = (torch.randint(0, 2, (6, 12), generator=g) * 2 - 1).float()
+    d["con_probe_spins"] = probe.numpy().astype(np.int8)
+    d["con_probe_violation"] = np.asarray(
+        [enc.evaluate_all_constraints(p)["total_violation"] for p in probe], np.float64)
+    ms = IsingModel(IsingModelConfig(n_spins=12, use_sparse=True))
+    apply_all(ms)
+    d["con_sparse_J"] = ms.couplings.to_dense().numpy().copy()
+    d["con_sparse_h"] = ms.external_fields.numpy().copy()
+
+    # problem encoders, forced onto dense models (their sparse default cannot index couplings)
+    orig_create = pbase.ProblemTemplate.create_ising_model
+
+    def dense_create(self, n_spins, device="cpu"):
+        model = IsingModel(IsingModelConfig(n_spins=n_spins, use_sparse=False, device=device))
+        self.constraint_encoder = ConstraintEncoder(model)
+        return model
+
+    pbase.ProblemTemplate.create_ising_model = dense_create
+    try:
+        tsp = TSPProblem()
+        xy = [(0.0, 0.0), (3.0, 4.0), (6.0, 0.0), (3.0, -2.0), (1.0, 5.0)]
+        for i, (x, y) in enumerate(xy):
+            tsp.add_location(Location(i, f"c{i}", x, y))
+        m = tsp.encode_to_ising(penalty_weights={"city_visit": 40.0, "position_fill": 30.0})
+        d["tsp_xy"] = np.asarray(xy)
+        d["tsp_dist"] = np.asarray(tsp.distance_matrix, np.float64)
+        d["tsp_J"], d["tsp_h"] = m.couplings.numpy().copy(), m.external_fields.numpy().copy()
+
+        sch = SchedulingProblem()
+        sch.time_horizon, sch.time_discretization = 8.0, 4
+        for i, (dur, due, pr) in enumerate([(2.0, None, 1.0), (4.0, 6.0, 2.0), (1.0, 3.0, 0.5)]):
+            sch.add_task(Task(id=i, duration=dur, due_date=due, priority=pr))
+        for j in range(2):
+            sch.add_agent(Agent(id=j, name=f"a{j}"))
+        m = sch.encode_to_ising(objective="makespan",
+                                penalty_weights={"assignment": 100.0, "capacity": 50.0,
+                                                 "time_window": 60.0})
+        d["sched_durations"] = np.asarray([2.0, 4.0, 1.0])
+        d["sched_due"] = np.asarray([np.nan, 6.0, 3.0])
+        d["sched_J"], d["sched_h"] = m.couplings.numpy().copy(), m.external_fields.numpy().copy()
+    finally:
+        pbase.ProblemTemplate.create_ising_model = orig_create
+    np.savez_compressed(os.path.join(out, "encoders.npz"), kind="encoders", **d)
+    print("encoders: ok", {k: v.shape for k, v in d.items() if hasattr(v, "shape")})
+
+
 def case_schedules(out):
     """TemperatureSchedule.get_temperature tables (temperature_scheduler.py:68-213)."""
     d = {}
@@ -391,6 +460,8 @@ def main():
         case_operator("operator_n48", pm1_couplings(48, 6), h, 1.7, 21, a.out)
     if want("schedules"):
         case_schedules(a.out)
+    if want("encoders"):
+        case_encoders(a.out)
 
 
 if __name__ == "__main__":

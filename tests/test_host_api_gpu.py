@@ -315,6 +315,34 @@ def test_multi_gpu_annealer_interface(sg):
                             acfg).anneal(model_from(sg, g["J"], g["h"]))
 
 
+def test_encoded_instances_anneal_to_feasible_solutions(sg):
+    """Encoders -> engine: assignment (C2b-shaped) and scheduling (C4-shaped, CSR) instances
+    built in the physical convention reach zero-penalty configurations."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    rng = np.random.RandomState(1)
+    costs = rng.randint(1, 20, (12, 12)).astype(float)
+    b = enc.assignment_ising(12, 12, weight=40.0, costs=costs)
+    sch = sg.SpinGlassScheduler(device="cuda", random_seed=3)
+    res = sch.anneal(b.to_model(sparse=False), n_replicas=128, n_sweeps=400, beta_min=0.02,
+                     beta_max=2.0)
+    x = (res.best_configuration.numpy().reshape(12, 12) > 0)
+    assert np.all(x.sum(0) == 1) and np.all(x.sum(1) == 1), "not a permutation"
+    assert res.best_energy + b.constant == pytest.approx(costs[x].sum())
+    from scipy.optimize import linear_sum_assignment
+    r, c = linear_sum_assignment(costs)
+    assert costs[x].sum() <= 1.25 * costs[r, c].sum()
+    # scheduling: 40 unit tasks, 1 agent, 40 slots -> every task alone in a slot
+    s = enc.scheduling_ising(np.full(40, 1.0), n_agents=1, time_horizon=40.0,
+                             time_discretization=40,
+                             penalty_weights={"assignment": 100.0, "capacity": 50.0})
+    m = s.to_model(sparse=True)
+    res = sch.anneal(m, n_replicas=256, n_sweeps=600, beta_min=0.01, beta_max=1.0)
+    y = (res.best_configuration.numpy().reshape(40, 40) > 0)
+    assert np.all(y.sum(1) == 1) and np.all(y.sum(0) <= 1)
+    prob = oracle.Problem(csr=s.to_csr(), h=s.fields())
+    assert oracle.energy(prob, res.best_configuration.numpy().astype(np.int8)) == res.best_energy
+
+
 # ----------------------------------------------------------------------------- full size
 def test_full_size_c2_properties(sg):
     """BASELINE configs[1] at full size (10 000 spins, 1024 replicas): size-independent
