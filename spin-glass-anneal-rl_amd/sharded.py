@@ -55,6 +55,9 @@ class ShardedTempering:
             return self._all_E
         if self.dist.get_backend() == "nccl":
             self.dist.all_gather_into_tensor(self._all_E, self._local_E)
+            # the engine launches on its own HIP stream: the gathered vector must be complete
+            # before sga_exchange reads it (8 KiB collective -- the wait is microseconds)
+            torch.cuda.current_stream(self._all_E.device).synchronize()
         else:
             parts = list(self._all_E.chunk(self.world))
             self.dist.all_gather(parts, self._local_E)
