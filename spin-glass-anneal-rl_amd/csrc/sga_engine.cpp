@@ -227,7 +227,7 @@ int ensure_packed(sga_engine *e) {
                         std::to_string(e->n) + "); use CSR or int8 couplings");
     const long long ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
     if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
-    if (sga::sweep_dense_lds_bytes(ld, W) > 160 * 1024)
+    if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
         return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     dev_free(e->J_packed);
     const size_t bytes = (size_t)e->n * ld * (e->want_i8 ? 1 : 4);
@@ -344,6 +344,22 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     e->want_i8 = (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
     // fp32 partial sums are exact when every J is an integer below 2^10 and n < 2^14
     e->acc64 = !e->want_i8 && !(hflags[1] == 0 && n <= 16384);
+    // integer problem with few possible uphill moves -> per-sweep accept table in LDS
+    {
+        unsigned int *d_out = nullptr, h_out[2] = {0u, 1u};
+        HIPCHK(hipMalloc(&d_out, 2 * sizeof(unsigned int)));
+        hipError_t he = hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned int), e->stream);
+        if (he == hipSuccess) he = sga::launch_dense_row_abs_max(e->J_raw, n, e->h, n, d_out, e->stream);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        (void)hipFree(d_out);
+        HIPCHK(he);
+        float m;
+        std::memcpy(&m, &h_out[0], sizeof(float));
+        if (h_out[1] == 0u && m >= 1.0f && m <= 2048.0f && (e->want_i8 || !e->acc64))
+            e->table_m = (int)m;
+    }
     return ensure_packed(e);
 }
 
@@ -1039,10 +1055,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     else
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d "
-                      "ld=%lld row_bytes=%lld",
+                      "ld=%lld row_bytes=%lld table_m=%d",
                       e->n, e->want_i8 ? "i8" : "f32",
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
-                      e->ld, e->ld * (e->want_i8 ? 1 : 4));
+                      e->ld, e->ld * (e->want_i8 ? 1 : 4), e->table_m);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;
 }

@@ -59,6 +59,40 @@ hipError_t launch_scan_values(const float *v, long long rows, long long cols, lo
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__restrict__ J,
+                                                                long long ldJ,
+                                                                const float *__restrict__ h, int n,
+                                                                unsigned int *out) {
+    __shared__ double red[4];
+    __shared__ int bad[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double acc = 0.0;
+    int nonint = 0;
+    for (int j = tid; j < n; j += 256) {
+        const float x = J[(long long)i * ldJ + j];
+        acc += (double)__builtin_fabsf(x);
+        nonint |= (x != __builtin_rintf(x));
+    }
+    const double ws = wave_sum(acc);
+    const int wb = wave_sum(nonint);
+    if (lane == 0) {
+        red[w] = ws;
+        bad[w] = wb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float hi = h[i];
+        const float row = (float)((red[0] + red[1]) + (red[2] + red[3]) + (double)__builtin_fabsf(hi));
+        atomicMax(&out[0], __builtin_bit_cast(unsigned int, row));  // non-negative: bit order = value order
+        if (bad[0] | bad[1] | bad[2] | bad[3] | (hi != __builtin_rintf(hi))) atomicOr(&out[1], 1u);
+    }
+}
+hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, int n,
+                                    unsigned int *out, hipStream_t st) {
+    hipLaunchKernelGGL(dense_row_abs_max_kernel, dim3(n), dim3(256), 0, st, J, ldJ, h, n, out);
+    return hipGetLastError();
+}
+
 __global__ void gather_diag_csr_kernel(const int32_t *rowptr, const int32_t *colidx,
                                        const float *val, int n, float *diag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,5 +14,7 @@ hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int 
     return acc64 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
                  : launch_sweep_dense_f32(a, waves, cpw, st);
 }
-size_t sweep_dense_lds_bytes(long long ld, int) { return (size_t)ld + DENSE_LDS_EXTRA; }
+size_t sweep_dense_lds_bytes(long long ld, int table_m) {
+    return (size_t)ld + DENSE_LDS_EXTRA + sizeof(float) * (size_t)(table_m + 1);
+}
 }  // namespace sga

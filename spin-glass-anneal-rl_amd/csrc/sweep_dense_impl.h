@@ -64,6 +64,10 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     int8_t *s_lds = reinterpret_cast<int8_t *>(smem);                      // [ld]
     unsigned char *part_raw = smem + a.ld;                                 // [2][MAX_WAVES] 8-B slots
     int *sislot = reinterpret_cast<int *>(smem + a.ld + 2 * MAX_WAVES * PART_SLOT_BYTES);  // [2]
+    // integer problems with few distinct uphill moves: exp(float32(-dE/T)) tabulated per sweep
+    // (bit-identical decisions, no fp64 divide / exp on the per-update chain); LEAN only
+    float *ptab = reinterpret_cast<float *>(smem + a.ld + DENSE_LDS_EXTRA);  // [table_m + 1]
+    const bool use_tab = LEAN && a.table_m > 0;
 
     const int tid = threadIdx.x;
     const int W = blockDim.x >> 6;
@@ -152,7 +156,14 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             si = s_lds[site];
         }
         double dE;
-        const bool acc = metropolis_accept(rule, arith, (float)tot, si, h_site, d_site, T, u, dE);
+        bool acc;
+        if (use_tab) {  // every quantity is an integer: dE = 2 k exactly, k <= table_m
+            const float fk = (float)si * ((float)tot + h_site);
+            dE = (double)(2.0f * fk);
+            acc = fk <= 0.0f || u < ptab[(int)fk];
+        } else {
+            acc = metropolis_accept(rule, arith, (float)tot, si, h_site, d_site, T, u, dE);
+        }
         if (acc) {
             E += dE;
             ++nacc;
@@ -178,6 +189,12 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        if (use_tab) {
+            __syncthreads();  // nobody still reads last sweep's table
+            for (int q = tid; q <= a.table_m; q += blockDim.x)
+                ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+            __syncthreads();
+        }
         for (int b = 0; b < nb; ++b) {
             const bool last = (b + 1 == nb);
             const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
@@ -227,7 +244,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 
 template <typename JT, bool ACC64, int CPW>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
-    const size_t lds = (size_t)a.ld + DENSE_LDS_EXTRA;
+    const size_t lds = (size_t)a.ld + DENSE_LDS_EXTRA + sizeof(float) * (size_t)(a.table_m + 1);
     auto kern = sweep_args_are_lean(a) ? sweep_dense_kernel<JT, CPW, ACC64, true>
                                        : sweep_dense_kernel<JT, CPW, ACC64, false>;
     if (lds > 48 * 1024) {
