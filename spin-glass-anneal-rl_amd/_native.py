@@ -10,7 +10,7 @@ import subprocess
 from .exceptions import AnnealingError, DeviceError, ResourceError
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libsga.so")
+_SO = os.environ.get("SGA_LIBRARY_PATH") or os.path.join(_CSRC, "libsga.so")  # env: A/B builds
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_MEMORY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 J_AUTO, J_F32, J_I8 = 0, 1, 2

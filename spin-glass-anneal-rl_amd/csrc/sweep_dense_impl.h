@@ -91,6 +91,8 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     auto load_row = [&](vec_t(&buf)[CPW], int site) {
         const JT *p = Jlane + (long long)site * a.ld;
 #pragma unroll
+        // default cache policy on purpose: non-temporal loads measured 3-5 % slower here (part
+        // of J is re-served by the 256 MB Infinity Cache; profiles/r01_experiments.md)
         for (int k = 0; k < CPW; ++k) buf[k] = *reinterpret_cast<const vec_t *>(p + k * kstride);
     };
 
