@@ -195,7 +195,11 @@ bool choose_geometry(int n, bool i8, int R, int forced_waves, int &W, int &CPW) 
             CPW = cpw;
         }
     }
-    return W > 0;
+    if (W == 0) {  // row too long for the register-resident form: streaming kernel, 16 waves
+        W = forced_waves > 0 ? forced_waves : sga::MAX_WAVES;
+        CPW = (C + W - 1) / W;
+    }
+    return true;
 }
 
 int recompute_energy_range(sga_engine *e, int r0, int count) {
@@ -221,10 +225,7 @@ int ensure_packed(sga_engine *e) {
     if (e->csr) return SGA_OK;
     if (!e->J_raw) return fail(SGA_ERR_INVALID, "no couplings set");
     int W, CPW;
-    if (!choose_geometry(e->n, e->want_i8, std::max(e->R, 1), e->tune_waves, W, CPW))
-        return fail(SGA_ERR_UNSUPPORTED,
-                    "dense row too long for the register-resident sweep kernel (n=" +
-                        std::to_string(e->n) + "); use CSR or int8 couplings");
+    choose_geometry(e->n, e->want_i8, std::max(e->R, 1), e->tune_waves, W, CPW);
     const long long ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
     if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
     if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
@@ -644,7 +645,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             HIPCHK(hipEventRecord(ev0, st));
         }
         hipError_t le = e->csr ? sga::launch_sweep_csr(a, st)
-                               : sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves, e->cpw, st);
+                               : sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
+                                                         e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
         if (e->timing) {
             (void)hipEventRecord(ev1, st);
             e->events.emplace_back(ev0, ev1);
@@ -1054,11 +1056,12 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->table_m > 0 ? "integer-fast" : "general", e->table_m);
     else
         std::snprintf(tmp, sizeof(tmp),
-                      "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d "
+                      "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d%s "
                       "ld=%lld row_bytes=%lld table_m=%d",
                       e->n, e->want_i8 ? "i8" : "f32",
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
-                      e->ld, e->ld * (e->want_i8 ? 1 : 4), e->table_m);
+                      e->cpw > sga::MAX_CPW ? "(streaming)" : "", e->ld,
+                      e->ld * (e->want_i8 ? 1 : 4), e->table_m);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;
 }

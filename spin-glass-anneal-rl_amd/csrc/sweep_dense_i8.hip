@@ -9,7 +9,7 @@ hipError_t launch_sweep_dense_f32acc64(const SweepArgs &, int, int, hipStream_t)
 
 hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
                               hipStream_t st) {
-    if (waves < 1 || waves > MAX_WAVES || cpw < 1 || cpw > MAX_CPW) return hipErrorInvalidValue;
+    if (waves < 1 || waves > MAX_WAVES || cpw < 0 || cpw > MAX_CPW) return hipErrorInvalidValue;
     if (j_is_i8) return launch_sweep_dense_i8(a, waves, cpw, st);
     return acc64 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
                  : launch_sweep_dense_f32(a, waves, cpw, st);

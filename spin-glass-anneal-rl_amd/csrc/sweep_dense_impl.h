@@ -16,7 +16,11 @@
 //     while row t is reduced: CPW KiB per wave stay in flight across the per-update
 //     barrier (plain loads survive s_barrier);
 //   * per update: lane partial -> DPP wave sum -> W partials through LDS (one barrier,
-//     double-buffered slots) -> every thread evaluates the same accept rule.
+//     double-buffered slots) -> every thread evaluates the same accept rule;
+//   * CPW = 0 selects the STREAMING form for rows too long for the register buffers
+//     (n > 40 960 fp32 / 163 840 int8 elements per 16 waves x 10 chunks): each wave walks its
+//     chunks in batches of four loads and reduces them on the fly (no cross-update prefetch;
+//     at those sizes 16 waves x 3+ workgroups per CU keep enough bytes in flight).
 #pragma once
 #include "sweep_common.h"
 
@@ -88,7 +92,11 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     const int8_t *slane = s_lds + (w * EPC + lane * EPL);
     const bool arith32 = arith == SGA_ARITH_F32;
 
-    auto load_row = [&](vec_t(&buf)[CPW], int site) {
+    constexpr int NBUF = CPW > 0 ? CPW : 1;
+    const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
+
+    auto load_row = [&](vec_t(&buf)[NBUF], int site) {
+        if constexpr (CPW == 0) return;  // streaming form loads inside the reduction
         const JT *p = Jlane + (long long)site * a.ld;
 #pragma unroll
         // default cache policy on purpose: non-temporal loads measured 3-5 % slower here (part
@@ -96,34 +104,51 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         for (int k = 0; k < CPW; ++k) buf[k] = *reinterpret_cast<const vec_t *>(p + k * kstride);
     };
 
-    auto dot_row = [&](const vec_t(&buf)[CPW]) -> acc_t {
+    auto accumulate = [&](acc_t &acc, const vec_t &x, long long k) {
+        if constexpr (sizeof(JT) == 4) {  // J * (+-1) is exact in fp32
+            const int sw = *reinterpret_cast<const int *>(slane + k * kstride);
+            const float s0 = (float)(int8_t)(sw), s1 = (float)(int8_t)(sw >> 8),
+                        s2 = (float)(int8_t)(sw >> 16), s3 = (float)(sw >> 24);
+            if constexpr (ACC64) {
+                acc += (double)(x.x * s0);
+                acc += (double)(x.y * s1);
+                acc += (double)(x.z * s2);
+                acc += (double)(x.w * s3);
+            } else {
+                acc = __builtin_fmaf(x.x, s0, acc);
+                acc = __builtin_fmaf(x.y, s1, acc);
+                acc = __builtin_fmaf(x.z, s2, acc);
+                acc = __builtin_fmaf(x.w, s3, acc);
+            }
+        } else {
+            const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstride);
+            acc = __builtin_amdgcn_sdot4(x.x, sv.x, acc, false);
+            acc = __builtin_amdgcn_sdot4(x.y, sv.y, acc, false);
+            acc = __builtin_amdgcn_sdot4(x.z, sv.z, acc, false);
+            acc = __builtin_amdgcn_sdot4(x.w, sv.w, acc, false);
+        }
+    };
+
+    // streaming reduction of row `site`: batches of four 1-KiB chunks per wave
+    auto dot_stream = [&](int site) -> acc_t {
+        const JT *p = Jlane + (long long)site * a.ld;
+        acc_t acc = 0;
+        for (int k0 = 0; k0 < cpw_rt; k0 += 4) {
+            vec_t t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < cpw_rt) t[j] = *reinterpret_cast<const vec_t *>(p + (k0 + j) * kstride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < cpw_rt) accumulate(acc, t[j], k0 + j);
+        }
+        return acc;
+    };
+
+    auto dot_row = [&](const vec_t(&buf)[NBUF]) -> acc_t {
         acc_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-            if constexpr (sizeof(JT) == 4) {
-                const int sw = *reinterpret_cast<const int *>(slane + k * kstride);
-                const float s0 = (float)(int8_t)(sw), s1 = (float)(int8_t)(sw >> 8),
-                            s2 = (float)(int8_t)(sw >> 16), s3 = (float)(sw >> 24);
-                // J * (+-1) is exact in fp32
-                if constexpr (ACC64) {
-                    acc += (double)(buf[k].x * s0);
-                    acc += (double)(buf[k].y * s1);
-                    acc += (double)(buf[k].z * s2);
-                    acc += (double)(buf[k].w * s3);
-                } else {
-                    acc = __builtin_fmaf(buf[k].x, s0, acc);
-                    acc = __builtin_fmaf(buf[k].y, s1, acc);
-                    acc = __builtin_fmaf(buf[k].z, s2, acc);
-                    acc = __builtin_fmaf(buf[k].w, s3, acc);
-                }
-            } else {
-                const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstride);
-                acc = __builtin_amdgcn_sdot4(buf[k].x, sv.x, acc, false);
-                acc = __builtin_amdgcn_sdot4(buf[k].y, sv.y, acc, false);
-                acc = __builtin_amdgcn_sdot4(buf[k].z, sv.z, acc, false);
-                acc = __builtin_amdgcn_sdot4(buf[k].w, sv.w, acc, false);
-            }
-        }
+        for (int k = 0; k < NBUF; ++k) accumulate(acc, buf[k], k);
         return acc;
     };
 
@@ -134,9 +159,12 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     double T = 1.0;
 
     // one Metropolis update at `site` using the row held in `buf`
-    auto step = [&](const vec_t(&buf)[CPW], int site, float u, float h_site, float d_site,
+    auto step = [&](const vec_t(&buf)[NBUF], int site, float u, float h_site, float d_site,
                     long long upd) {
-        acc_t tot = wave_sum(dot_row(buf));
+        acc_t lane_sum;
+        if constexpr (CPW == 0) lane_sum = dot_stream(site);
+        else lane_sum = dot_row(buf);
+        acc_t tot = wave_sum(lane_sum);
         const int owner = (site / EPC) % W;
         int si;
         if (W > 1) {
@@ -183,7 +211,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     };
 
     const int nb = (n + 1) >> 1;
-    vec_t X[CPW], Y[CPW];
+    vec_t X[NBUF], Y[NBUF];
     PairSource<LEAN> rng;
     UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
     load_row(X, cur.sA);
@@ -213,7 +241,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
                 step(Y, cur.sB, cur.uB, hY, dY, (long long)k * n + 2 * b + 1);
             } else {  // odd n: the prefetched row is the next sweep's first
 #pragma unroll
-                for (int q = 0; q < CPW; ++q) X[q] = Y[q];
+                for (int q = 0; q < NBUF; ++q) X[q] = Y[q];
                 hX = hY;
                 dX = dY;
             }
@@ -261,6 +289,7 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
 template <typename JT, bool ACC64>
 static hipError_t launch_variant(const SweepArgs &a, int waves, int cpw, hipStream_t st) {
     switch (cpw) {
+        case 0: return launch_one<JT, ACC64, 0>(a, waves, st);  // streaming form
         case 1: return launch_one<JT, ACC64, 1>(a, waves, st);
         case 2: return launch_one<JT, ACC64, 2>(a, waves, st);
         case 3: return launch_one<JT, ACC64, 3>(a, waves, st);

@@ -495,3 +495,37 @@ def test_error_paths(sg):
         with pytest.raises(sg.AnnealingError):
             e.set_csr(np.asarray([0, 2, 1], np.int32), np.asarray([0, 1], np.int32),
                       np.ones(2, np.float32), np.zeros(2, np.float32))
+
+
+# ----------------------------------------------------------------------------- streaming form
+@pytest.mark.parametrize("n,storage,waves", [(3000, "f32", 1), (45000, "i8", 4), (6000, "f32", 2)])
+def test_streaming_form_matches_oracle(sg, n, storage, waves):
+    """Rows longer than waves x 10 chunks take the streaming form of the dense kernel
+    (forced here with few waves so that small instances exercise it)."""
+    rng = np.random.RandomState(n)
+    if n > 20000:  # keep the host-side instance cheap: banded +-1 couplings
+        J = np.zeros((n, n), np.float32)
+        for d in (1, 7, 300):
+            v = (rng.randint(0, 2, n - d) * 2 - 1).astype(np.float32)
+            J[np.arange(n - d), np.arange(d, n)] = v
+            J[np.arange(d, n), np.arange(n - d)] = v
+    else:
+        J = pm1(n, n)
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    R, ns, seed = 3, 2, 7000 + n
+    temps = ladder(R, 4.0, 0.5)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=waves)
+        e.set_dense(J, h, storage=storage)
+        e.init_replicas(R, seed=seed)
+        assert "(streaming)" in e.describe()
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+        out2 = e.sweep(1, energy_trace=True, trace=True)   # general (traced) variant too
+        ref2 = oracle.sweeps(prob, s, temps, 1, seed=seed, sweep0=ns, energy=ref["energy"])
+        assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
