@@ -343,8 +343,7 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     if (storage == SGA_J_I8 && !fits_i8)
         return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
     e->want_i8 = (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
-    // fp32 partial sums are exact when every J is an integer below 2^10 and n < 2^14
-    e->acc64 = !e->want_i8 && !(hflags[1] == 0 && n <= 16384);
+    (void)hflags[1];
     // integer problem with few possible uphill moves -> per-sweep accept table in LDS
     {
         unsigned int *d_out = nullptr, h_out[2] = {0u, 1u};
@@ -358,8 +357,10 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
         HIPCHK(he);
         float m;
         std::memcpy(&m, &h_out[0], sizeof(float));
-        if (h_out[1] == 0u && m >= 1.0f && m <= 2048.0f && (e->want_i8 || !e->acc64))
-            e->table_m = (int)m;
+        // fp32 partial sums are exact (any order) when J is integer valued and no row's
+        // sum of |J| reaches 2^24; otherwise the row sum is accumulated in fp64
+        e->acc64 = !e->want_i8 && !((h_out[1] & 1u) == 0u && m < 16777216.0f);
+        if (h_out[1] == 0u && m >= 1.0f && m <= 2048.0f) e->table_m = (int)m;
     }
     return ensure_packed(e);
 }

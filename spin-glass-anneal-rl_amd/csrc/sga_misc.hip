@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__r
         const float hi = h[i];
         const float row = (float)((red[0] + red[1]) + (red[2] + red[3]) + (double)__builtin_fabsf(hi));
         atomicMax(&out[0], __builtin_bit_cast(unsigned int, row));  // non-negative: bit order = value order
-        if (bad[0] | bad[1] | bad[2] | bad[3] | (hi != __builtin_rintf(hi))) atomicOr(&out[1], 1u);
+        if (bad[0] | bad[1] | bad[2] | bad[3]) atomicOr(&out[1], 1u);  // some J not an integer
+        if (hi != __builtin_rintf(hi)) atomicOr(&out[1], 2u);           // some h not an integer
     }
 }
 hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, int n,
