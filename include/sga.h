@@ -86,6 +86,13 @@ int sga_set_stream(sga_engine *e, void *hip_stream);
  * fields h[n]. */
 int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
                   int storage);
+/* A batch of n_models independent dense problems of the same size (the reference's
+ * BatchProcessor workload, annealing/batch_processor.py:231-288): J is the models' matrices
+ * stacked row-wise, [n_models*n][ldJ]; h is [n_models][n].  Replicas are split evenly over
+ * the models (global replica g belongs to model g / (R_global / n_models)); with a ladder,
+ * use n_ladders = n_models so that exchanges stay inside a model. */
+int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
+                        int n_models, int storage);
 /* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]. */
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
                 const float *h, int n, int64_t nnz);

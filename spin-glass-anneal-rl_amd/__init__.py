@@ -19,6 +19,7 @@ from .kernel_manager import CUDAKernelManager, GPUMemoryOptimizer, HIPKernelMana
 from .scheduler import SpinGlassScheduler
 from .sharded import LocalShardedTempering, ShardedTempering
 from .multi_gpu import MultiGPUAnnealer, MultiGPUConfig
+from .batch import BatchConfig, BatchProcessor
 from . import encoders
 from .encoders import IsingBuilder
 
@@ -30,5 +31,5 @@ __all__ = [
     "GPUAnnealer", "GPUAnnealerConfig", "ParallelTempering", "ParallelTemperingConfig",
     "HIPKernelManager", "CUDAKernelManager", "GPUMemoryOptimizer", "SpinGlassScheduler",
     "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig",
-    "encoders", "IsingBuilder",
+    "encoders", "IsingBuilder", "BatchConfig", "BatchProcessor",
 ]

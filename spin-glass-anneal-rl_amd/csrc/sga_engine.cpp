@@ -99,6 +99,7 @@ struct sga_engine {
 
     // problem
     int n = 0;
+    int n_models = 1;  // dense batches: models stacked row-wise, replicas split evenly
     bool csr = false;
     float *J_raw = nullptr;  // dense fp32 [n][n], engine copy of the caller's matrix
     bool want_i8 = false, acc64 = false;
@@ -215,6 +216,9 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     a.n = e->n;
     a.sstride = e->sstride;
     a.R = count;
+    a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
+    a.replica_base = e->replica0 + r0;
+    a.model_stride_j = (long long)e->n * e->ld;
     HIPCHK(e->csr ? sga::launch_energy_csr(a, e->stream)
                   : sga::launch_energy_dense(a, e->want_i8, e->stream));
     return SGA_OK;
@@ -231,10 +235,11 @@ int ensure_packed(sga_engine *e) {
     if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
         return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     dev_free(e->J_packed);
-    const size_t bytes = (size_t)e->n * ld * (e->want_i8 ? 1 : 4);
+    const long long rows = (long long)e->n_models * e->n;
+    const size_t bytes = (size_t)rows * ld * (e->want_i8 ? 1 : 4);
     HIPCHK(hipMalloc(&e->J_packed, bytes));
-    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, e->n, e->J_packed, ld, e->want_i8, e->diag,
-                                    e->stream));
+    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ld, e->want_i8,
+                                    e->diag, e->stream));
     e->waves = W;
     e->cpw = CPW;
     e->ld = ld;
@@ -311,8 +316,14 @@ int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch) 
 }
 
 int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n, int storage) {
+    return sga_set_dense_batch(e, J, ldJ, h, n, 1, storage);
+}
+
+int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
+                        int n_models, int storage) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
-    if (!J || !h || n <= 0 || ldJ < n) return fail(SGA_ERR_INVALID, "bad dense problem arguments");
+    if (!J || !h || n <= 0 || ldJ < n || n_models <= 0)
+        return fail(SGA_ERR_INVALID, "bad dense problem arguments");
     if (storage != SGA_J_AUTO && storage != SGA_J_F32 && storage != SGA_J_I8)
         return fail(SGA_ERR_INVALID, "bad storage selector");
     HIPCHK(hipSetDevice(e->device));
@@ -322,20 +333,26 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     e->csr = false;
     e->table_m = 0;
     e->n = n;
-    HIPCHK(hipMalloc(&e->J_raw, sizeof(float) * (size_t)n * n));
+    e->n_models = n_models;
+    const long long rows = (long long)n_models * n;
+    HIPCHK(hipMalloc(&e->J_raw, sizeof(float) * (size_t)rows * n));
     HIPCHK(hipMemcpy2DAsync(e->J_raw, sizeof(float) * (size_t)n, J, sizeof(float) * (size_t)ldJ,
-                            sizeof(float) * (size_t)n, (size_t)n, hipMemcpyDefault, e->stream));
-    HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)n));
-    HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
-    HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)n));
-    // value scan: can J live in int8; is fp32 accumulation exact?
+                            sizeof(float) * (size_t)n, (size_t)rows, hipMemcpyDefault, e->stream));
+    HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)rows));
+    HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)rows, hipMemcpyDefault, e->stream));
+    HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)rows));
+    // value scans over all models: can J live in int8; is fp32 accumulation exact; is the
+    // problem integer valued with few possible uphill moves (per-sweep accept table)?
     int *flags = nullptr;
-    HIPCHK(hipMalloc(&flags, 2 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(flags, 0, 2 * sizeof(int), e->stream));
-    hipError_t le = sga::launch_scan_values(e->J_raw, n, n, n, flags, e->stream);
-    int hflags[2] = {1, 1};
+    HIPCHK(hipMalloc(&flags, 4 * sizeof(int)));
+    unsigned int *uflags = reinterpret_cast<unsigned int *>(flags) + 2;
+    int hflags[4] = {1, 1, 0, 1};
+    hipError_t le = hipMemsetAsync(flags, 0, 4 * sizeof(int), e->stream);
+    if (le == hipSuccess) le = sga::launch_scan_values(e->J_raw, rows, n, n, flags, e->stream);
     if (le == hipSuccess)
-        le = hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream);
+        le = sga::launch_dense_row_abs_max(e->J_raw, n, e->h, rows, n, uflags, e->stream);
+    if (le == hipSuccess)
+        le = hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, e->stream);
     if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
     (void)hipFree(flags);
     HIPCHK(le);
@@ -343,25 +360,13 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     if (storage == SGA_J_I8 && !fits_i8)
         return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
     e->want_i8 = (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
-    (void)hflags[1];
-    // integer problem with few possible uphill moves -> per-sweep accept table in LDS
-    {
-        unsigned int *d_out = nullptr, h_out[2] = {0u, 1u};
-        HIPCHK(hipMalloc(&d_out, 2 * sizeof(unsigned int)));
-        hipError_t he = hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned int), e->stream);
-        if (he == hipSuccess) he = sga::launch_dense_row_abs_max(e->J_raw, n, e->h, n, d_out, e->stream);
-        if (he == hipSuccess)
-            he = hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, e->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-        (void)hipFree(d_out);
-        HIPCHK(he);
-        float m;
-        std::memcpy(&m, &h_out[0], sizeof(float));
-        // fp32 partial sums are exact (any order) when J is integer valued and no row's
-        // sum of |J| reaches 2^24; otherwise the row sum is accumulated in fp64
-        e->acc64 = !e->want_i8 && !((h_out[1] & 1u) == 0u && m < 16777216.0f);
-        if (h_out[1] == 0u && m >= 1.0f && m <= 2048.0f) e->table_m = (int)m;
-    }
+    float m;
+    std::memcpy(&m, &hflags[2], sizeof(float));
+    const unsigned nonint = (unsigned)hflags[3];  // bit 0: some J, bit 1: some h not an integer
+    // fp32 partial sums are exact (any order) when J is integer valued and no row's sum of
+    // |J| reaches 2^24; otherwise the row sum is accumulated in fp64
+    e->acc64 = !e->want_i8 && !((nonint & 1u) == 0u && m < 16777216.0f);
+    if (nonint == 0u && m >= 1.0f && m <= 2048.0f) e->table_m = (int)m;
     return ensure_packed(e);
 }
 
@@ -376,6 +381,7 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
     e->free_problem();
     e->csr = true;
     e->n = n;
+    e->n_models = 1;
     e->nnz = nnz;
     HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * (size_t)(n + 1)));
     HIPCHK(hipMemcpyAsync(e->rowptr, rowptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDefault,
@@ -442,6 +448,8 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
     if (e->n <= 0) return fail(SGA_ERR_INVALID, "set the couplings before the replicas");
     if (R_local <= 0 || R_global < R_local || replica0 < 0 || replica0 + R_local > R_global)
         return fail(SGA_ERR_INVALID, "bad replica partition");
+    if (e->n_models > 1 && R_global % e->n_models != 0)
+        return fail(SGA_ERR_INVALID, "R_global must be a multiple of the number of models");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->free_replicas();
@@ -634,6 +642,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.arith = arith;
         a.rule = e->rule;
         a.table_m = e->table_m;
+        a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
+        a.model_stride_j = (long long)e->n * e->ld;
         a.seed_lo = (uint32_t)e->seed;
         a.seed_hi = (uint32_t)(e->seed >> 32);
         a.sweep0 = e->sweeps_done + (uint32_t)k0;
@@ -706,12 +716,14 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         he = hipMemcpyAsync(d_sites, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st);
     if (he == hipSuccess) {
         sga::PointArgs a{};
+        const long long model = e->n_models > 1 ? (e->replica0 + r) / (e->Rg / e->n_models) : 0;
         a.J = e->J_packed;
+        a.model_offset_j = model * e->n * e->ld;
         a.rowptr = e->rowptr;
         a.colidx = e->colidx;
         a.val = e->val;
-        a.h = e->h;
-        a.diag = e->diag;
+        a.h = e->h + model * e->n;
+        a.diag = e->diag + model * e->n;
         a.spins = e->spins + (long long)r * e->sstride;
         a.energy = e->energy + r;
         a.n_accepted = e->n_acc + r;
@@ -1057,9 +1069,9 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->table_m > 0 ? "integer-fast" : "general", e->table_m);
     else
         std::snprintf(tmp, sizeof(tmp),
-                      "dense n=%d storage=%s acc=%s R=%d waves_per_replica=%d chunks_per_wave=%d%s "
-                      "ld=%lld row_bytes=%lld table_m=%d",
-                      e->n, e->want_i8 ? "i8" : "f32",
+                      "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "
+                      "chunks_per_wave=%d%s ld=%lld row_bytes=%lld table_m=%d",
+                      e->n, e->n_models, e->want_i8 ? "i8" : "f32",
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
                       e->cpw > sga::MAX_CPW ? "(streaming)" : "", e->ld,
                       e->ld * (e->want_i8 ? 1 : 4), e->table_m);

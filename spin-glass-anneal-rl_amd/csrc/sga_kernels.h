@@ -41,11 +41,17 @@ struct SweepArgs {
     long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
     int n, sstride, R, n_sweeps;
     int site_mode, arith, rule;
+    // many-model batches (dense): replica r belongs to model (replica0 + r) / reps_per_model;
+    // J / h / diag of model m start at m * model_stride_j / m * n elements (0 = one model)
+    int reps_per_model;
+    long long model_stride_j;
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
 struct EnergyArgs {
+    int reps_per_model, replica_base;  // many-model batches, as in SweepArgs
+    long long model_stride_j;
     const void *J;
     const int32_t *rowptr, *colidx;
     const float *val;
@@ -79,8 +85,8 @@ hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
 hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
                              uint32_t seed_hi, uint32_t replica0, hipStream_t st);
 // J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded, plus diag[n]
-hipError_t launch_repack_dense(const float *J, long long ldJ, int n, void *out, long long ld,
-                               bool to_i8, float *diag, hipStream_t st);
+hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, int n, void *out,
+                               long long ld, bool to_i8, float *diag, hipStream_t st);
 // flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is not
 // integer-valued or |J| >= 2^10 (fp32 row sums then may be inexact -> fp64 accumulation)
 hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
@@ -110,6 +116,7 @@ struct PointArgs {
     int arith, rule;
     double T;
     float u;
+    long long model_offset_j;  // element offset of this replica's model in J; h/diag pre-offset
 };
 hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st);
 
@@ -123,7 +130,7 @@ hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, co
 size_t sweep_dense_lds_bytes(long long ld, int table_m);
 // integrality and max_i(sum_j |J_ij| + |h_i|) of a dense problem: out[0] = float bits of the
 // max, out[1] bit 0 = some J is not an integer, bit 1 = some h is not an integer
-hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, int n,
-                                    unsigned int *out, hipStream_t st);
+hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, long long rows,
+                                    int n, unsigned int *out, hipStream_t st);
 
 }  // namespace sga

@@ -9,28 +9,30 @@ namespace sga {
 // to a whole number of 1-KiB chunks per wave, so the sweep kernel needs no tail masking.
 // ---------------------------------------------------------------------------------------
 template <typename OT>
-__global__ void repack_dense_kernel(const float *__restrict__ J, long long ldJ, int n,
-                                    OT *__restrict__ out, long long ld, float *__restrict__ diag) {
-    const long long total = (long long)n * ld;
+__global__ void repack_dense_kernel(const float *__restrict__ J, long long ldJ, long long rows,
+                                    int n, OT *__restrict__ out, long long ld,
+                                    float *__restrict__ diag) {
+    // `rows` = n_models * n stacked rows of n columns each
+    const long long total = rows * ld;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / ld, col = i - row * ld;
         const float v = (col < n) ? J[row * ldJ + col] : 0.0f;
         out[i] = (OT)v;
-        if (diag && col == row) diag[row] = v;
+        if (diag && col == row % n) diag[row] = v;
     }
 }
 
-hipError_t launch_repack_dense(const float *J, long long ldJ, int n, void *out, long long ld,
-                               bool to_i8, float *diag, hipStream_t st) {
-    const long long total = (long long)n * ld;
+hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, int n, void *out,
+                               long long ld, bool to_i8, float *diag, hipStream_t st) {
+    const long long total = rows * ld;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (to_i8)
-        hipLaunchKernelGGL(repack_dense_kernel<int8_t>, dim3(blocks), dim3(256), 0, st, J, ldJ, n,
-                           (int8_t *)out, ld, diag);
+        hipLaunchKernelGGL(repack_dense_kernel<int8_t>, dim3(blocks), dim3(256), 0, st, J, ldJ, rows,
+                           n, (int8_t *)out, ld, diag);
     else
-        hipLaunchKernelGGL(repack_dense_kernel<float>, dim3(blocks), dim3(256), 0, st, J, ldJ, n,
-                           (float *)out, ld, diag);
+        hipLaunchKernelGGL(repack_dense_kernel<float>, dim3(blocks), dim3(256), 0, st, J, ldJ, rows,
+                           n, (float *)out, ld, diag);
     return hipGetLastError();
 }
 
@@ -63,6 +65,7 @@ __global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__r
                                                                 long long ldJ,
                                                                 const float *__restrict__ h, int n,
                                                                 unsigned int *out) {
+    // one workgroup per stacked row (gridDim.x = n_models * n), n columns each
     __shared__ double red[4];
     __shared__ int bad[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -88,9 +91,10 @@ __global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__r
         if (hi != __builtin_rintf(hi)) atomicOr(&out[1], 2u);           // some h not an integer
     }
 }
-hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, int n,
-                                    unsigned int *out, hipStream_t st) {
-    hipLaunchKernelGGL(dense_row_abs_max_kernel, dim3(n), dim3(256), 0, st, J, ldJ, h, n, out);
+hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, long long rows,
+                                    int n, unsigned int *out, hipStream_t st) {
+    hipLaunchKernelGGL(dense_row_abs_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, J, ldJ, h,
+                       n, out);
     return hipGetLastError();
 }
 
@@ -209,7 +213,9 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
         for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const JT *J = reinterpret_cast<const JT *>(a.J);
+    const int model = a.reps_per_model > 0 ? (a.replica_base + r) / a.reps_per_model : 0;
+    const JT *J = reinterpret_cast<const JT *>(a.J) + model * a.model_stride_j;
+    const float *hvec = a.h + (long long)model * a.n;
     double e_acc = 0.0, h_acc = 0.0;
     for (int i = w; i < a.n; i += 4) {
         const JT *row = J + (long long)i * a.ld;
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
         const float mv_i = (float)wave_sum(acc);  // torch.mv row, fp32
         const double si = (double)s[i];
         e_acc += (double)mv_i * si;
-        h_acc += (double)a.h[i] * si;
+        h_acc += (double)hvec[i] * si;
     }
     if (lane == 0) {
         red[w] = e_acc;
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
             for (int j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
                 acc += (double)(a.val[j] * (float)a.spins[a.colidx[j]]);
         } else {
-            const JT *row = reinterpret_cast<const JT *>(a.J) + (long long)site * a.ld;
+            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ld;
             for (long long c = (long long)tid * EPL; c < a.ld; c += 4 * EPC) {
                 if constexpr (sizeof(JT) == 4) {
                     const float4 x = *reinterpret_cast<const float4 *>(row + c);

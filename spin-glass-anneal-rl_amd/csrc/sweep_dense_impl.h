@@ -88,7 +88,11 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     __syncthreads();
 
     const long long kstride = (long long)W * EPC;  // elements between a wave's chunks
-    const JT *Jlane = reinterpret_cast<const JT *>(a.J) + (w * EPC + lane * EPL);
+    const int model = a.reps_per_model > 0 ? (int)((a.replica0 + (uint32_t)r) / a.reps_per_model) : 0;
+    const JT *Jlane = reinterpret_cast<const JT *>(a.J) + model * a.model_stride_j +
+                      (w * EPC + lane * EPL);
+    const float *hvec = a.h + (long long)model * n;
+    const float *dvec = a.diag + (long long)model * n;
     const int8_t *slane = s_lds + (w * EPC + lane * EPL);
     const bool arith32 = arith == SGA_ARITH_F32;
 
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     PairSource<LEAN> rng;
     UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
     load_row(X, cur.sA);
-    float hX = a.h[cur.sA], dX = arith32 ? a.diag[cur.sA] : 0.0f;
+    float hX = hvec[cur.sA], dX = arith32 ? dvec[cur.sA] : 0.0f;
 
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
@@ -232,12 +236,12 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             const bool hasB = (2 * b + 1) < n;
             const int sY = hasB ? cur.sB : nxt.sA;
             load_row(Y, sY);  // in flight while X is reduced
-            float hY = a.h[sY], dY = arith32 ? a.diag[sY] : 0.0f;
+            float hY = hvec[sY], dY = arith32 ? dvec[sY] : 0.0f;
             step(X, cur.sA, cur.uA, hX, dX, (long long)k * n + 2 * b);
             if (hasB) {
                 load_row(X, nxt.sA);
-                hX = a.h[nxt.sA];
-                dX = arith32 ? a.diag[nxt.sA] : 0.0f;
+                hX = hvec[nxt.sA];
+                dX = arith32 ? dvec[nxt.sA] : 0.0f;
                 step(Y, cur.sB, cur.uB, hY, dY, (long long)k * n + 2 * b + 1);
             } else {  // odd n: the prefetched row is the next sweep's first
 #pragma unroll

@@ -49,6 +49,7 @@ class AnnealEngine:
         self.R_global = 0
         self.replica0 = 0
         self.n_ladders = 0
+        self.n_models = 1
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -97,7 +98,28 @@ class AnnealEngine:
             raise AnnealingError("external fields must have n entries")
         N.check(self._lib.sga_set_dense(self._h, jp, int(ld), hp, int(n), sel), "sga_set_dense")
         del keep
-        self.n, self.R = n, 0
+        self.n, self.R, self.n_models = n, 0, 1
+
+    def set_dense_batch(self, J, h, storage: str = "auto"):
+        """Many independent models of one size: J [M, n, n], h [M, n] (numpy or torch)."""
+        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8}[storage]
+        if _is_tensor(J):
+            Jt = J.detach().float().contiguous()
+            M, n = Jt.shape[0], Jt.shape[1]
+            jp, keep = C.c_void_p(Jt.data_ptr()), Jt
+        else:
+            Ja = np.ascontiguousarray(J, dtype=np.float32)
+            M, n = Ja.shape[0], Ja.shape[1]
+            jp, keep = Ja.ctypes.data_as(C.c_void_p), Ja
+        if keep.ndim != 3 or keep.shape[2] != n:
+            raise AnnealingError("batched couplings must be [M, n, n]")
+        hp, hk = _buf(h, np.float32, "float32")
+        if (hk.numel() if _is_tensor(hk) else hk.size) != M * n:
+            raise AnnealingError("batched fields must be [M, n]")
+        N.check(self._lib.sga_set_dense_batch(self._h, jp, int(n), hp, int(n), int(M), sel),
+                "sga_set_dense_batch")
+        del keep
+        self.n, self.R, self.n_models = n, 0, M
 
     def set_csr(self, rowptr, colidx, val, h):
         rp, k1 = _buf(rowptr, np.int32, "int32")

@@ -529,3 +529,41 @@ def test_streaming_form_matches_oracle(sg, n, storage, waves):
         out2 = e.sweep(1, energy_trace=True, trace=True)   # general (traced) variant too
         ref2 = oracle.sweeps(prob, s, temps, 1, seed=seed, sweep0=ns, energy=ref["energy"])
         assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
+
+
+# ----------------------------------------------------------------------------- model batches
+@pytest.mark.parametrize("n,M,k,storage", [(64, 5, 3, "auto"), (300, 4, 2, "f32"), (1100, 3, 4, "i8")])
+def test_many_model_batch_matches_per_model_oracle(sg, n, M, k, storage):
+    """sga_set_dense_batch: M stacked models, k replicas each, one launch; every replica must
+    follow the oracle run on ITS model (reference BatchProcessor workload)."""
+    Js = np.stack([pm1(n, 100 + m) for m in range(M)])
+    hs = np.stack([np.random.RandomState(m).randint(-1, 2, n).astype(np.float32) for m in range(M)])
+    R, ns, seed = M * k, 5, 999 + n
+    temps = np.tile(ladder(k, 3.0, 0.5), M)
+    with sg.AnnealEngine(0) as e:
+        e.set_dense_batch(Js, hs, storage=storage)
+        e.init_replicas(R, seed=seed)
+        e.set_ladder(temps, n_ladders=M)
+        out = e.sweep(ns, energy_trace=True)
+        swaps = e.exchange()
+        spins, energies, slot_map = e.spins(), e.energies(), e.slot_map()
+        f = e.local_fields(R - 1, [0, n - 1])
+        e.recompute_energies()
+        assert np.array_equal(e.energies(), energies)
+    n_acc = 0
+    for m in range(M):
+        prob = oracle.Problem(J=Js[m], h=hs[m])
+        sl = slice(m * k, (m + 1) * k)
+        s = oracle.init_spins(n, k, seed, replica0=m * k)
+        ref = oracle.sweeps(prob, s, temps[sl], ns, seed=seed, replica0=m * k)
+        assert np.array_equal(out["energy_trace"][:, sl], ref["energy_trace"])
+        assert np.array_equal(spins[sl], s)
+        view = np.arange(m * k, (m + 1) * k, dtype=np.int32)
+        full_e = np.zeros(R)
+        full_e[sl] = ref["energy"]
+        n_acc += oracle.pt_exchange_round(temps[sl], full_e, view, seed=seed, round_=0, ladder=m)
+        assert np.array_equal(slot_map[sl], view)
+    assert swaps == n_acc
+    prob = oracle.Problem(J=Js[M - 1], h=hs[M - 1])
+    assert f[0] == oracle.local_field(prob, spins[R - 1], 0)
+    assert f[1] == oracle.local_field(prob, spins[R - 1], n - 1)

@@ -346,6 +346,31 @@ def test_encoded_instances_anneal_to_feasible_solutions(sg):
         pytest.approx(res.best_energy, rel=1e-6)
 
 
+def test_batch_processor_many_models(sg):
+    rng = np.random.RandomState(3)
+    models, probs = [], []
+    for n in (20, 48, 20, 48, 20):
+        J = np.triu(rng.randint(0, 2, (n, n)) * 2 - 1, 1).astype(np.float32)
+        J = J + J.T
+        h = rng.randint(-1, 2, n).astype(np.float32)
+        models.append(model_from(sg, J, h))
+        probs.append(oracle.Problem(J=J, h=h))
+    bp = sg.BatchProcessor(sg.GPUAnnealerConfig(n_sweeps=120, random_seed=8),
+                           sg.BatchConfig(batch_size=2, replicas_per_model=4))
+    res = bp.process_models_batch(models)
+    assert len(res) == 5 and bp.get_processing_stats()["processed_models"] == 5
+    for m, p, r in zip(models, probs, res):
+        best = r.best_configuration.numpy().astype(np.int8)
+        assert best.size == m.n_spins and oracle.energy(p, best) == r.best_energy
+        assert r.best_energy <= r.energy_history[0] and len(r.energy_history) == 13
+    again = sg.BatchProcessor(sg.GPUAnnealerConfig(n_sweeps=120, random_seed=8),
+                              sg.BatchConfig(batch_size=2, replicas_per_model=4))
+    streamed = [r for chunk in again.process_models_stream(iter(models)) for r in chunk]
+    assert len(streamed) == 5
+    with pytest.raises(ValueError):
+        sg.BatchConfig(batch_size=0)
+
+
 # ----------------------------------------------------------------------------- full size
 def test_full_size_c2_properties(sg):
     """BASELINE configs[1] at full size (10 000 spins, 1024 replicas): size-independent
