@@ -113,6 +113,7 @@ struct sga_engine {
     float *h = nullptr, *diag = nullptr;
     int tune_waves = 0, tune_spl = 0;
     int rule = SGA_RULE_METROPOLIS;
+    bool consistent_dE = true;  // J symmetric with zero diagonal: dE of the rule == energy change
     int table_m = 0;  // integer problems: largest possible |dE| / 2 (0 = not integer / too big)
 
     // replicas
@@ -356,6 +357,17 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
     (void)hipFree(flags);
     HIPCHK(le);
+    {
+        int *d_bad = nullptr, h_bad = 0;
+        HIPCHK(hipMalloc(&d_bad, sizeof(int)));
+        hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(int), e->stream);
+        if (he == hipSuccess) he = sga::launch_check_symmetric(e->J_raw, rows, n, d_bad, e->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        (void)hipFree(d_bad);
+        HIPCHK(he);
+        e->consistent_dE = h_bad == 0;
+    }
     const bool fits_i8 = hflags[0] == 0;
     if (storage == SGA_J_I8 && !fits_i8)
         return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
@@ -438,6 +450,34 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
             m = std::max(m, row);
         }
         if (integral && m >= 1.0 && m <= 2048.0) e->table_m = (int)m;
+        // symmetric with zero diagonal?  (value of (i,j) must equal value of (j,i))
+        e->consistent_dE = true;
+        if (nnz > 0 && nnz <= 200000000) {
+            std::vector<int32_t> ci((size_t)nnz);
+            HIPCHK(hipMemcpy(ci.data(), e->colidx, sizeof(int32_t) * ci.size(), hipMemcpyDeviceToHost));
+            std::vector<std::pair<long long, float>> fwd((size_t)nnz), rev((size_t)nnz);
+            size_t q = 0;
+            for (int i = 0; i < n; ++i)
+                for (int32_t k = rp[i]; k < rp[i + 1]; ++k, ++q) {
+                    fwd[q] = {(long long)i * n + ci[k], hv[k]};
+                    rev[q] = {(long long)ci[k] * n + i, hv[k]};
+                    if (ci[k] == i && hv[k] != 0.0f) e->consistent_dE = false;
+                }
+            std::sort(fwd.begin(), fwd.end());
+            std::sort(rev.begin(), rev.end());
+            // duplicates are summed by the kernels; compare the merged entries
+            auto merged = [](std::vector<std::pair<long long, float>> &v) {
+                size_t w = 0;
+                for (size_t r = 0; r < v.size(); ++r) {
+                    if (w > 0 && v[w - 1].first == v[r].first) v[w - 1].second += v[r].second;
+                    else v[w++] = v[r];
+                }
+                v.resize(w);
+            };
+            merged(fwd);
+            merged(rev);
+            if (fwd != rev) e->consistent_dE = false;
+        }
     }
     return SGA_OK;
 }
@@ -607,6 +647,12 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         spl = (int)std::min<double>(n_sweeps, std::max(1.0, std::floor(0.05 / per_sweep)));
     }
     spl = std::max(1, std::min(spl, n_sweeps));
+    // Asymmetric J or a non-zero diagonal: the rule's dE (row i only, as the reference computes
+    // it) is not the energy change, so E += dE would drift from compute_energy().  Then every
+    // sweep is its own launch, followed by a from-scratch energy evaluation and the best update
+    // (exactly the reference's sequence, core/spin_dynamics.py:87, gpu_annealer.py:151-153).
+    const bool exact_mode = !e->consistent_dE;
+    if (exact_mode) spl = 1;
 
     for (int k0 = 0; k0 < n_sweeps; k0 += spl) {
         const int ks = std::min(spl, n_sweeps - k0);
@@ -630,7 +676,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.replay_site = d_site.ptr ? d_site.ptr + off : nullptr;
         a.replay_u = d_u.ptr ? d_u.ptr + off : nullptr;
         a.replay_stride = per;
-        a.energy_trace = d_etrace.ptr ? d_etrace.ptr + (long long)k0 * R : nullptr;
+        a.energy_trace = (d_etrace.ptr && !exact_mode) ? d_etrace.ptr + (long long)k0 * R : nullptr;
         a.accept_trace = d_acc.ptr ? d_acc.ptr + off : nullptr;
         a.dE_trace = d_dE.ptr ? d_dE.ptr + off : nullptr;
         a.ld = e->ld;
@@ -641,7 +687,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.site_mode = site_mode;
         a.arith = arith;
         a.rule = e->rule;
-        a.table_m = e->table_m;
+        a.table_m = exact_mode ? 0 : e->table_m;
+        a.no_best = exact_mode ? 1 : 0;
         a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
         a.model_stride_j = (long long)e->n * e->ld;
         a.seed_lo = (uint32_t)e->seed;
@@ -663,6 +710,15 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             e->events.emplace_back(ev0, ev1);
         }
         HIPCHK(le);
+        if (exact_mode) {
+            int rc2 = recompute_energy_range(e, 0, R);
+            if (rc2 != SGA_OK) return rc2;
+            HIPCHK(sga::launch_update_best(e->energy, e->spins, e->best_energy, e->best_spins,
+                                           e->sstride, R, st));
+            if (d_etrace.ptr)
+                HIPCHK(hipMemcpyAsync(d_etrace.ptr + (long long)k0 * R, e->energy, sizeof(double) * R,
+                                      hipMemcpyDeviceToDevice, st));
+        }
     }
     e->sweeps_done += (uint32_t)n_sweeps;
     e->attempted += per;
@@ -745,6 +801,11 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
     (void)hipFree(d_sites);
     (void)hipFree(d_out);
     HIPCHK(he);
+    if (op != 0 && !e->consistent_dE) {  // the rule's dE is not the energy change here
+        int rc = recompute_energy_range(e, r, 1);
+        if (rc != SGA_OK) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+    }
     return SGA_OK;
 }
 
@@ -1064,9 +1125,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (e->csr)
         std::snprintf(tmp, sizeof(tmp),
                       "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d "
-                      "path=%s table_m=%d",
+                      "path=%s table_m=%d%s",
                       e->n, e->nnz, e->R, sga::CSR_WAVES_PER_BLOCK, e->sstride,
-                      e->table_m > 0 ? "integer-fast" : "general", e->table_m);
+                      e->table_m > 0 ? "integer-fast" : "general", e->table_m,
+                      e->consistent_dE ? "" : " energy=recomputed-per-sweep");
     else
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "
@@ -1075,6 +1137,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
                       e->cpw > sga::MAX_CPW ? "(streaming)" : "", e->ld,
                       e->ld * (e->want_i8 ? 1 : 4), e->table_m);
+    if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;
 }

@@ -45,6 +45,7 @@ struct SweepArgs {
     // J / h / diag of model m start at m * model_stride_j / m * n elements (0 = one model)
     int reps_per_model;
     long long model_stride_j;
+    int no_best;  // 1: leave best tracking to the host-driven pass (asymmetric / diagonal J)
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
@@ -119,6 +120,12 @@ struct PointArgs {
     long long model_offset_j;  // element offset of this replica's model in J; h/diag pre-offset
 };
 hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st);
+
+// 1 -> out[0] if some J[i][j] != J[j][i] or J[i][i] != 0 (per model block of n rows)
+hipError_t launch_check_symmetric(const float *J, long long rows, int n, int *out, hipStream_t st);
+// best[r] = min(best[r], energy[r]) with the spins, one workgroup per replica
+hipError_t launch_update_best(const double *energy, const int8_t *spins, double *best_energy,
+                              int8_t *best_spins, int sstride, int R, hipStream_t st);
 
 // operator-form PT exchange (cuda_kernels.py:415-443): decide sequentially, then permute rows
 hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, const float *temps,

@@ -4,6 +4,8 @@
 
 namespace sga {
 
+static int grid_for(long long total);
+
 // ---------------------------------------------------------------------------------------
 // J repack: caller's fp32 [n][ldJ] -> engine layout [n][ld] (float | int8), rows zero padded
 // to a whole number of 1-KiB chunks per wave, so the sweep kernel needs no tail masking.
@@ -95,6 +97,42 @@ hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *
                                     int n, unsigned int *out, hipStream_t st) {
     hipLaunchKernelGGL(dense_row_abs_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, J, ldJ, h,
                        n, out);
+    return hipGetLastError();
+}
+
+__global__ void check_symmetric_kernel(const float *__restrict__ J, long long rows, int n, int *out) {
+    const long long total = rows * n;
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / n, col = i - row * n;
+        const long long base = (row / n) * n;  // first row of this model's block
+        const long long r = row - base;
+        const float a = J[i], b = J[(base + col) * n + r];
+        if (a != b || (r == col && a != 0.0f)) bad = 1;
+    }
+    if (bad) atomicOr(out, 1);
+}
+hipError_t launch_check_symmetric(const float *J, long long rows, int n, int *out, hipStream_t st) {
+    hipLaunchKernelGGL(check_symmetric_kernel, dim3(grid_for(rows * n)), dim3(256), 0, st, J, rows,
+                       n, out);
+    return hipGetLastError();
+}
+
+__global__ void update_best_kernel(const double *energy, const int8_t *spins, double *best_energy,
+                                   int8_t *best_spins, int sstride, int R) {
+    const int r = blockIdx.x;
+    if (r >= R || !(energy[r] < best_energy[r])) return;  // uniform per workgroup
+    const int4 *src = reinterpret_cast<const int4 *>(spins + (long long)r * sstride);
+    int4 *dst = reinterpret_cast<int4 *>(best_spins + (long long)r * sstride);
+    for (int i = threadIdx.x; i < sstride / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) best_energy[r] = energy[r];
+}
+hipError_t launch_update_best(const double *energy, const int8_t *spins, double *best_energy,
+                              int8_t *best_spins, int sstride, int R, hipStream_t st) {
+    hipLaunchKernelGGL(update_best_kernel, dim3(R), dim3(256), 0, st, energy, spins, best_energy,
+                       best_spins, sstride, R);
     return hipGetLastError();
 }
 

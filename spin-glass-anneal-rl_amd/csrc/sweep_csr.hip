@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
             hA = hN;
         }
         if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
-        if (E < bestE) {  // annealing/gpu_annealer.py:151-153
+        if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
             int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
             const int4 *src = reinterpret_cast<const int4 *>(s);

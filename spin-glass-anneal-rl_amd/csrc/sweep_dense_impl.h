@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         }
         // sweep boundary: energy record and best tracking (annealing/gpu_annealer.py:151-153)
         if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
-        if (E < bestE) {
+        if (E < bestE && !a.no_best) {
             bestE = E;
             __syncthreads();
             int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
