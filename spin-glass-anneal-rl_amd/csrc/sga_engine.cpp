@@ -506,10 +506,10 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         e->sstride = (int)e->ld;
     } else {
         e->sstride = (e->n + 15) / 16 * 16;
-        if ((size_t)e->sstride * sga::CSR_WAVES_PER_BLOCK > 160 * 1024)
+        if (sga::csr_waves_per_block(e->sstride, 0) < 1)
             return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
-        if (((size_t)e->sstride + 4 * (size_t)(e->table_m + 1)) * sga::CSR_WAVES_PER_BLOCK > 160 * 1024)
-            e->table_m = 0;  // no room for the probability tables: general path
+        if (sga::csr_waves_per_block(e->sstride, e->table_m) < 1)
+            e->table_m = 0;  // no room for the probability table: general path
     }
     const size_t sb = (size_t)R_local * e->sstride;
     HIPCHK(hipMalloc(&e->spins, sb));
@@ -1126,7 +1126,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
         std::snprintf(tmp, sizeof(tmp),
                       "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d "
                       "path=%s table_m=%d%s",
-                      e->n, e->nnz, e->R, sga::CSR_WAVES_PER_BLOCK, e->sstride,
+                      e->n, e->nnz, e->R, sga::csr_waves_per_block(e->sstride, e->table_m), e->sstride,
                       e->table_m > 0 ? "integer-fast" : "general", e->table_m,
                       e->consistent_dE ? "" : " energy=recomputed-per-sweep");
     else

@@ -6,8 +6,8 @@
 // own sparse branch (ising_model.py:133-135) raises under the container's torch, so the math
 // is the dense path's with the row restricted to its stored entries.
 //
-// Mapping: one replica per wavefront, CSR_WAVES_PER_BLOCK independent replicas per
-// workgroup (no workgroup barrier anywhere: each wave owns a private LDS slice holding its
+// Mapping: one replica per wavefront, up to CSR_WAVES_PER_BLOCK independent replicas per
+// workgroup (as many as fit LDS: 4 up to n = 40k, 2 up to 80k, 1 up to 160k) (no workgroup barrier anywhere: each wave owns a private LDS slice holding its
 // replica's spins).  A row has ~32 entries, i.e. one (colidx, val) wave-load each; the spin
 // gather goes through LDS; the dot is a DPP wave sum.  The structure (2.6 MB at C3) is
 // L2-resident, so the kernel is bound by instruction issue and the dependent-load chain,
@@ -32,11 +32,12 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int r = blockIdx.x * CSR_WAVES_PER_BLOCK + w;
+    const int wpb = blockDim.x >> 6;  // replicas (waves) per workgroup
+    const int r = blockIdx.x * wpb + w;
     if (r >= a.R) return;  // wave-uniform; no barriers below
     const int n = a.n;
     int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)w * a.sstride;
-    float *ptab = reinterpret_cast<float *>(smem + (long long)CSR_WAVES_PER_BLOCK * a.sstride) +
+    float *ptab = reinterpret_cast<float *>(smem + (long long)wpb * a.sstride) +
                   (long long)w * (a.table_m + 1);
     {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
@@ -162,11 +163,17 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
     }
 }
 
+int csr_waves_per_block(int sstride, int table_m) {
+    const size_t per = (size_t)sstride + (table_m > 0 ? sizeof(float) * (size_t)(table_m + 1) : 0);
+    int wpb = (int)((160 * 1024) / per);
+    return wpb > CSR_WAVES_PER_BLOCK ? CSR_WAVES_PER_BLOCK : wpb;  // 0: does not fit
+}
+
 hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st) {
     const bool fast = a.table_m > 0;
-    const size_t lds = (size_t)a.sstride * CSR_WAVES_PER_BLOCK +
-                       (fast ? sizeof(float) * (size_t)(a.table_m + 1) * CSR_WAVES_PER_BLOCK : 0);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int wpb = csr_waves_per_block(a.sstride, a.table_m);
+    if (wpb < 1) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)a.sstride + (fast ? sizeof(float) * (size_t)(a.table_m + 1) : 0)) * wpb;
     const bool lean = sweep_args_are_lean(a);
     auto kern = fast ? (lean ? sweep_csr_kernel<true, true> : sweep_csr_kernel<true, false>)
                      : (lean ? sweep_csr_kernel<false, true> : sweep_csr_kernel<false, false>);
@@ -175,8 +182,8 @@ hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int blocks = (a.R + CSR_WAVES_PER_BLOCK - 1) / CSR_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * CSR_WAVES_PER_BLOCK), lds, st, a);
+    const int blocks = (a.R + wpb - 1) / wpb;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, st, a);
     return hipGetLastError();
 }
 

@@ -404,3 +404,47 @@ def test_full_size_c2_properties(sg):
     assert np.array_equal(runs["f32"][0], runs["i8"][0]) and runs["f32"][1] == runs["i8"][1]
     assert np.array_equal(runs["f32"][2], runs["i8"][2])
     assert np.array_equal(runs["f32"][3], runs["i8"][3])
+
+
+def test_c4_shaped_instance_full_size(sg):
+    """BASELINE configs[3] shape: 500 tasks x 100 slots = 50 000 spins of constraint-compiled
+    penalties, CSR (degree 598), replicas on one ladder.  Size-independent properties: tracked
+    energy == from-scratch energy (integer penalties), dense-int8 and CSR layouts run the same
+    chain, and the first sweeps match the oracle on a few replicas."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    b = enc.scheduling_ising(np.full(500, 1.0), n_agents=1, time_horizon=100.0,
+                             time_discretization=100, objective="total_time",
+                             penalty_weights={"assignment": 100.0, "capacity": 50.0})
+    csr, h = b.to_csr(), b.fields()
+    n, R, seed = 50000, 64, 31
+    temps = np.asarray(sg.temperature_ladder(R, 5.0, 500.0))
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        assert "n=50000" in e.describe() and "replicas_per_block=3" in e.describe()
+        e.set_ladder(temps)
+        out = e.sweep(2, energy_trace=True)
+        e.exchange()
+        e.sweep(1)
+        tracked, spins_csr = e.energies(), e.spins()
+        e.recompute_energies()
+        # |E| ~ 1e9 here: the from-scratch value is rounded to fp32 as torch.dot rounds it
+        # (core/ising_model.py:161-168), the tracked one is an exact double sum
+        assert np.allclose(e.energies(), tracked, rtol=1e-6, atol=0)
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, 4, seed)
+    ref = oracle.sweeps(prob, s, temps[:4], 2, seed=seed, n_threads=4)
+    assert np.array_equal(out["energy_trace"][:, :4], ref["energy_trace"])
+    J = np.zeros((n, n), np.float32)                  # same couplings, dense int8 path
+    rows = np.repeat(np.arange(n), np.diff(csr[0]))
+    J[rows, csr[1]] = csr[2]
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(torch.from_numpy(J).cuda(), h)
+        del J
+        e.init_replicas(R, seed=seed)
+        assert "storage=i8" in e.describe()
+        e.set_ladder(temps)
+        e.sweep(2)
+        e.exchange()
+        e.sweep(1)
+        assert np.array_equal(e.energies(), tracked) and np.array_equal(e.spins(), spins_csr)
