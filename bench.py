@@ -87,13 +87,14 @@ def host_cores():
     return int(os.environ.get("SGA_CPU_THREADS", cores))
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None):
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None, h=None):
     import oracle
     cores = host_cores()
     R = max(cores * budget_replicas_per_core, 1)
     if csr is not None:
-        sweeps *= 40  # a sparse sweep is ~100x cheaper: keep the sample at seconds of CPU work
-        prob = oracle.Problem(csr=csr, h=np.zeros(n, np.float32))
+        # sparse sweeps are cheap: scale the sample to seconds of CPU work
+        sweeps = max(1, int(sweeps * 40 * 32 * n / max(len(csr[1]), 1) * 10000 / n))
+        prob = oracle.Problem(csr=csr, h=np.zeros(n, np.float32) if h is None else h)
     else:
         prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
     oracle.set_exact_f32(True)  # +-1 couplings: fp32 SIMD accumulation is exact
@@ -135,8 +136,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2a", choices=["c2a", "c3"],
-                    help="c2a: dense SK instance (headline); c3: CSR, degree ~32, 4096 replicas")
+    ap.add_argument("--workload", default="c2a", choices=["c2a", "c3", "c4", "c5"],
+                    help="c2a: dense SK instance (headline); c3: CSR, degree ~32, 4096 replicas; "
+                         "c4: 50k-spin scheduling penalties (CSR), 1024 replicas/GPU; "
+                         "c5: 100-city TSP QUBO (CSR), 2048 replicas in 32 ladders")
     ap.add_argument("--spins", type=int, default=10000)
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0 = workload default)")
     ap.add_argument("--storage", default="f32", choices=["f32", "i8"])
@@ -176,7 +179,23 @@ def main():
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
 
     n = a.spins
-    R = a.replicas or (1024 if a.workload == "c2a" else 4096)
+    R = a.replicas or {"c2a": 1024, "c3": 4096, "c4": 1024, "c5": 2048}[a.workload]
+    n_ladders, t_hot, t_cold, label = 1, 10.0, 0.1, ""
+    if a.workload in ("c4", "c5"):
+        from spin_glass_anneal_rl_amd import encoders as enc
+        if a.workload == "c4":  # BASELINE configs[3]: 500 tasks x 100 slots, cardinality penalties
+            bld = enc.scheduling_ising(np.full(500, 1.0), n_agents=1, time_horizon=100.0,
+                                       time_discretization=100, objective="total_time",
+                                       penalty_weights={"assignment": 100.0, "capacity": 50.0})
+            t_hot, t_cold, label = 500.0, 5.0, "C4: 50000-spin scheduling Ising (500 tasks x 100 slots)"
+        else:                   # BASELINE configs[4] at 100 cities: n = 10^4, degree ~ 4(n_c - 1)
+            rs = np.random.RandomState(5)
+            xy = rs.rand(100, 2) * 100.0
+            dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+            bld = enc.tsp_ising(dmat, city_visit=200.0, position_fill=200.0)
+            n_ladders, t_hot, t_cold = 32, 200.0, 2.0
+            label = "C5: 100-city TSP QUBO (10000 spins)"
+        n = bld.n
     Rg = R * world
     h = torch.zeros(n, device=dev)
     eng = sg.AnnealEngine(local_rank)
@@ -186,12 +205,16 @@ def main():
     if a.workload == "c2a":
         J = make_sk_instance(n, 2, dev)
         eng.set_dense(J, h, storage=a.storage)
-    else:
+    elif a.workload == "c3":
         csr = make_sparse_instance(n, 16, 3)
         eng.set_csr(*csr, h)
+    else:
+        csr = bld.to_csr()
+        h = torch.from_numpy(bld.fields()).to(dev)
+        eng.set_csr(*csr, h)
+    ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
-                          slot_temps=geometric_ladder(Rg), n_ladders=1,
-                          dist=dist, device=comm_dev)
+                          slot_temps=ladder, n_ladders=n_ladders, dist=dist, device=comm_dev)
     geometry = eng.describe()
 
     def barrier():
@@ -253,9 +276,11 @@ def main():
         "dtype": "f32" if (a.storage == "f32" or csr is not None) else "i8",
         "data": "synthetic",
         "config": {"workload": (f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
-                                f"C3: {n}-spin CSR +-1 Ising, mean degree {len(csr[1]) / n:.1f}") +
-                               f", {R} replicas/GPU, geometric ladder T 10->0.1, random-site "
-                               f"Metropolis sweeps, exchange every {a.exchange_interval}",
+                                (label or f"C3: {n}-spin CSR +-1 Ising") +
+                                f", CSR mean degree {len(csr[1]) / n:.1f}") +
+                               f", {R} replicas/GPU, {n_ladders} geometric ladder(s) T {t_hot:g}->"
+                               f"{t_cold:g}, random-site Metropolis sweeps, exchange every "
+                               f"{a.exchange_interval}",
                    "spins": n, "replicas_per_gpu": R, "replicas_total": Rg,
                    "coupling_storage": a.storage if csr is None else "csr", "geometry": geometry,
                    "best_energy_rank0": best_e},
@@ -270,7 +295,8 @@ def main():
                      "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr)
+        out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr,
+                                           h=None if csr is None else h.cpu().numpy())
     else:
         out["cpu_baseline"] = None
     if rank == 0:

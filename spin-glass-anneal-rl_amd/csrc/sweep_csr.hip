@@ -24,6 +24,8 @@
 
 namespace sga {
 
+constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight together
+
 template <bool FAST, bool LEAN>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(const SweepArgs a) {
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
@@ -79,13 +81,37 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
         float dot;
         if constexpr (FAST) {
             float acc = hd.val * (float)s[hd.col];
-            for (int j = x.beg + 64 + lane; j < x.end; j += 64)
-                acc += a.val[j] * (float)s[a.colidx[j]];
+            // long rows: issue eight (colidx, val) wave-loads before the first gather so the
+            // round trips overlap instead of serialising (degree ~600 at C4)
+            for (int j0 = x.beg + 64 + lane; j0 < x.end; j0 += 64 * TAIL_UNROLL) {
+                int c[TAIL_UNROLL];
+                float v[TAIL_UNROLL];
+#pragma unroll
+                for (int q = 0; q < TAIL_UNROLL; ++q) {
+                    const int j = j0 + 64 * q;
+                    const bool in = j < x.end;
+                    c[q] = in ? a.colidx[j] : 0;
+                    v[q] = in ? a.val[j] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * (float)s[c[q]];
+            }
             dot = wave_sum(acc);
         } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
             double acc = (double)(hd.val * (float)s[hd.col]);
-            for (int j = x.beg + 64 + lane; j < x.end; j += 64)
-                acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
+            for (int j0 = x.beg + 64 + lane; j0 < x.end; j0 += 64 * TAIL_UNROLL) {
+                int c[TAIL_UNROLL];
+                float v[TAIL_UNROLL];
+#pragma unroll
+                for (int q = 0; q < TAIL_UNROLL; ++q) {
+                    const int j = j0 + 64 * q;
+                    const bool in = j < x.end;
+                    c[q] = in ? a.colidx[j] : 0;
+                    v[q] = in ? a.val[j] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * (float)s[c[q]]);
+            }
             dot = (float)wave_sum(acc);
         }
         const int si = s[site];
