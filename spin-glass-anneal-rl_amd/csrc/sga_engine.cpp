@@ -510,6 +510,14 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
         if (sga::csr_waves_per_block(e->sstride, e->table_m) < 1)
             e->table_m = 0;  // no room for the probability table: general path
+        // Long rows AND too few replicas to give every SIMD a wave: deal each row to two waves
+        // (one replica per workgroup).  The kernel is issue bound, so with >= 2048 replicas the
+        // extra waves only repeat the per-update work (measured: C4, R = 1024: 1 / 2 / 4 / 8
+        // waves -> 2.98 / 3.69 / 3.67 / 3.34 e8 attempts/s; C5, R = 2048: 1.55 vs 1.19 e9).
+        const double deg = (double)e->nnz / e->n;
+        const int wpr = e->tune_waves > 0 ? e->tune_waves : ((deg >= 192.0 && R_local <= 1024) ? 2 : 1);
+        e->waves = std::min(wpr, 8);
+        e->cpw = 0;
     }
     const size_t sb = (size_t)R_local * e->sstride;
     HIPCHK(hipMalloc(&e->spins, sb));
@@ -702,7 +710,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             HIPCHK(hipEventCreate(&ev1));
             HIPCHK(hipEventRecord(ev0, st));
         }
-        hipError_t le = e->csr ? sga::launch_sweep_csr(a, st)
+        hipError_t le = e->csr ? sga::launch_sweep_csr(a, e->waves, st)
                                : sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
                                                          e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
         if (e->timing) {
@@ -1124,9 +1132,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     char tmp[512];
     if (e->csr)
         std::snprintf(tmp, sizeof(tmp),
-                      "csr n=%d nnz=%lld R=%d waves_per_replica=1 replicas_per_block=%d sstride=%d "
+                      "csr n=%d nnz=%lld R=%d waves_per_replica=%d replicas_per_block=%d sstride=%d "
                       "path=%s table_m=%d%s",
-                      e->n, e->nnz, e->R, sga::csr_waves_per_block(e->sstride, e->table_m), e->sstride,
+                      e->n, e->nnz, e->R, e->waves,
+                      e->waves > 1 ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m), e->sstride,
                       e->table_m > 0 ? "integer-fast" : "general", e->table_m,
                       e->consistent_dE ? "" : " energy=recomputed-per-sweep");
     else

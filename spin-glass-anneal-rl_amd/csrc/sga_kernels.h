@@ -79,7 +79,7 @@ struct ExchangeArgs {
 // launchers (defined in the .hip files); all return hipGetLastError() after the launch
 hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
                               hipStream_t st);
-hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st);
+hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);

@@ -25,27 +25,43 @@
 namespace sga {
 
 constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight together
+constexpr int CSR_MAX_WIDE = 8;  // most waves one replica's row is dealt to
 
-template <bool FAST, bool LEAN>
-__global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(const SweepArgs a) {
+// WIDE = several waves per replica (long rows, few replicas): one replica per workgroup, the
+// row's entries are dealt to the waves in 64-entry slices, the per-wave sums meet in LDS with
+// one barrier per update (double-buffered slots, as in the dense kernel).  Every wave applies
+// an accepted flip to the shared spin byte itself before its next gather (same value from all
+// waves), so no second barrier is needed.
+template <bool FAST, bool LEAN, bool WIDE>
+__global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
+    sweep_csr_kernel(const SweepArgs a) {
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int wpb = blockDim.x >> 6;  // replicas (waves) per workgroup
-    const int r = blockIdx.x * wpb + w;
-    if (r >= a.R) return;  // wave-uniform; no barriers below
+    const int nw = blockDim.x >> 6;                     // waves in the workgroup
+    const int r = WIDE ? (int)blockIdx.x : (int)blockIdx.x * nw + w;
+    if (!WIDE && r >= a.R) return;  // wave-uniform; the narrow form has no barriers
     const int n = a.n;
-    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)w * a.sstride;
-    float *ptab = reinterpret_cast<float *>(smem + (long long)wpb * a.sstride) +
-                  (long long)w * (a.table_m + 1);
+    const int slots = WIDE ? 1 : nw;                    // replicas sharing this workgroup's LDS
+    const int me = WIDE ? 0 : w;
+    const int stride_lanes = WIDE ? 64 * nw : 64;       // entries between a lane's row elements
+    const int first_lane = WIDE ? w * 64 + lane : lane; // this lane's first entry of a row
+    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)me * a.sstride;
+    float *ptab = reinterpret_cast<float *>(smem + (long long)slots * a.sstride) +
+                  (long long)me * (a.table_m + 1);
+    double *part = reinterpret_cast<double *>(smem + (long long)slots * a.sstride +
+                                              sizeof(float) * ((a.table_m + 2) & ~1) * slots);
+    int pp = 0;
     {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
         int4 *dst = reinterpret_cast<int4 *>(s);
-        for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+        const int step = WIDE ? (int)blockDim.x : 64, first = WIDE ? tid : lane;
+        for (int i = first; i < a.sstride / 16; i += step) dst[i] = src[i];
     }
+    if constexpr (WIDE) __syncthreads();
     const bool arith32 = arith == SGA_ARITH_F32;
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
@@ -68,7 +84,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
     };
     auto load_head = [&](const Extent &x) {
         Head o;
-        const int j = x.beg + lane;
+        const int j = x.beg + first_lane;
         const bool in = j < x.end;
         o.col = in ? a.colidx[j] : 0;
         o.val = in ? a.val[j] : 0.0f;
@@ -77,18 +93,21 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
 
     double T = 1.0;
     auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
+        // read s_i before any wave can have applied THIS update's flip (WIDE: before the barrier)
+        const int si = s[site];
         // J[site,:].s over the stored entries; products val * (+-1) are exact
         float dot;
         if constexpr (FAST) {
             float acc = hd.val * (float)s[hd.col];
             // long rows: issue eight (colidx, val) wave-loads before the first gather so the
             // round trips overlap instead of serialising (degree ~600 at C4)
-            for (int j0 = x.beg + 64 + lane; j0 < x.end; j0 += 64 * TAIL_UNROLL) {
+            for (int j0 = x.beg + stride_lanes + first_lane; j0 < x.end;
+                 j0 += stride_lanes * TAIL_UNROLL) {
                 int c[TAIL_UNROLL];
                 float v[TAIL_UNROLL];
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const int j = j0 + 64 * q;
+                    const int j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
                     c[q] = in ? a.colidx[j] : 0;
                     v[q] = in ? a.val[j] : 0.0f;
@@ -97,14 +116,24 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
                 for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * (float)s[c[q]];
             }
             dot = wave_sum(acc);
+            if constexpr (WIDE) {
+                float *slot = reinterpret_cast<float *>(part) + pp * CSR_MAX_WIDE;
+                if (lane == 0) slot[w] = dot;
+                __syncthreads();
+                float t = slot[0];
+                for (int i = 1; i < nw; ++i) t += slot[i];
+                dot = t;
+                pp ^= 1;
+            }
         } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
             double acc = (double)(hd.val * (float)s[hd.col]);
-            for (int j0 = x.beg + 64 + lane; j0 < x.end; j0 += 64 * TAIL_UNROLL) {
+            for (int j0 = x.beg + stride_lanes + first_lane; j0 < x.end;
+                 j0 += stride_lanes * TAIL_UNROLL) {
                 int c[TAIL_UNROLL];
                 float v[TAIL_UNROLL];
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const int j = j0 + 64 * q;
+                    const int j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
                     c[q] = in ? a.colidx[j] : 0;
                     v[q] = in ? a.val[j] : 0.0f;
@@ -112,9 +141,18 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * (float)s[c[q]]);
             }
-            dot = (float)wave_sum(acc);
+            double tot = wave_sum(acc);
+            if constexpr (WIDE) {
+                double *slot = part + pp * CSR_MAX_WIDE;
+                if (lane == 0) slot[w] = tot;
+                __syncthreads();
+                double t = slot[0];
+                for (int i = 1; i < nw; ++i) t += slot[i];
+                tot = t;
+                pp ^= 1;
+            }
+            dot = (float)tot;
         }
-        const int si = s[site];
         double dE;
         bool flip;
         if (FAST && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
@@ -150,8 +188,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         if constexpr (FAST) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
-            for (int q = lane; q <= a.table_m; q += 64)
+            if constexpr (WIDE) __syncthreads();  // nobody still reads last sweep's table
+            for (int q = first_lane; q <= a.table_m; q += stride_lanes)
                 ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+            if constexpr (WIDE) __syncthreads();
         }
         for (int b = 0; b < nb; ++b) {
             const bool last = (b + 1 == nb);
@@ -169,48 +209,70 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_kernel(con
             xB = nB;
             hA = hN;
         }
-        if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+        const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
+        if (lane == 0 && (!WIDE || w == 0) && a.energy_trace)
+            a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
+            if constexpr (WIDE) __syncthreads();  // every wave has applied the last flip
             int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
             const int4 *src = reinterpret_cast<const int4 *>(s);
-            for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+            for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
+            if constexpr (WIDE) __syncthreads();
         }
     }
+    if constexpr (WIDE) __syncthreads();
     {
         int4 *dst = reinterpret_cast<int4 *>(a.spins + (long long)r * a.sstride);
         const int4 *src = reinterpret_cast<const int4 *>(s);
-        for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+        const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
+        for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
     }
-    if (lane == 0) {
+    if (lane == 0 && (!WIDE || w == 0)) {
         a.energy[r] = E;
         a.best_energy[r] = bestE;
         a.n_accepted[r] += nacc;
     }
 }
 
+static size_t csr_lds_per_replica(int sstride, int table_m) {  // spins + accept table (>= 8 B)
+    return (size_t)sstride + sizeof(float) * (size_t)((table_m + 2) & ~1);
+}
+
 int csr_waves_per_block(int sstride, int table_m) {
-    const size_t per = (size_t)sstride + (table_m > 0 ? sizeof(float) * (size_t)(table_m + 1) : 0);
-    int wpb = (int)((160 * 1024) / per);
+    const int wpb = (int)((160 * 1024 - 256) / csr_lds_per_replica(sstride, table_m));
     return wpb > CSR_WAVES_PER_BLOCK ? CSR_WAVES_PER_BLOCK : wpb;  // 0: does not fit
 }
 
-hipError_t launch_sweep_csr(const SweepArgs &a, hipStream_t st) {
-    const bool fast = a.table_m > 0;
-    const int wpb = csr_waves_per_block(a.sstride, a.table_m);
-    if (wpb < 1) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)a.sstride + (fast ? sizeof(float) * (size_t)(a.table_m + 1) : 0)) * wpb;
-    const bool lean = sweep_args_are_lean(a);
-    auto kern = fast ? (lean ? sweep_csr_kernel<true, true> : sweep_csr_kernel<true, false>)
-                     : (lean ? sweep_csr_kernel<false, true> : sweep_csr_kernel<false, false>);
+template <bool WIDE>
+static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
+    const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a);
+    const int slots = WIDE ? 1 : waves;
+    const size_t lds = csr_lds_per_replica(a.sstride, a.table_m) * slots +
+                       2 * CSR_MAX_WIDE * sizeof(double);
+    auto kern = fast ? (lean ? sweep_csr_kernel<true, true, WIDE> : sweep_csr_kernel<true, false, WIDE>)
+                     : (lean ? sweep_csr_kernel<false, true, WIDE> : sweep_csr_kernel<false, false, WIDE>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int blocks = (a.R + wpb - 1) / wpb;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, st, a);
+    const int blocks = WIDE ? a.R : (a.R + waves - 1) / waves;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, st, a);
     return hipGetLastError();
+}
+
+// waves_per_replica == 1: several replicas per workgroup (as many as fit LDS), no barriers;
+// > 1: one replica per workgroup, its rows dealt to that many waves.
+hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st) {
+    if (waves_per_replica > 1) {
+        if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1)
+            return hipErrorInvalidValue;
+        return launch_csr<true>(a, waves_per_replica, st);
+    }
+    const int wpb = csr_waves_per_block(a.sstride, a.table_m);
+    if (wpb < 1) return hipErrorInvalidValue;
+    return launch_csr<false>(a, wpb, st);
 }
 
 }  // namespace sga

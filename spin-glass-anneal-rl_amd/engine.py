@@ -218,10 +218,15 @@ class AnnealEngine:
     def recompute_energies(self):
         N.check(self._lib.sga_recompute_energies(self._h), "sga_recompute_energies")
 
-    def exchange(self, energies_global=None, start=None, u=None) -> int:
+    def exchange(self, energies_global=None, start=None, u=None, count: bool = True):
+        """One exchange round.  With count=False the call only enqueues the kernel (no host
+        synchronisation) and returns None -- use it inside sweep / exchange loops."""
         ep, k1 = _buf(energies_global, np.float64, "float64")
         stp, k2 = _buf(None if start is None else np.atleast_1d(start), np.int32, "int32")
         up, k3 = _buf(u, np.float64, "float64")
+        if not count:
+            N.check(self._lib.sga_exchange(self._h, ep, stp, up, None), "sga_exchange")
+            return None
         out = C.c_int(0)
         N.check(self._lib.sga_exchange(self._h, ep, stp, up, C.byref(out)), "sga_exchange")
         return int(out.value)

@@ -73,7 +73,7 @@ class SpinGlassScheduler:
                 eng.sweep(step)
                 done += step
                 if L > 1 and done < n_sweeps:
-                    eng.exchange()
+                    eng.exchange(count=False)  # enqueue only: no host round trip per round
                 if (done // exchange_interval) % max(1, record_interval // exchange_interval) == 0:
                     e_hist.append(float(eng.best(with_spins=False)[0]))
                     t_hist.append(float(temps.min()))

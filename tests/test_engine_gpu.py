@@ -384,6 +384,42 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R):
         assert be == ref["best_energy"].min()
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("integer", [True, False])
+def test_csr_wide_rows_match_oracle(sg, waves, integer):
+    """Rows of a few hundred entries dealt to several waves per replica (C4/C5 shape)."""
+    n, R = 900, 5
+    rng = np.random.RandomState(17)
+    mask = np.triu(rng.rand(n, n) < 0.35, 1)
+    vals = (rng.randint(0, 2, (n, n)) * 2 - 1) if integer else rng.randn(n, n)
+    J = (mask * vals).astype(np.float32)
+    J = J + J.T
+    h = (rng.randint(-2, 3, n) if integer else rng.randn(n)).astype(np.float32)
+    csr = csr_of(J)
+    prob = oracle.Problem(csr=csr, h=h)
+    ns, seed = 5, 6006
+    temps = ladder(R, 30.0, 3.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=waves)
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        assert f"waves_per_replica={waves}" in e.describe()
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+        for r in range(R):
+            be, bs, _ = e.best(r)
+            assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+        out2 = e.sweep(2, energy_trace=True, trace=True)       # general (traced) variant
+        ref2 = oracle.sweeps(prob, s, temps, 2, seed=seed, sweep0=ns, energy=ref["energy"],
+                             trace=True)
+        assert np.array_equal(out2["accept_trace"], ref2["accept_trace"])
+        assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
+
+
 # ----------------------------------------------------------------------------- exchange
 @pytest.mark.parametrize("R,n_ladders", [(8, 1), (9, 1), (24, 3), (64, 4)])
 def test_exchange_rounds_match_oracle(sg, R, n_ladders):

@@ -421,7 +421,7 @@ def test_c4_shaped_instance_full_size(sg):
     with sg.AnnealEngine(0) as e:
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
-        assert "n=50000" in e.describe() and "replicas_per_block=3" in e.describe()
+        assert "n=50000" in e.describe() and "waves_per_replica=2" in e.describe()
         e.set_ladder(temps)
         out = e.sweep(2, energy_trace=True)
         e.exchange()
