@@ -106,7 +106,6 @@ struct sga_engine {
     void *J_packed = nullptr;  // [n][ld] float | int8
     long long ld = 0;
     int waves = 0, cpw = 0;
-    int packed_for_R = -1;
     int32_t *rowptr = nullptr, *colidx = nullptr;
     float *val = nullptr;
     long long nnz = 0;
@@ -149,7 +148,6 @@ struct sga_engine {
         dev_free(diag);
         n = 0;
         ld = 0;
-        packed_for_R = -1;
     }
     void free_replicas() {
         dev_free(spins);

@@ -17,10 +17,10 @@ import torch
 
 from . import _native as N
 from .engine import AnnealEngine
-from .exceptions import AnnealingError, ConfigurationError
+from .exceptions import ConfigurationError
 from .ising_model import IsingModel, _device_index
 from .result import AnnealingResult
-from .spin_dynamics import UpdateRule, require_metropolis
+from .spin_dynamics import UpdateRule, rule_code
 from .temperature_scheduler import ScheduleType, TemperatureScheduler
 
 
@@ -85,7 +85,7 @@ class GPUAnnealer:
         `_replay=(sites, uniforms)`: parity-test hook -- per-update arrays recorded from the
         reference's RNG replace the Philox stream (tests/test_host_api_gpu.py).
         """
-        rule = require_metropolis(update_rule)
+        rule = rule_code(update_rule)
         cfg = self.config
         t_start = time.time()
         dev_idx = cfg.device_index if cfg.device_index is not None else _device_index(model.device)

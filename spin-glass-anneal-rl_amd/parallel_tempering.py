@@ -20,7 +20,7 @@ from .exceptions import AnnealingError, ConfigurationError
 from .gpu_annealer import fresh_seed
 from .ising_model import IsingModel, _device_index
 from .result import AnnealingResult
-from .spin_dynamics import UpdateRule, require_metropolis
+from .spin_dynamics import UpdateRule, rule_code
 from .temperature_scheduler import temperature_ladder
 
 
@@ -63,7 +63,7 @@ class ParallelTempering:
             _replay=None) -> AnnealingResult:
         """`_replay`: parity-test hook, dict(s0, site[ns,R,n], u[ns,R,n], exch_start, exch_u)
         recorded from the reference, replacing every Philox draw."""
-        rule = require_metropolis(update_rule)
+        rule = rule_code(update_rule)
         cfg = self.config
         if cfg.exchange_method != "nearest_neighbor":
             raise AnnealingError("only exchange_method='nearest_neighbor' runs on the HIP engine")

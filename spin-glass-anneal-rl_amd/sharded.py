@@ -18,8 +18,6 @@ is a validated string, annealing/multi_gpu.py:26,41-43; "multi-GPU" is a thread 
 The engine argument only needs the small surface used below, which lets the coordination
 logic be exercised on CPU with a stand-in engine (tests/test_sharded_gloo.py).
 """
-from typing import Optional
-
 import numpy as np
 import torch
 

@@ -36,15 +36,11 @@ def rule_code(rule: UpdateRule) -> int:
     return _RULE_CODE[rule]
 
 
-def require_metropolis(rule: UpdateRule) -> int:  # kept name: validates and returns the code
-    return rule_code(rule)
-
-
 class SpinDynamics:
     def __init__(self, model: IsingModel, temperature: float = 1.0,
                  update_rule: UpdateRule = UpdateRule.METROPOLIS,
                  random_seed: Optional[int] = None):
-        require_metropolis(update_rule)
+        rule_code(update_rule)  # raises for rules the engine does not implement
         self.model = model
         self.temperature = temperature
         self.update_rule = update_rule

@@ -6,7 +6,6 @@ it, tests/golden/schedules.npz).  Written here as closed-form `T(sweep)` functio
 shared `update` bookkeeping path; the hot path only ever receives the resulting array of
 temperatures (sga_sweep's `sched`).
 """
-import math
 from dataclasses import dataclass
 from enum import Enum
 from typing import Callable, Dict, List, Optional
