@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--exchange-interval", type=int, default=10)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on one GPU together with --share-device)")
@@ -294,6 +295,28 @@ def main():
                      "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
+    # the same workload with the couplings held as int8 (what coupling_storage="auto" picks for
+    # integer J; exact arithmetic, identical chain): reported beside the fp32 headline
+    if a.workload == "c2a" and a.storage == "f32" and world == 1 and not a.no_variants:
+        eng.set_dense(J, h, storage="i8")
+        pt2 = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder,
+                               n_ladders=1, dist=None, device=comm_dev)
+        pt2.sweep(1)
+        torch.cuda.synchronize()
+        eng.enable_timing(True)
+        eng.kernel_time(reset=True)
+        t1 = time.perf_counter()
+        pt2.sweep(4)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        l2, ms2 = eng.kernel_time(reset=True)
+        eng.enable_timing(False)
+        ach2 = per_launch_attempts * n / ((ms2 / max(l2, 1)) * 1e-3) / 1e9
+        out["variants"] = {"int8_couplings": {
+            "value": float(R) * n * 4 / dt2, "unit": "attempts/s", "ms_per_step": dt2 / 4 * 1e3,
+            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_attempt": n},
+            "note": "exact for integer J in [-127,127]; bit-identical chain to the fp32 layout"}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr,
                                            h=None if csr is None else h.cpu().numpy())

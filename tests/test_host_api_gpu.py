@@ -448,3 +448,31 @@ def test_c4_shaped_instance_full_size(sg):
         e.exchange()
         e.sweep(1)
         assert np.array_equal(e.energies(), tracked) and np.array_equal(e.spins(), spins_csr)
+
+
+def test_c2b_assignment_instance_full_size(sg):
+    """BASELINE configs[1] parity instance: 100 agents x 100 tasks one-hot
+    penalties (lambda = 100), 10 000 spins dense, 1024 replicas."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    b = enc.assignment_ising(100, 100, weight=100.0)
+    J, h = torch.from_numpy(b.to_dense()).cuda(), b.fields()
+    n, R, seed = 10000, 1024, 77
+    temps = np.asarray(sg.temperature_ladder(R, 1.0, 400.0))
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, h)
+        assert "storage=i8" in e.describe()          # penalties are +-25 / -50: integer
+        e.init_replicas(R, seed=seed)
+        e.set_ladder(temps)
+        out = e.sweep(3, energy_trace=True)
+        e.exchange()
+        e.sweep(2)
+        tracked = e.energies()
+        e.recompute_energies()
+        assert np.array_equal(e.energies(), tracked)
+        cold = e.spins(R - 1)
+    prob = oracle.Problem(J=b.to_dense(), h=h)
+    s = oracle.init_spins(n, 2, seed)
+    ref = oracle.sweeps(prob, s, temps[:2], 3, seed=seed, n_threads=2)
+    assert np.array_equal(out["energy_trace"][:, :2], ref["energy_trace"])
+    x = cold.reshape(100, 100) > 0       # the coldest replica is already nearly one-hot
+    assert abs(int(x.sum()) - 100) <= 30
