@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # make sure both shared libraries exist (no-op when they are up to date): libsga.so is
+    # cross-compiled by hipcc without a GPU, the oracle by gcc
+    import shutil
+    import spin_glass_anneal_rl_amd as sg
+    if not os.path.exists(sg._native.library_path()) and (
+            shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        sg._native.build()
+    import oracle
+    oracle.build()
 
 
 def load_golden(name):
