@@ -112,6 +112,22 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
 
 
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
+    """Device stream-copy rate (read + write bytes / s) on this box, GB/s -- the practical HBM
+    ceiling next to the 8 TB/s spec figure (SURVEY.md 8d asks for both denominators)."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    ev1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+
 def pmc_traffic(storage, n, R):
     """HBM bytes per sweep-kernel launch from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json, written by profiles/summarize_rocprof.py), or None."""
@@ -262,6 +278,7 @@ def main():
     achieved = per_launch_attempts * bytes_per_attempt / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
     traffic, traffic_src = pmc_traffic(a.storage, n, R) if csr is None else (None, None)
+    copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -287,6 +304,8 @@ def main():
                    "best_energy_rank0": best_e},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_stream_copy_GBs": copy_gbs,
+                     "frac_of_measured_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + "
                                      "WRITE_SIZE, separate --pmc passes)",
                      "traffic_source": traffic_src,

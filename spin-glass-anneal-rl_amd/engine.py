@@ -5,6 +5,7 @@ buffers (numpy arrays, or torch tensors whose `data_ptr()` is handed over) and t
 codes into exceptions.  PyTorch is used for device memory only.
 """
 import ctypes as C
+import threading
 from typing import Optional
 
 import numpy as np
@@ -36,12 +37,31 @@ def _buf(x, np_dtype, torch_dtype_name):
     return a.ctypes.data_as(C.c_void_p), a
 
 
+class _SerialisedLib:
+    """Calls on one handle must not overlap (include/sga.h); ctypes releases the GIL during a
+    call, so the reference's habit of driving sweeps from a thread pool
+    (parallel_tempering.py:199, multi_gpu.py:148) is made safe by one lock per engine."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._lock = threading.RLock()
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            with self._lock:
+                return fn(*args)
+
+        return call
+
+
 class AnnealEngine:
     """One engine per GPU: packed couplings + R replicas resident in HBM."""
 
     def __init__(self, device: int = 0):
         self._h = C.c_void_p()
-        self._lib = N.lib()
+        self._lib = _SerialisedLib(N.lib())
         N.check(self._lib.sga_create(int(device), C.byref(self._h)), "sga_create")
         self.device = int(device)
         self.n = 0
