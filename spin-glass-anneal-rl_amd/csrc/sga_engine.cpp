@@ -48,24 +48,47 @@ bool is_device_ptr(const void *p) {
     return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+// Grow-only device scratch slots owned by an engine: staging of host-side call arguments and
+// outputs re-uses them, so the steady-state call path performs no hipMalloc / hipFree (which
+// would synchronise the device).
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
 // A read-only view of a user buffer on the device: borrowed if it already lives there,
-// otherwise staged into a temporary allocation that dies with the object.
+// otherwise staged into a scratch slot.
 template <typename T>
 struct DevIn {
     const T *ptr = nullptr;
-    T *owned = nullptr;
-    int init(const T *user, size_t count, hipStream_t st) {
+    bool staged = false;
+    int init(Scratch &slot, const T *user, size_t count, hipStream_t st) {
         if (!user || count == 0) return SGA_OK;
         if (is_device_ptr(user)) {
             ptr = user;
             return SGA_OK;
         }
-        HIPCHK(hipMalloc(&owned, count * sizeof(T)));
-        HIPCHK(hipMemcpyAsync(owned, user, count * sizeof(T), hipMemcpyHostToDevice, st));
-        ptr = owned;
+        HIPCHK(slot.reserve(count * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(slot.ptr, user, count * sizeof(T), hipMemcpyHostToDevice, st));
+        ptr = static_cast<const T *>(slot.ptr);
+        staged = true;
         return SGA_OK;
     }
-    ~DevIn() { dev_free(owned); }
 };
 
 // A device scratch buffer whose contents are copied to a user buffer (host or device).
@@ -74,11 +97,12 @@ struct DevOut {
     T *ptr = nullptr;
     T *user = nullptr;
     size_t count = 0;
-    int init(T *user_, size_t count_, hipStream_t st) {
+    int init(Scratch &slot, T *user_, size_t count_, hipStream_t st) {
         user = user_;
         count = count_;
         if (!user || count == 0) return SGA_OK;
-        HIPCHK(hipMalloc(&ptr, count * sizeof(T)));
+        HIPCHK(slot.reserve(count * sizeof(T)));
+        ptr = static_cast<T *>(slot.ptr);
         HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T), st));
         return SGA_OK;
     }
@@ -87,7 +111,6 @@ struct DevOut {
         HIPCHK(hipMemcpyAsync(user, ptr, count * sizeof(T), hipMemcpyDefault, st));
         return SGA_OK;
     }
-    ~DevOut() { dev_free(ptr); }
 };
 
 }  // namespace
@@ -131,6 +154,10 @@ struct sga_engine {
     int32_t *slot_to_rep = nullptr;
     long long *ex_attempts = nullptr, *ex_accepts = nullptr;
     int *d_count = nullptr;
+
+    // staging slots: 0 sched, 1 replay sites, 2 replay u, 3 energy trace, 4 accept trace,
+    // 5 dE trace, 6 exchange energies, 7 exchange start, 8 exchange u
+    Scratch scratch[9];
 
     // timing
     bool timing = false;
@@ -292,6 +319,7 @@ void sga_destroy(sga_engine *e) {
     }
     e->free_replicas();
     e->free_problem();
+    for (auto &sl : e->scratch) sl.release();
     dev_free(e->d_count);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -533,7 +561,7 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
     }
     if (s0) {
         DevIn<int8_t> in;
-        int rc = in.init(s0, (size_t)R_local * e->n, e->stream);
+        int rc = in.init(e->scratch[1], s0, (size_t)R_local * e->n, e->stream);
         if (rc != SGA_OK) return rc;
         HIPCHK(sga::launch_pad_spins(in.ptr, e->n, e->spins, e->sstride, R_local, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -622,26 +650,26 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             return fail(SGA_ERR_INVALID, "negative schedule stride");
         const size_t extent =
             (size_t)((n_sweeps - 1) * sched_sweep_stride + (R - 1) * sched_replica_stride + 1);
-        rc = d_sched.init(sched, extent, st);
+        rc = d_sched.init(e->scratch[0], sched, extent, st);
         if (rc != SGA_OK) return rc;
     }
     DevIn<int32_t> d_site;
     DevIn<float> d_u;
     if (site_mode == SGA_SITE_REPLAY) {
-        rc = d_site.init(replay_site, (size_t)R * per, st);
+        rc = d_site.init(e->scratch[1], replay_site, (size_t)R * per, st);
         if (rc != SGA_OK) return rc;
     }
     if (site_mode != SGA_SITE_RANDOM && replay_u) {
-        rc = d_u.init(replay_u, (size_t)R * per, st);
+        rc = d_u.init(e->scratch[2], replay_u, (size_t)R * per, st);
         if (rc != SGA_OK) return rc;
     }
     DevOut<double> d_etrace, d_dE;
     DevOut<uint8_t> d_acc;
-    rc = d_etrace.init(energy_trace, (size_t)n_sweeps * R, st);
+    rc = d_etrace.init(e->scratch[3], energy_trace, (size_t)n_sweeps * R, st);
     if (rc != SGA_OK) return rc;
-    rc = d_acc.init(accept_trace, (size_t)R * per, st);
+    rc = d_acc.init(e->scratch[4], accept_trace, (size_t)R * per, st);
     if (rc != SGA_OK) return rc;
-    rc = d_dE.init(dE_trace, (size_t)R * per, st);
+    rc = d_dE.init(e->scratch[5], dE_trace, (size_t)R * per, st);
     if (rc != SGA_OK) return rc;
 
     // sweeps per launch: aim for ~50 ms of estimated work per launch
@@ -735,8 +763,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     if (rc != SGA_OK) return rc;
     rc = d_dE.flush(st);
     if (rc != SGA_OK) return rc;
-    // staged inputs / outputs are freed on return: wait for the stream in that case only
-    if (d_sched.owned || d_site.owned || d_u.owned || d_etrace.ptr || d_acc.ptr || d_dE.ptr)
+    // host-side outputs must be complete, and staged host inputs consumed, before returning
+    if (d_sched.staged || d_site.staged || d_u.staged || d_etrace.ptr || d_acc.ptr || d_dE.ptr)
         HIPCHK(hipStreamSynchronize(st));
     return SGA_OK;
 }
@@ -855,15 +883,15 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
     DevIn<int32_t> d_start;
     int rc;
     if (energies_global) {
-        rc = d_e.init(energies_global, (size_t)e->Rg, st);
+        rc = d_e.init(e->scratch[6], energies_global, (size_t)e->Rg, st);
         if (rc != SGA_OK) return rc;
     }
     if (start) {
-        rc = d_start.init(start, (size_t)e->n_ladders, st);
+        rc = d_start.init(e->scratch[7], start, (size_t)e->n_ladders, st);
         if (rc != SGA_OK) return rc;
     }
     if (u) {
-        rc = d_u.init(u, (size_t)e->n_ladders * (L / 2), st);
+        rc = d_u.init(e->scratch[8], u, (size_t)e->n_ladders * (L / 2), st);
         if (rc != SGA_OK) return rc;
     }
     HIPCHK(hipMemsetAsync(e->d_count, 0, sizeof(int), st));
@@ -889,8 +917,8 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
     if (n_accepted) {
         HIPCHK(hipMemcpyAsync(n_accepted, e->d_count, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-    } else if (d_e.owned || d_u.owned || d_start.owned) {
-        HIPCHK(hipStreamSynchronize(st));
+    } else if (d_e.staged || d_u.staged || d_start.staged) {
+        HIPCHK(hipStreamSynchronize(st));  // the host buffers may be reused by the caller
     }
     return SGA_OK;
 }
@@ -910,10 +938,15 @@ int sga_op_pt_exchange(int device, float *spins, float *energies, const float *t
     int32_t *d_src = nullptr;
     int *d_cnt = nullptr;
     DevIn<float> d_t, d_uu;
-    int rc = d_t.init(temps, (size_t)R, st);
+    Scratch tmp_t, tmp_u;  // stateless entry point: its own short-lived staging
+    struct Release {
+        Scratch &a, &b;
+        ~Release() { a.release(); b.release(); }
+    } release_on_exit{tmp_t, tmp_u};
+    int rc = d_t.init(tmp_t, temps, (size_t)R, st);
     if (rc != SGA_OK) return rc;
     if (u && R > 1) {
-        rc = d_uu.init(u, (size_t)(R - 1), st);
+        rc = d_uu.init(tmp_u, u, (size_t)(R - 1), st);
         if (rc != SGA_OK) return rc;
     }
     const bool spins_dev = is_device_ptr(spins), en_dev = is_device_ptr(energies);
