@@ -603,3 +603,79 @@ def test_many_model_batch_matches_per_model_oracle(sg, n, M, k, storage):
     prob = oracle.Problem(J=Js[M - 1], h=hs[M - 1])
     assert f[0] == oracle.local_field(prob, spins[R - 1], 0)
     assert f[1] == oracle.local_field(prob, spins[R - 1], n - 1)
+
+
+# ----------------------------------------------------------------------------- physics
+@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("storage", ["dense", "csr"])
+def test_samples_follow_the_boltzmann_distribution(sg, rule, storage):
+    """Independent of the oracle: at fixed T every rule must sample exp(-E/T).  The exact mean
+    energy of a 14-spin instance (16384 states, enumerated) is compared with the average over
+    4096 replicas after equilibration."""
+    n, R, T = 14, 4096, 2.5
+    rng = np.random.RandomState(3)
+    J = np.triu(rng.randint(-2, 3, (n, n)), 1).astype(np.float32)
+    J = J + J.T
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    states = ((np.arange(1 << n)[:, None] >> np.arange(n)[None, :]) & 1) * 2.0 - 1.0
+    E = -0.5 * np.einsum("si,ij,sj->s", states, J.astype(np.float64), states) - states @ h
+    w = np.exp(-(E - E.min()) / T)
+    exact_mean = float((E * w).sum() / w.sum())
+    exact_var = float((E * E * w).sum() / w.sum() - exact_mean ** 2)
+    with sg.AnnealEngine(0) as e:
+        if storage == "csr":
+            e.set_csr(*csr_of(J), h)
+        else:
+            e.set_dense(J, h)
+        e.set_update_rule(rule)
+        e.init_replicas(R, seed=1234 + rule)
+        e.set_temperatures(np.full(R, T))
+        e.sweep(60)                       # equilibrate
+        samples = []
+        for _ in range(8):
+            e.sweep(5)
+            samples.append(e.energies())
+    est = float(np.mean(samples))
+    sigma = np.sqrt(exact_var / R)        # per snapshot; snapshots are correlated: be generous
+    assert abs(est - exact_mean) < 5 * sigma, (est, exact_mean, sigma)
+
+
+def test_replica_exchange_preserves_every_slots_distribution(sg):
+    """Label swapping must leave slot i at temperature T_i in equilibrium: with 512 ladders of
+    8 temperatures the per-slot mean energies are compared with the exact Boltzmann means."""
+    n, L, ladders = 12, 8, 512
+    R = L * ladders
+    rng = np.random.RandomState(5)
+    J = np.triu(rng.randint(-2, 3, (n, n)), 1).astype(np.float32)
+    J = J + J.T
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    temps_one = ladder(L, 6.0, 0.8)
+    states = ((np.arange(1 << n)[:, None] >> np.arange(n)[None, :]) & 1) * 2.0 - 1.0
+    E = -0.5 * np.einsum("si,ij,sj->s", states, J.astype(np.float64), states) - states @ h
+    exact, var = [], []
+    for T in temps_one:
+        w = np.exp(-(E - E.min()) / T)
+        m = (E * w).sum() / w.sum()
+        exact.append(m)
+        var.append((E * E * w).sum() / w.sum() - m * m)
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, h)
+        e.init_replicas(R, seed=99)
+        e.set_ladder(np.tile(temps_one, ladders), n_ladders=ladders)
+        for _ in range(30):               # equilibrate with exchanges
+            e.sweep(2)
+            e.exchange(count=False)
+        acc = np.zeros(L)
+        rounds = 12
+        for _ in range(rounds):
+            e.sweep(2)
+            e.exchange(count=False)
+            en = e.energies()[e.slot_map()].reshape(ladders, L)   # energy found in each slot
+            acc += en.mean(0)
+        att, ok = e.exchange_stats()
+        assert ok.sum() > 0.2 * att.sum()  # exchanges really happen
+        assert np.array_equal(np.sort(e.slot_map().reshape(ladders, L), axis=1) % L,
+                              np.tile(np.arange(L), (ladders, 1)))  # swaps stay inside a ladder
+    est = acc / rounds
+    sigma = np.sqrt(np.asarray(var) / ladders)
+    assert np.all(np.abs(est - np.asarray(exact)) < 5 * sigma), (est, exact, sigma)
