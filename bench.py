@@ -158,7 +158,7 @@ def main():
                          "c5: 100-city TSP QUBO (CSR), 2048 replicas in 32 ladders")
     ap.add_argument("--spins", type=int, default=10000)
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0 = workload default)")
-    ap.add_argument("--storage", default="f32", choices=["f32", "i8"])
+    ap.add_argument("--storage", default="f32", choices=["f32", "i8", "t2"])
     ap.add_argument("--exchange-interval", type=int, default=10)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,7 +268,7 @@ def main():
 
     attempts = float(Rg) * n * a.steps
     value = attempts / dt
-    elem = 4 if a.storage == "f32" else 1
+    elem = {"f32": 4, "i8": 1, "t2": 0.25}[a.storage]
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
     if csr is None:
@@ -291,7 +291,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if (a.storage == "f32" or csr is not None) else "i8",
+        "dtype": "f32" if (a.storage == "f32" or csr is not None) else ("i8" if a.storage == "i8" else "b2"),
         "data": "synthetic",
         "config": {"workload": (f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
                                 (label or f"C3: {n}-spin CSR +-1 Ising") +

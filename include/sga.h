@@ -54,9 +54,10 @@ typedef struct sga_engine sga_engine;
 #define SGA_ERR_UNSUPPORTED -4
 
 /* coupling storage in HBM */
-#define SGA_J_AUTO 0 /* int8 if every J is an integer in [-127,127], else fp32 */
+#define SGA_J_AUTO 0 /* bit-planes if J is ternary and n >= 4096, int8 if integer in [-127,127], else fp32 */
 #define SGA_J_F32 1
 #define SGA_J_I8 2
+#define SGA_J_T2 3 /* J in {-1,0,+1} as two bit-planes (sign, non-zero): 2 bits per coupling */
 
 /* site order of a sweep */
 #define SGA_SITE_RANDOM 0     /* uniform with replacement, Philox4x32-10 (spin_dynamics.py:69) */

@@ -13,7 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("SGA_LIBRARY_PATH") or os.path.join(_CSRC, "libsga.so")  # env: A/B builds
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_MEMORY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-J_AUTO, J_F32, J_I8 = 0, 1, 2
+J_AUTO, J_F32, J_I8, J_T2 = 0, 1, 2, 3
 SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
 RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH = 0, 1, 2

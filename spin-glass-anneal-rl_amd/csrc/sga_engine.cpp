@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -126,6 +127,10 @@ struct sga_engine {
     bool csr = false;
     float *J_raw = nullptr;  // dense fp32 [n][n], engine copy of the caller's matrix
     bool want_i8 = false, acc64 = false;
+    bool use_t2 = false;           // ternary J as two bit-planes for the production sweeps
+    unsigned int *J_bits = nullptr;  // [2][n][ld/32]
+    float *row_nnz = nullptr;        // [n]
+    int waves_t2 = 0, cpw_t2 = 0;    // bit-plane geometry (waves/cpw then describe the int8 fallback)
     void *J_packed = nullptr;  // [n][ld] float | int8
     long long ld = 0;
     int waves = 0, cpw = 0;
@@ -168,6 +173,9 @@ struct sga_engine {
     void free_problem() {
         dev_free(J_raw);
         dev_free(J_packed);
+        dev_free(J_bits);
+        dev_free(row_nnz);
+        use_t2 = false;
         dev_free(rowptr);
         dev_free(colidx);
         dev_free(val);
@@ -195,13 +203,13 @@ struct sga_engine {
 namespace {
 
 int elems_per_chunk(bool i8) { return i8 ? 1024 : 256; }
+constexpr int T2_ELEMS_PER_CHUNK = 8192;  // 1 KiB of one bit-plane
 
 // Pick waves-per-replica W and chunks-per-wave CPW for a dense row of C chunks.  Measured on
 // MI355X at n = 10^4, R = 1024 (profiles/r01_geometry_sweep.md): full occupancy (R*W ~ 32
 // waves per CU) is best as long as every wave keeps >= 4 KiB of the row in flight and W
 // balances the four SIMDs; row padding is paid on every read, so it dominates the cost.
-bool choose_geometry(int n, bool i8, int R, int forced_waves, int &W, int &CPW) {
-    const int epc = elems_per_chunk(i8);
+bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW) {
     const int C = (n + epc - 1) / epc;
     double target = 8192.0 / std::max(R, 1);
     target = std::min(16.0, std::max(1.0, target));
@@ -250,22 +258,44 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     return SGA_OK;
 }
 
-// (Re)build the packed dense layout for the current replica count / tuning.
+// (Re)build the packed dense layout(s) for the current replica count / tuning.
 int ensure_packed(sga_engine *e) {
     if (e->csr) return SGA_OK;
     if (!e->J_raw) return fail(SGA_ERR_INVALID, "no couplings set");
     int W, CPW;
-    choose_geometry(e->n, e->want_i8, std::max(e->R, 1), e->tune_waves, W, CPW);
-    const long long ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
-    if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+    long long ld;
+    if (e->use_t2) {
+        // bit-plane geometry first; the int8 layout (energy / single-site kernels, non-LEAN
+        // sweeps) shares its row length: 8 waves x (Wb * CPWb) chunks of 1024 int8
+        int Wb, Cb;
+        choose_geometry(e->n, T2_ELEMS_PER_CHUNK, std::max(e->R, 1), e->tune_waves, Wb, Cb);
+        ld = (long long)Wb * Cb * T2_ELEMS_PER_CHUNK;
+        W = 8;
+        CPW = Wb * Cb;
+        if (e->J_packed && e->J_bits && e->ld == ld && e->waves_t2 == Wb && e->cpw_t2 == Cb)
+            return SGA_OK;
+        e->waves_t2 = Wb;
+        e->cpw_t2 = Cb;
+    } else {
+        choose_geometry(e->n, elems_per_chunk(e->want_i8), std::max(e->R, 1), e->tune_waves, W, CPW);
+        ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
+        if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+    }
     if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
         return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     dev_free(e->J_packed);
+    dev_free(e->J_bits);
+    dev_free(e->row_nnz);
     const long long rows = (long long)e->n_models * e->n;
     const size_t bytes = (size_t)rows * ld * (e->want_i8 ? 1 : 4);
     HIPCHK(hipMalloc(&e->J_packed, bytes));
     HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ld, e->want_i8,
                                     e->diag, e->stream));
+    if (e->use_t2) {
+        HIPCHK(hipMalloc(&e->J_bits, sizeof(unsigned int) * 2 * (size_t)e->n * (size_t)(ld / 32)));
+        HIPCHK(hipMalloc(&e->row_nnz, sizeof(float) * (size_t)e->n));
+        HIPCHK(sga::launch_repack_tern2(e->J_raw, e->n, e->J_bits, ld, e->row_nnz, e->stream));
+    }
     e->waves = W;
     e->cpw = CPW;
     e->ld = ld;
@@ -351,7 +381,7 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (!J || !h || n <= 0 || ldJ < n || n_models <= 0)
         return fail(SGA_ERR_INVALID, "bad dense problem arguments");
-    if (storage != SGA_J_AUTO && storage != SGA_J_F32 && storage != SGA_J_I8)
+    if (storage < SGA_J_AUTO || storage > SGA_J_T2)
         return fail(SGA_ERR_INVALID, "bad storage selector");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -397,7 +427,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     const bool fits_i8 = hflags[0] == 0;
     if (storage == SGA_J_I8 && !fits_i8)
         return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
-    e->want_i8 = (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
+    const bool ternary = hflags[1] == 0 && n_models == 1;
+    if (storage == SGA_J_T2 && !ternary)
+        return fail(SGA_ERR_INVALID, "bit-plane storage needs one model with J in {-1, 0, +1}");
+    e->use_t2 = storage == SGA_J_T2 || (storage == SGA_J_AUTO && ternary && n >= 4096);
+    e->want_i8 = e->use_t2 || (storage == SGA_J_I8) || (storage == SGA_J_AUTO && fits_i8);
     float m;
     std::memcpy(&m, &hflags[2], sizeof(float));
     const unsigned nonint = (unsigned)hflags[3];  // bit 0: some J, bit 1: some h not an integer
@@ -736,9 +770,21 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             HIPCHK(hipEventCreate(&ev1));
             HIPCHK(hipEventRecord(ev0, st));
         }
-        hipError_t le = e->csr ? sga::launch_sweep_csr(a, e->waves, st)
-                               : sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
-                                                         e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
+        static const bool force_general = std::getenv("SGA_FORCE_GENERAL") != nullptr;
+        const bool lean = !force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
+                          e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
+        hipError_t le;
+        if (e->csr) {
+            le = sga::launch_sweep_csr(a, e->waves, st);
+        } else if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
+            a.J = e->J_bits;
+            a.plane_bytes = (long long)e->n * (e->ld / 8);
+            a.diag = e->row_nnz;
+            le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::MAX_CPW ? 0 : e->cpw_t2, st);
+        } else {
+            le = sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
+                                         e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
+        }
         if (e->timing) {
             (void)hipEventRecord(ev1, st);
             e->events.emplace_back(ev0, ev1);
@@ -1173,10 +1219,11 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "
                       "chunks_per_wave=%d%s ld=%lld row_bytes=%lld table_m=%d",
-                      e->n, e->n_models, e->want_i8 ? "i8" : "f32",
-                      e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R, e->waves, e->cpw,
-                      e->cpw > sga::MAX_CPW ? "(streaming)" : "", e->ld,
-                      e->ld * (e->want_i8 ? 1 : 4), e->table_m);
+                      e->n, e->n_models, e->use_t2 ? "t2" : (e->want_i8 ? "i8" : "f32"),
+                      e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
+                      e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
+                      (e->use_t2 ? e->cpw_t2 : e->cpw) > sga::MAX_CPW ? "(streaming)" : "", e->ld,
+                      e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

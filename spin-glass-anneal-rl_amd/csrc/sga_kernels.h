@@ -39,6 +39,7 @@ struct SweepArgs {
     uint8_t *accept_trace;       // [R][replay_stride]
     double *dE_trace;            // [R][replay_stride]
     long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
+    long long plane_bytes;       // bit-plane form: byte offset of the non-zero plane from the sign plane
     int n, sstride, R, n_sweeps;
     int site_mode, arith, rule;
     // many-model batches (dense): replica r belongs to model (replica0 + r) / reps_per_model;
@@ -79,6 +80,11 @@ struct ExchangeArgs {
 // launchers (defined in the .hip files); all return hipGetLastError() after the launch
 hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
                               hipStream_t st);
+// ternary couplings as two bit-planes (production configuration only)
+hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStream_t st);
+// fp32 [n][n] -> sign plane + non-zero plane, each [n][ld/32] words, plus nnz[n] (as float)
+hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long ld,
+                               float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
@@ -89,8 +95,8 @@ hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t 
 // J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded, plus diag[n]
 hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, int n, void *out,
                                long long ld, bool to_i8, float *diag, hipStream_t st);
-// flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is not
-// integer-valued or |J| >= 2^10 (fp32 row sums then may be inexact -> fp64 accumulation)
+// flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is outside
+// {-1, 0, +1} (ternary couplings can be held as two bit-planes)
 hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
                               int *flags, hipStream_t st);
 hipError_t launch_pad_spins(const int8_t *src, int n, int8_t *dst, int sstride, int R,

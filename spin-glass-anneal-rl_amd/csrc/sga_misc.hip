@@ -40,7 +40,7 @@ hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, in
 
 __global__ void scan_values_kernel(const float *__restrict__ v, long long rows, long long cols,
                                    long long ld, int *flags) {
-    int not_i8 = 0, not_small_int = 0;
+    int not_i8 = 0, not_small_int = 0;  // second flag: not ternary
     const long long total = rows * cols;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -48,10 +48,10 @@ __global__ void scan_values_kernel(const float *__restrict__ v, long long rows, 
         const float x = v[row * ld + col];
         const bool is_int = (x == __builtin_rintf(x));
         if (!is_int || !(__builtin_fabsf(x) <= 127.0f)) not_i8 = 1;
-        if (!is_int || !(__builtin_fabsf(x) < 1024.0f)) not_small_int = 1;
+        if (!is_int || !(__builtin_fabsf(x) <= 1.0f)) not_small_int = 1;
     }
     if (not_i8) atomicOr(&flags[0], 1);
-    if (not_small_int) atomicOr(&flags[1], 1);
+    if (not_small_int) atomicOr(&flags[1], 1);  // some J outside {-1, 0, +1}
 }
 
 hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
@@ -97,6 +97,39 @@ hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *
                                     int n, unsigned int *out, hipStream_t st) {
     hipLaunchKernelGGL(dense_row_abs_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, J, ldJ, h,
                        n, out);
+    return hipGetLastError();
+}
+
+// fp32 row -> sign plane / non-zero plane words (bit b of word q = coupling 32 q + b)
+__global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restrict__ J, int n,
+                                                            unsigned int *__restrict__ planes,
+                                                            long long ld, float *row_nnz) {
+    __shared__ int cnt[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long words = ld / 32;
+    unsigned int *S = planes + (long long)i * words;
+    unsigned int *Z = planes + (long long)gridDim.x * words + (long long)i * words;
+    int nnz = 0;
+    for (long long q = tid; q < words; q += 256) {
+        unsigned int sb = 0, zb = 0;
+        for (int b = 0; b < 32; ++b) {
+            const long long j = q * 32 + b;
+            const float v = j < n ? J[(long long)i * n + j] : 0.0f;
+            sb |= (v < 0.0f ? 1u : 0u) << b;
+            zb |= (v != 0.0f ? 1u : 0u) << b;
+        }
+        S[q] = sb;
+        Z[q] = zb;
+        nnz += __builtin_popcount(zb);
+    }
+    const int ws = wave_sum(nnz);
+    if (lane == 0) cnt[w] = ws;
+    __syncthreads();
+    if (tid == 0) row_nnz[i] = (float)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+}
+hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long ld,
+                               float *row_nnz, hipStream_t st) {
+    hipLaunchKernelGGL(repack_tern2_kernel, dim3(n), dim3(256), 0, st, J, n, planes, ld, row_nnz);
     return hipGetLastError();
 }
 

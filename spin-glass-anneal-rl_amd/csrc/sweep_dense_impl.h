@@ -22,6 +22,8 @@
 //     chunks in batches of four loads and reduces them on the fly (no cross-update prefetch;
 //     at those sizes 16 waves x 3+ workgroups per CU keep enough bytes in flight).
 #pragma once
+#include <type_traits>
+
 #include "sweep_common.h"
 
 namespace sga {
@@ -39,9 +41,25 @@ struct JTraits<int8_t> {
     static constexpr int EPL = 16;
 };
 
+// Ternary couplings J in {-1, 0, +1} as two bit-planes per row (sign, non-zero): 16x fewer
+// bytes than fp32; the row dot becomes deg_i - 2 * popcount(nz & (sign ^ spin_bits)).
+struct Tern2 {};
+struct BitPair {
+    int4 s, z;  // 128 sign bits (1 = negative) and 128 non-zero bits per lane per chunk
+};
+template <>
+struct JTraits<Tern2> {
+    using vec_t = BitPair;
+    static constexpr int EPL = 128;
+};
+
 template <typename JT, bool ACC64>
 struct AccType {
     using type = float;
+};
+template <bool ACC64>
+struct AccType<Tern2, ACC64> {
+    using type = int;
 };
 template <>
 struct AccType<float, true> {
@@ -63,14 +81,18 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     using vec_t = typename TR::vec_t;
     using acc_t = typename AccType<JT, ACC64>::type;
     constexpr int EPL = TR::EPL, EPC = 64 * EPL;
+    constexpr bool BITS = std::is_same<JT, Tern2>::value;  // spins are bits in LDS as well
+    static_assert(!BITS || LEAN, "the bit-plane form serves the production configuration only");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int8_t *s_lds = reinterpret_cast<int8_t *>(smem);                      // [ld]
-    unsigned char *part_raw = smem + a.ld;                                 // [2][MAX_WAVES] 8-B slots
-    int *sislot = reinterpret_cast<int *>(smem + a.ld + 2 * MAX_WAVES * PART_SLOT_BYTES);  // [2]
+    const long long sbytes = BITS ? a.ld / 8 : a.ld;                       // LDS bytes of the spins
+    int8_t *s_lds = reinterpret_cast<int8_t *>(smem);                      // [ld] int8 | [ld/8] bits
+    unsigned int *s_bits = reinterpret_cast<unsigned int *>(smem);
+    unsigned char *part_raw = smem + sbytes;                               // [2][MAX_WAVES] 8-B slots
+    int *sislot = reinterpret_cast<int *>(smem + sbytes + 2 * MAX_WAVES * PART_SLOT_BYTES);  // [2]
     // integer problems with few distinct uphill moves: exp(float32(-dE/T)) tabulated per sweep
     // (bit-identical decisions, no fp64 divide / exp on the per-update chain); LEAN only
-    float *ptab = reinterpret_cast<float *>(smem + a.ld + DENSE_LDS_EXTRA);  // [table_m + 1]
+    float *ptab = reinterpret_cast<float *>(smem + sbytes + DENSE_LDS_EXTRA);  // [table_m + 1]
     const bool use_tab = LEAN && a.table_m > 0;
 
     const int tid = threadIdx.x;
@@ -80,36 +102,94 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     const int r = blockIdx.x;
     const int n = a.n;
 
-    {  // replica spins -> LDS (pad bytes are zero in HBM)
+    if constexpr (BITS) {  // int8 spins in HBM -> one bit per spin in LDS (1 = spin down)
+        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
+        for (int i = tid; i < a.sstride / 32; i += blockDim.x) {
+            const int4 lo = src[2 * i], hi = src[2 * i + 1];
+            const int wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            unsigned int bits = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)  // sign bit of each of the 4 bytes of a dword
+                bits |= (((unsigned)wds[q] >> 7) & 1u) << (4 * q) | (((unsigned)wds[q] >> 15) & 1u) << (4 * q + 1) |
+                        (((unsigned)wds[q] >> 23) & 1u) << (4 * q + 2) | (((unsigned)wds[q] >> 31) & 1u) << (4 * q + 3);
+            s_bits[i] = bits;
+        }
+    } else {  // replica spins -> LDS (pad bytes are zero in HBM)
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
         int4 *dst = reinterpret_cast<int4 *>(s_lds);
         for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
+    // LDS spins back to the int8 HBM layout (bit form: pad spins beyond n stay 0)
+    auto store_spins = [&](int8_t *dst_row) {
+        if constexpr (BITS) {
+            int4 *dst = reinterpret_cast<int4 *>(dst_row);
+            for (int i = tid; i < a.sstride / 16; i += blockDim.x) {
+                const unsigned int half = (s_bits[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                int out[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned int v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = 16 * i + 4 * q + b;
+                        const unsigned int byte = j < n ? (((half >> (4 * q + b)) & 1u) ? 0xFFu : 0x01u) : 0u;
+                        v |= byte << (8 * b);
+                    }
+                    out[q] = (int)v;
+                }
+                dst[i] = make_int4(out[0], out[1], out[2], out[3]);
+            }
+        } else {
+            int4 *dst = reinterpret_cast<int4 *>(dst_row);
+            const int4 *src = reinterpret_cast<const int4 *>(s_lds);
+            for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+        }
+    };
 
     const long long kstride = (long long)W * EPC;  // elements between a wave's chunks
     const int model = a.reps_per_model > 0 ? (int)((a.replica0 + (uint32_t)r) / a.reps_per_model) : 0;
-    const JT *Jlane = reinterpret_cast<const JT *>(a.J) + model * a.model_stride_j +
-                      (w * EPC + lane * EPL);
+    // element-addressed for fp32 / int8; the bit-plane form addresses bytes (two planes)
+    using JE = typename std::conditional<BITS, unsigned char, JT>::type;
+    constexpr int LANE_STEP = BITS ? 16 : EPL, CHUNK_STEP = BITS ? 1024 : EPC;
+    const long long row_step = BITS ? a.ld / 8 : a.ld;
+    const JE *Jlane = reinterpret_cast<const JE *>(a.J) + (BITS ? 0 : model * a.model_stride_j) +
+                      (w * CHUNK_STEP + lane * LANE_STEP);
     const float *hvec = a.h + (long long)model * n;
     const float *dvec = a.diag + (long long)model * n;
-    const int8_t *slane = s_lds + (w * EPC + lane * EPL);
+    const long long kstep = (long long)W * CHUNK_STEP;  // address step between a wave's chunks
+    const int8_t *slane = s_lds + (w * CHUNK_STEP + lane * LANE_STEP);
     const bool arith32 = arith == SGA_ARITH_F32;
 
     constexpr int NBUF = CPW > 0 ? CPW : 1;
     const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
 
-    auto load_row = [&](vec_t(&buf)[NBUF], int site) {
-        if constexpr (CPW == 0) return;  // streaming form loads inside the reduction
-        const JT *p = Jlane + (long long)site * a.ld;
-#pragma unroll
+    auto load_chunk = [&](const JE *p, long long k) -> vec_t {
         // default cache policy on purpose: non-temporal loads measured 3-5 % slower here (part
         // of J is re-served by the 256 MB Infinity Cache; profiles/r01_experiments.md)
-        for (int k = 0; k < CPW; ++k) buf[k] = *reinterpret_cast<const vec_t *>(p + k * kstride);
+        if constexpr (BITS) {
+            BitPair o;
+            o.s = *reinterpret_cast<const int4 *>(p + k * kstep);
+            o.z = *reinterpret_cast<const int4 *>(p + a.plane_bytes + k * kstep);
+            return o;
+        } else {
+            return *reinterpret_cast<const vec_t *>(p + k * kstep);
+        }
+    };
+
+    auto load_row = [&](vec_t(&buf)[NBUF], int site) {
+        if constexpr (CPW == 0) return;  // streaming form loads inside the reduction
+        const JE *p = Jlane + (long long)site * row_step;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) buf[k] = load_chunk(p, k);
     };
 
     auto accumulate = [&](acc_t &acc, const vec_t &x, long long k) {
-        if constexpr (sizeof(JT) == 4) {  // J * (+-1) is exact in fp32
+        if constexpr (BITS) {  // count the stored couplings whose product with the spin is -1
+            const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstep);
+            acc += __builtin_popcount(x.z.x & (x.s.x ^ sv.x)) + __builtin_popcount(x.z.y & (x.s.y ^ sv.y)) +
+                   __builtin_popcount(x.z.z & (x.s.z ^ sv.z)) + __builtin_popcount(x.z.w & (x.s.w ^ sv.w));
+        } else if constexpr (sizeof(JT) == 4) {  // J * (+-1) is exact in fp32
             const int sw = *reinterpret_cast<const int *>(slane + k * kstride);
             const float s0 = (float)(int8_t)(sw), s1 = (float)(int8_t)(sw >> 8),
                         s2 = (float)(int8_t)(sw >> 16), s3 = (float)(sw >> 24);
@@ -135,13 +215,13 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 
     // streaming reduction of row `site`: batches of four 1-KiB chunks per wave
     auto dot_stream = [&](int site) -> acc_t {
-        const JT *p = Jlane + (long long)site * a.ld;
+        const JE *p = Jlane + (long long)site * row_step;
         acc_t acc = 0;
         for (int k0 = 0; k0 < cpw_rt; k0 += 4) {
             vec_t t[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (k0 + j < cpw_rt) t[j] = *reinterpret_cast<const vec_t *>(p + (k0 + j) * kstride);
+                if (k0 + j < cpw_rt) t[j] = load_chunk(p, k0 + j);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (k0 + j < cpw_rt) accumulate(acc, t[j], k0 + j);
@@ -170,13 +250,17 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         else lane_sum = dot_row(buf);
         acc_t tot = wave_sum(lane_sum);
         const int owner = (site / EPC) % W;
+        auto spin_at = [&](int i) -> int {
+            if constexpr (BITS) return ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -1 : 1;
+            else return s_lds[i];
+        };
         int si;
         if (W > 1) {
             acc_t *part = reinterpret_cast<acc_t *>(part_raw + pp * MAX_WAVES * PART_SLOT_BYTES);
             if (lane == 0) {
                 *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
                                            w * PART_SLOT_BYTES) = tot;
-                if (w == owner) sislot[pp] = s_lds[site];
+                if (w == owner) sislot[pp] = spin_at(site);
             }
             __syncthreads();
             acc_t s = *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part));
@@ -187,21 +271,26 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             si = sislot[pp];
             pp ^= 1;
         } else {
-            si = s_lds[site];
+            si = spin_at(site);
         }
+        // bit-plane form: tot counts the -1 products, d_site carries the row's non-zero count
+        const float dotf = BITS ? d_site - 2.0f * (float)tot : (float)tot;
         double dE;
         bool acc;
         if (use_tab) {  // every quantity is an integer: dE = 2 k exactly, k <= table_m
-            const float fk = (float)si * ((float)tot + h_site);
+            const float fk = (float)si * (dotf + h_site);
             dE = (double)(2.0f * fk);
             acc = fk <= 0.0f || u < ptab[(int)fk];
         } else {
-            acc = metropolis_accept(rule, arith, (float)tot, si, h_site, d_site, T, u, dE);
+            acc = metropolis_accept(rule, arith, dotf, si, h_site, d_site, T, u, dE);
         }
         if (acc) {
             E += dE;
             ++nacc;
-            if (w == owner && lane == 0) s_lds[site] = (int8_t)(-si);
+            if (w == owner && lane == 0) {
+                if constexpr (BITS) s_bits[site >> 5] ^= 1u << (site & 31);
+                else s_lds[site] = (int8_t)(-si);
+            }
         }
         if constexpr (!LEAN) {
             if (tid == 0) {
@@ -219,7 +308,8 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     PairSource<LEAN> rng;
     UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
     load_row(X, cur.sA);
-    float hX = hvec[cur.sA], dX = arith32 ? dvec[cur.sA] : 0.0f;
+    const bool need_d = arith32 || BITS;  // J_ii for the fp32 rule | row non-zero count (bits)
+    float hX = hvec[cur.sA], dX = need_d ? dvec[cur.sA] : 0.0f;
 
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
@@ -236,12 +326,12 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             const bool hasB = (2 * b + 1) < n;
             const int sY = hasB ? cur.sB : nxt.sA;
             load_row(Y, sY);  // in flight while X is reduced
-            float hY = hvec[sY], dY = arith32 ? dvec[sY] : 0.0f;
+            float hY = hvec[sY], dY = need_d ? dvec[sY] : 0.0f;
             step(X, cur.sA, cur.uA, hX, dX, (long long)k * n + 2 * b);
             if (hasB) {
                 load_row(X, nxt.sA);
                 hX = hvec[nxt.sA];
-                dX = arith32 ? dvec[nxt.sA] : 0.0f;
+                dX = need_d ? dvec[nxt.sA] : 0.0f;
                 step(Y, cur.sB, cur.uB, hY, dY, (long long)k * n + 2 * b + 1);
             } else {  // odd n: the prefetched row is the next sweep's first
 #pragma unroll
@@ -256,19 +346,13 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         if (E < bestE && !a.no_best) {
             bestE = E;
             __syncthreads();
-            int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
-            const int4 *src = reinterpret_cast<const int4 *>(s_lds);
-            for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+            store_spins(a.best_spins + (long long)r * a.sstride);
             __syncthreads();
         }
     }
 
     __syncthreads();
-    {
-        int4 *dst = reinterpret_cast<int4 *>(a.spins + (long long)r * a.sstride);
-        const int4 *src = reinterpret_cast<const int4 *>(s_lds);
-        for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
-    }
+    store_spins(a.spins + (long long)r * a.sstride);
     if (tid == 0) {
         a.energy[r] = E;
         a.best_energy[r] = bestE;
@@ -278,9 +362,17 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 
 template <typename JT, bool ACC64, int CPW>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
-    const size_t lds = (size_t)a.ld + DENSE_LDS_EXTRA + sizeof(float) * (size_t)(a.table_m + 1);
-    auto kern = sweep_args_are_lean(a) ? sweep_dense_kernel<JT, CPW, ACC64, true>
-                                       : sweep_dense_kernel<JT, CPW, ACC64, false>;
+    constexpr bool BITS = std::is_same<JT, Tern2>::value;
+    const size_t lds = (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
+                       sizeof(float) * (size_t)(a.table_m + 1);
+    void (*kern)(const SweepArgs);
+    if constexpr (BITS) {
+        if (!sweep_args_are_lean(a)) return hipErrorInvalidValue;  // engine falls back to int8
+        kern = sweep_dense_kernel<JT, CPW, ACC64, true>;
+    } else {
+        kern = sweep_args_are_lean(a) ? sweep_dense_kernel<JT, CPW, ACC64, true>
+                                      : sweep_dense_kernel<JT, CPW, ACC64, false>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

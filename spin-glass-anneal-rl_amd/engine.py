@@ -98,7 +98,7 @@ class AnnealEngine:
 
     # ------------------------------------------------------------------ problem
     def set_dense(self, J, h, storage: str = "auto"):
-        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8}[storage]
+        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8, "t2": N.J_T2}[storage]
         if _is_tensor(J):
             if J.dim() != 2 or J.shape[0] != J.shape[1]:
                 raise AnnealingError("couplings must be a square matrix")
@@ -122,7 +122,7 @@ class AnnealEngine:
 
     def set_dense_batch(self, J, h, storage: str = "auto"):
         """Many independent models of one size: J [M, n, n], h [M, n] (numpy or torch)."""
-        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8}[storage]
+        sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8, "t2": N.J_T2}[storage]
         if _is_tensor(J):
             Jt = J.detach().float().contiguous()
             M, n = Jt.shape[0], Jt.shape[1]

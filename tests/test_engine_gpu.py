@@ -679,3 +679,73 @@ def test_replica_exchange_preserves_every_slots_distribution(sg):
     est = acc / rounds
     sigma = np.sqrt(np.asarray(var) / ladders)
     assert np.all(np.abs(est - np.asarray(exact)) < 5 * sigma), (est, exact, sigma)
+
+
+# ----------------------------------------------------------------------------- bit-plane couplings
+T2_CASES = [(64, 4, 0, 1.0), (300, 5, 0, 0.3), (5000, 3, 0, 1.0), (10000, 3, 2, 1.0),
+            (20000, 2, 3, 0.05), (8193, 3, 0, 1.0), (70000, 2, 0, 0.001)]
+
+
+@pytest.mark.parametrize("n,R,waves,density", T2_CASES)
+def test_ternary_bit_plane_storage_matches_oracle(sg, n, R, waves, density):
+    """J in {-1, 0, +1} held as two bit-planes (popcount row sums) must run the oracle's chain."""
+    rng = np.random.RandomState(n)
+    if n <= 10000:
+        J = np.triu((rng.randint(0, 2, (n, n)) * 2 - 1) * (rng.rand(n, n) < density), 1).astype(np.float32)
+        J = J + J.T
+        prob_args = dict(J=J)
+    else:  # large n: a banded / scattered ternary matrix, oracle through CSR
+        import scipy.sparse as sp
+        m = int(n * n * density / 2)
+        i, j = rng.randint(0, n, m), rng.randint(0, n, m)
+        keep = i < j
+        up = sp.coo_matrix(((rng.randint(0, 2, keep.sum()) * 2 - 1).astype(np.float32),
+                            (i[keep], j[keep])), shape=(n, n)).tocsr()
+        up.data = np.sign(up.data).astype(np.float32)       # merged duplicates back to +-1 / 0
+        A = (up + up.T).tocsr()
+        A.eliminate_zeros()
+        A.sort_indices()
+        J = torch_dense = None
+        prob_args = dict(csr=(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data))
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(h=h, **prob_args)
+    ns, seed = 3, 4321 + n
+    temps = ladder(R, 4.0, 0.6)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=waves)
+        if J is None:
+            import torch
+            Jt = torch.sparse_csr_tensor(torch.from_numpy(A.indptr.astype(np.int64)),
+                                         torch.from_numpy(A.indices.astype(np.int64)),
+                                         torch.from_numpy(A.data), size=(n, n)).to_dense().cuda()
+            e.set_dense(Jt, h, storage="t2")
+            del Jt
+        else:
+            e.set_dense(J, h, storage="t2")
+        e.init_replicas(R, seed=seed)
+        assert "storage=t2" in e.describe()
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"]), e.describe()
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"])
+        for r in range(R):
+            be, bs, _ = e.best(r)
+            assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+        e.recompute_energies()
+        assert np.array_equal(e.energies(), ref["energy"])
+        # traced sweeps fall back to the int8 layout of the same couplings
+        out2 = e.sweep(1, energy_trace=True, trace=True)
+        ref2 = oracle.sweeps(prob, s, temps, 1, seed=seed, sweep0=ns, energy=ref["energy"])
+        assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
+
+
+def test_bit_plane_storage_needs_ternary_couplings(sg):
+    with sg.AnnealEngine(0) as e:
+        with pytest.raises(sg.AnnealingError):
+            e.set_dense(pm1(32, 1) * 2.0, np.zeros(32, np.float32), storage="t2")
+        e.set_dense(pm1(5000, 1), np.zeros(5000, np.float32))       # auto: ternary and n >= 4096
+        e.init_replicas(2, seed=1)
+        assert "storage=t2" in e.describe()
