@@ -438,7 +438,8 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // fp32 partial sums are exact (any order) when J is integer valued and no row's sum of
     // |J| reaches 2^24; otherwise the row sum is accumulated in fp64
     e->acc64 = !e->want_i8 && !((nonint & 1u) == 0u && m < 16777216.0f);
-    if (nonint == 0u && m >= 1.0f && m <= 2048.0f) e->table_m = (int)m;
+    // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
+    if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
     return ensure_packed(e);
 }
 
@@ -509,7 +510,7 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
             }
             m = std::max(m, row);
         }
-        if (integral && m >= 1.0 && m <= 2048.0) e->table_m = (int)m;
+        if (integral && m >= 1.0 && m < 16777216.0) e->table_m = (int)std::min(m, 2048.0);
         // symmetric with zero diagonal?  (value of (i,j) must equal value of (j,i))
         e->consistent_dE = true;
         if (nnz > 0 && nnz <= 200000000) {

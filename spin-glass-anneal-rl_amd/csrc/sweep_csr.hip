@@ -159,7 +159,9 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2k exactly
             const float fk = (float)si * (dot + x.h);
             dE = (double)(2.0f * fk);
-            flip = fk <= 0.0f || u < ptab[(int)fk];
+            if (fk <= 0.0f) flip = true;
+            else if (fk <= (float)a.table_m) flip = u < ptab[(int)fk];
+            else flip = u < expf_det((float)(-dE / T));  // beyond the table: evaluate
         } else {
             flip = metropolis_accept(rule, arith, dot, si, x.h, x.d, T, u, dE);
         }

@@ -277,10 +277,12 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         const float dotf = BITS ? d_site - 2.0f * (float)tot : (float)tot;
         double dE;
         bool acc;
-        if (use_tab) {  // every quantity is an integer: dE = 2 k exactly, k <= table_m
-            const float fk = (float)si * (dotf + h_site);
+        if (use_tab) {  // every quantity is an integer: dE = 2 k exactly; k beyond the table
+            const float fk = (float)si * (dotf + h_site);  // (rare, large moves) is evaluated
             dE = (double)(2.0f * fk);
-            acc = fk <= 0.0f || u < ptab[(int)fk];
+            if (fk <= 0.0f) acc = true;
+            else if (fk <= (float)a.table_m) acc = u < ptab[(int)fk];
+            else acc = u < expf_det((float)(-dE / T));
         } else {
             acc = metropolis_accept(rule, arith, dotf, si, h_site, d_site, T, u, dE);
         }
