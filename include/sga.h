@@ -182,6 +182,16 @@ int sga_set_seed(sga_engine *e, uint64_t seed);
 int sga_get_sweep_counter(sga_engine *e, uint32_t *sweeps_done, uint32_t *exchange_rounds);
 int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange_rounds);
 
+/* ---- checkpoint / resume ---------------------------------------------------------------- */
+/* Everything that makes a run continue bit-exactly -- spins, tracked and best energies, best
+ * configurations, temperatures, ladder permutation and statistics, acceptance counters, seed
+ * and stream counters -- as one host blob.  sga_export_state with buf == NULL only reports the
+ * size.  Import needs an engine holding the same problem with replicas (and ladder, if one was
+ * exported) initialised to the same counts.  (The reference can only save final results:
+ * AnnealingResult.save, annealing/result.py:147-165.) */
+int sga_export_state(sga_engine *e, void *buf, uint64_t capacity, uint64_t *needed);
+int sga_import_state(sga_engine *e, const void *buf, uint64_t size);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* With timing enabled every sweep-kernel launch is bracketed by HIP events on the launch
  * stream; sga_get_kernel_time returns the launches and their summed duration since the

@@ -13,6 +13,7 @@ from .temperature_scheduler import (ScheduleConfig, ScheduleType, TemperatureSch
 from .result import AnnealingResult
 from .ising_model import IsingModel, IsingModelConfig
 from .spin_dynamics import SpinDynamics, UpdateRule
+from .energy_computer import ComputeMode, EnergyComputer, EnergyStats
 from .gpu_annealer import GPUAnnealer, GPUAnnealerConfig
 from .parallel_tempering import ParallelTempering, ParallelTemperingConfig
 from .kernel_manager import CUDAKernelManager, GPUMemoryOptimizer, HIPKernelManager
@@ -31,5 +32,6 @@ __all__ = [
     "GPUAnnealer", "GPUAnnealerConfig", "ParallelTempering", "ParallelTemperingConfig",
     "HIPKernelManager", "CUDAKernelManager", "GPUMemoryOptimizer", "SpinGlassScheduler",
     "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig",
-    "encoders", "IsingBuilder", "BatchConfig", "BatchProcessor",
+    "encoders", "IsingBuilder", "BatchConfig", "BatchProcessor", "EnergyComputer", "ComputeMode",
+    "EnergyStats",
 ]

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("sga_set_seed", _i, [_p, _u64]),
     ("sga_get_sweep_counter", _i, [_p, C.POINTER(_u32), C.POINTER(_u32)]),
     ("sga_set_sweep_counter", _i, [_p, _u32, _u32]),
+    ("sga_export_state", _i, [_p, _p, _u64, C.POINTER(_u64)]),
+    ("sga_import_state", _i, [_p, _p, _u64]),
     ("sga_enable_timing", _i, [_p, _i]),
     ("sga_get_kernel_time", _i, [_p, C.POINTER(_i64), C.POINTER(_d), _i]),
     ("sga_describe", _i, [_p, C.c_char_p, _i]),

@@ -1175,6 +1175,97 @@ int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange
     return SGA_OK;
 }
 
+// ---- checkpoint / resume -------------------------------------------------------------------
+namespace {
+struct StateHeader {
+    uint64_t magic;
+    int32_t n, R, Rg, replica0, sstride, n_ladders;
+    uint32_t sweeps_done, rounds;
+    uint64_t seed;
+    int64_t attempted;
+};
+constexpr uint64_t STATE_MAGIC = 0x5347415354415445ull;  // "SGASTATE"
+
+uint64_t state_bytes(const sga_engine *e) {
+    const uint64_t R = (uint64_t)e->R, Rg = (uint64_t)e->Rg, sb = R * (uint64_t)e->sstride;
+    uint64_t total = sizeof(StateHeader) + 2 * sb + 3 * R * sizeof(double) + R * sizeof(uint64_t);
+    if (e->n_ladders > 0) total += Rg * (sizeof(int32_t) + 2 * sizeof(int64_t));
+    return total;
+}
+}  // namespace
+
+int sga_export_state(sga_engine *e, void *buf, uint64_t capacity, uint64_t *needed) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    const uint64_t total = state_bytes(e);
+    if (needed) *needed = total;
+    if (!buf) return SGA_OK;
+    if (capacity < total) return fail(SGA_ERR_INVALID, "state buffer too small");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    unsigned char *p = static_cast<unsigned char *>(buf);
+    StateHeader h{STATE_MAGIC, e->n, e->R, e->Rg, e->replica0, e->sstride, e->n_ladders,
+                  e->sweeps_done, e->rounds, e->seed, (int64_t)e->attempted};
+    std::memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    auto pull = [&](const void *dev, size_t bytes) -> hipError_t {
+        hipError_t r = hipMemcpy(p, dev, bytes, hipMemcpyDeviceToHost);
+        p += bytes;
+        return r;
+    };
+    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->sstride;
+    HIPCHK(pull(e->spins, sb));
+    HIPCHK(pull(e->best_spins, sb));
+    HIPCHK(pull(e->energy, R * sizeof(double)));
+    HIPCHK(pull(e->best_energy, R * sizeof(double)));
+    HIPCHK(pull(e->rep_temp, R * sizeof(double)));
+    HIPCHK(pull(e->n_acc, R * sizeof(uint64_t)));
+    if (e->n_ladders > 0) {
+        HIPCHK(pull(e->slot_to_rep, Rg * sizeof(int32_t)));
+        HIPCHK(pull(e->ex_attempts, Rg * sizeof(int64_t)));
+        HIPCHK(pull(e->ex_accepts, Rg * sizeof(int64_t)));
+    }
+    return SGA_OK;
+}
+
+int sga_import_state(sga_engine *e, const void *buf, uint64_t size) {
+    if (!e || !buf) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "initialise the replicas before importing a state");
+    if (size < sizeof(StateHeader)) return fail(SGA_ERR_INVALID, "state blob truncated");
+    StateHeader h;
+    std::memcpy(&h, buf, sizeof(h));
+    if (h.magic != STATE_MAGIC) return fail(SGA_ERR_INVALID, "not an engine state blob");
+    if (h.n != e->n || h.R != e->R || h.Rg != e->Rg || h.replica0 != e->replica0 ||
+        h.sstride != e->sstride || h.n_ladders != e->n_ladders)
+        return fail(SGA_ERR_INVALID, "state blob does not match this engine's problem / replicas / ladder");
+    if (size != state_bytes(e)) return fail(SGA_ERR_INVALID, "state blob has the wrong size");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const unsigned char *p = static_cast<const unsigned char *>(buf) + sizeof(h);
+    auto push = [&](void *dev, size_t bytes) -> hipError_t {
+        hipError_t r = hipMemcpy(dev, p, bytes, hipMemcpyHostToDevice);
+        p += bytes;
+        return r;
+    };
+    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->sstride;
+    HIPCHK(push(e->spins, sb));
+    HIPCHK(push(e->best_spins, sb));
+    HIPCHK(push(e->energy, R * sizeof(double)));
+    HIPCHK(push(e->best_energy, R * sizeof(double)));
+    HIPCHK(push(e->rep_temp, R * sizeof(double)));
+    HIPCHK(push(e->n_acc, R * sizeof(uint64_t)));
+    if (e->n_ladders > 0) {
+        HIPCHK(push(e->slot_to_rep, Rg * sizeof(int32_t)));
+        HIPCHK(push(e->ex_attempts, Rg * sizeof(int64_t)));
+        HIPCHK(push(e->ex_accepts, Rg * sizeof(int64_t)));
+    }
+    e->sweeps_done = h.sweeps_done;
+    e->rounds = h.rounds;
+    e->seed = h.seed;
+    e->attempted = h.attempted;
+    return SGA_OK;
+}
+
 // ---- measurement --------------------------------------------------------------------------
 int sga_enable_timing(sga_engine *e, int on) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");

@@ -332,6 +332,19 @@ class AnnealEngine:
     def set_counters(self, sweeps_done: int, exchange_rounds: int):
         N.check(self._lib.sga_set_sweep_counter(self._h, int(sweeps_done), int(exchange_rounds)))
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def export_state(self) -> bytes:
+        """Everything needed to continue this run bit-exactly (see sga_export_state)."""
+        need = C.c_uint64(0)
+        N.check(self._lib.sga_export_state(self._h, None, 0, C.byref(need)), "sga_export_state")
+        buf = (C.c_ubyte * need.value)()
+        N.check(self._lib.sga_export_state(self._h, buf, need.value, None), "sga_export_state")
+        return bytes(buf)
+
+    def import_state(self, blob: bytes):
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        N.check(self._lib.sga_import_state(self._h, buf, len(blob)), "sga_import_state")
+
     # ------------------------------------------------------------------ measurement
     def enable_timing(self, on: bool = True):
         N.check(self._lib.sga_enable_timing(self._h, 1 if on else 0))

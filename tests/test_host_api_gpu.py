@@ -514,3 +514,67 @@ def test_engine_calls_are_serialised_across_threads(sg):
         tracked = e.energies()
         e.recompute_energies()
         assert np.array_equal(e.energies(), tracked)
+
+
+def test_energy_computer_mirror(sg):
+    g = load_golden("sweeps_field_n64")
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    m = model_from(sg, g["J"], g["h"], g["s0"])
+    ec = sg.EnergyComputer(m, sg.ComputeMode.VECTORIZED)
+    s = g["s0"]
+    assert ec.compute_total_energy() == oracle.energy(prob, s)
+    assert ec.compute_energy_change(7) == 2.0 * s[7] * oracle.local_field(prob, s, 7)
+    grad = ec.compute_energy_gradient().numpy()
+    assert np.array_equal(grad, np.asarray([-oracle.local_field(prob, s, i) for i in range(64)],
+                                           np.float32))
+    st = ec.compute_energy_stats()
+    assert st.total_energy == oracle.energy(prob, s)
+    assert st.field_energy == -float(np.dot(g["h"].astype(np.float64), s))
+    assert float(st.per_spin_energy.sum()) == pytest.approx(st.total_energy)
+    cfgs = torch.from_numpy(oracle.init_spins(64, 5, 3).astype(np.float32))
+    batch = ec.compute_batch_energies(cfgs).numpy()
+    assert np.array_equal(batch, oracle.energy(prob, cfgs.numpy().astype(np.int8)).astype(np.float32))
+    assert ec.compute_total_energy(cfgs[2]) == batch[2]
+
+
+def test_checkpoint_resume_is_bit_exact(sg):
+    g = load_golden("sweeps_pm1_n300")
+    R, temps = 12, np.asarray(sg.temperature_ladder(12, 0.4, 5.0))
+
+    def fresh():
+        e = sg.AnnealEngine(0)
+        e.set_dense(g["J"], g["h"])
+        e.init_replicas(R, seed=77)
+        e.set_ladder(np.tile(temps[:6], 2), n_ladders=2)
+        return e
+
+    def advance(e, rounds):
+        for _ in range(rounds):
+            e.sweep(3)
+            e.exchange(count=False)
+
+    a = fresh()
+    advance(a, 4)
+    blob = a.export_state()
+    advance(a, 5)
+    b = fresh()
+    with pytest.raises(sg.AnnealingError):
+        b.import_state(blob[:-8])
+    b.import_state(blob)
+    assert b.counters() == (12, 4)
+    advance(b, 5)
+    assert np.array_equal(a.spins(), b.spins()) and np.array_equal(a.energies(), b.energies())
+    assert np.array_equal(a.slot_map(), b.slot_map()) and a.counters() == b.counters()
+    assert all(np.array_equal(x, y) for x, y in zip(a.exchange_stats(), b.exchange_stats()))
+    assert all(np.array_equal(x, y) for x, y in zip(a.stats(), b.stats()))
+    for r in (0, 5, 11):
+        ea, sa, _ = a.best(r)
+        eb, sb, _ = b.best(r)
+        assert ea == eb and np.array_equal(sa, sb)
+    other = sg.AnnealEngine(0)
+    other.set_dense(g["J"], g["h"])
+    other.init_replicas(R + 1, seed=77)
+    with pytest.raises(sg.AnnealingError):
+        other.import_state(blob)
+    for e in (a, b, other):
+        e.close()
