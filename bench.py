@@ -87,7 +87,10 @@ def host_cores():
     return int(os.environ.get("SGA_CPU_THREADS", cores))
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None, h=None):
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None, h=None, eng=None):
+    """Time the CPU port on a bounded sample and, with `eng` (already loaded with the same
+    couplings), replay the identical sample -- same seed, replica ids, temperatures -- on the GPU:
+    the energy gap between the two is the metric's "best-energy gap vs ref" (0 = bit-identical)."""
     import oracle
     cores = host_cores()
     R = max(cores * budget_replicas_per_core, 1)
@@ -102,11 +105,21 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None
     e0 = np.zeros(R)
     temps = geometric_ladder(R)
     t0 = time.perf_counter()
-    oracle.sweeps(prob, s, temps, sweeps, seed=seed, energy=e0, n_threads=cores)
+    res = oracle.sweeps(prob, s, temps, sweeps, seed=seed, energy=e0, n_threads=cores)
     dt = time.perf_counter() - t0
     oracle.set_exact_f32(False)
+    gap = None
+    if eng is not None:  # outside every timed region
+        eng.init_replicas(R, seed=seed)
+        eng.set_temperatures(temps)
+        e_start = eng.energies()  # the CPU sample tracked the change from these
+        eng.sweep(sweeps)
+        e_gpu, e_cpu = eng.energies(), e_start + res["energy"]
+        gap = {"max_abs_energy_gap": float(np.max(np.abs(e_gpu - e_cpu))),
+               "best_energy_cpu": float(e_cpu.min()), "best_energy_gpu": float(e_gpu.min()),
+               "spins_identical": bool(np.array_equal(eng.spins(), s))}
     return {"value": R * n * sweeps / dt, "unit": "spin-flip attempts/s", "cores": cores,
-            "kind": "port",
+            "kind": "port", "energy_gap_vs_gpu": gap,
             "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin "
                       f"{'CSR' if csr is not None else 'dense'} instance, OpenMP over replicas"
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
@@ -345,7 +358,7 @@ def main():
                                                "(latency bound, not HBM bound)")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr,
-                                           h=None if csr is None else h.cpu().numpy())
+                                           h=None if csr is None else h.cpu().numpy(), eng=eng)
     else:
         out["cpu_baseline"] = None
     if rank == 0:

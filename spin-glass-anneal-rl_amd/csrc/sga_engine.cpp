@@ -209,7 +209,8 @@ constexpr int T2_ELEMS_PER_CHUNK = 8192;  // 1 KiB of one bit-plane
 // MI355X at n = 10^4, R = 1024 (profiles/r01_geometry_sweep.md): full occupancy (R*W ~ 32
 // waves per CU) is best as long as every wave keeps >= 4 KiB of the row in flight and W
 // balances the four SIMDs; row padding is paid on every read, so it dominates the cost.
-bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW) {
+bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
+                     int max_cpw = sga::MAX_CPW) {
     const int C = (n + epc - 1) / epc;
     double target = 8192.0 / std::max(R, 1);
     target = std::min(16.0, std::max(1.0, target));
@@ -218,7 +219,7 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW) 
     for (int w = 1; w <= sga::MAX_WAVES; ++w) {
         if (forced_waves > 0 && w != forced_waves) continue;
         const int cpw = (C + w - 1) / w;
-        if (cpw > sga::MAX_CPW) continue;
+        if (cpw > max_cpw) continue;
         if (w > C && w > 1) continue;
         const double pad = (double)(w * cpw - C) / C;
         double cost = 4.0 * pad + 0.05 * std::fabs(std::log2(w / target));
@@ -268,7 +269,9 @@ int ensure_packed(sga_engine *e) {
         // bit-plane geometry first; the int8 layout (energy / single-site kernels, non-LEAN
         // sweeps) shares its row length: 8 waves x (Wb * CPWb) chunks of 1024 int8
         int Wb, Cb;
-        choose_geometry(e->n, T2_ELEMS_PER_CHUNK, std::max(e->R, 1), e->tune_waves, Wb, Cb);
+        // at most 4 chunks per wave: a bit-plane chunk costs 8 VGPRs per ring slot
+        choose_geometry(e->n, T2_ELEMS_PER_CHUNK, std::max(e->R, 1), e->tune_waves, Wb, Cb,
+                        sga::T2_MAX_CPW);
         ld = (long long)Wb * Cb * T2_ELEMS_PER_CHUNK;
         W = 8;
         CPW = Wb * Cb;
@@ -781,7 +784,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             a.J = e->J_bits;
             a.plane_bytes = (long long)e->n * (e->ld / 8);
             a.diag = e->row_nnz;
-            le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::MAX_CPW ? 0 : e->cpw_t2, st);
+            le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2,
+                                            st);
         } else {
             le = sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
                                          e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
@@ -1314,7 +1318,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->n, e->n_models, e->use_t2 ? "t2" : (e->want_i8 ? "i8" : "f32"),
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
-                      (e->use_t2 ? e->cpw_t2 : e->cpw) > sga::MAX_CPW ? "(streaming)" : "", e->ld,
+                      (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
                       e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);

@@ -7,6 +7,7 @@
 namespace sga {
 
 constexpr int MAX_CPW = 10;       // coupling-row chunks a wave holds per buffer (dense)
+constexpr int T2_MAX_CPW = 4;     // same for the bit-plane form (a chunk is two planes = 8 VGPRs)
 constexpr int MAX_WAVES = 16;     // waves per replica workgroup
 constexpr int CSR_WAVES_PER_BLOCK = 4;
 

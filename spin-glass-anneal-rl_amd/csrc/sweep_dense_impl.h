@@ -305,51 +305,77 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         }
     };
 
-    const int nb = (n + 1) >> 1;
-    vec_t X[NBUF], Y[NBUF];
-    PairSource<LEAN> rng;
-    UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
-    load_row(X, cur.sA);
+    // Ring of NB row buffers: update g reads ring[g % NB]; its row was requested NB - 1 updates
+    // earlier (sites come from the counter RNG, not from the chain's state).  Measured at depths
+    // 2, 3 and 6 (profiles/r01_experiments.md): long rows are bandwidth bound and short rows are
+    // bound by the update chain itself (LDS round trips + issue rate of one wave per SIMD), not
+    // by the HBM round trip, so depth 2 -- the smallest code and register footprint -- is kept.
+#ifndef SGA_RING_NB
+#define SGA_RING_NB 2
+#endif
+    constexpr int NB = CPW == 0 ? 1 : SGA_RING_NB;
+    struct Slot {
+        vec_t row[NBUF];
+        int site;
+        float u, h, d;
+    };
+    Slot ring[NB];
     const bool need_d = arith32 || BITS;  // J_ii for the fp32 rule | row non-zero count (bits)
-    float hX = hvec[cur.sA], dX = need_d ? dvec[cur.sA] : 0.0f;
 
-    for (int k = 0; k < a.n_sweeps; ++k) {
-        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-        if (use_tab) {
-            __syncthreads();  // nobody still reads last sweep's table
-            for (int q = tid; q <= a.table_m; q += blockDim.x)
-                ptab[q] = expf_det((float)(-(double)(2 * q) / T));
-            __syncthreads();
+    PairSource<LEAN> rng;
+    UpdatePair pairP{0, 0, 2.0f, 2.0f};
+    int kP = 0, tP = 0;  // producer cursor: the next update whose row is requested
+    auto produce = [&](Slot &sl) {
+        // No early-out past the end of the launch: the last NB - 1 requests read rows nobody
+        // uses, but a conditional request makes the compiler drain vmcnt at every update.
+        const bool second = tP & 1;
+        if (!second) pairP = rng.get(a, r, kP, tP >> 1, true, lane);
+        // values first, then the select: a select between the two members' addresses would
+        // push the pair into scratch, and scratch loads drain vmcnt -- the whole prefetch ring
+        const int sA = pairP.sA, sB = pairP.sB;
+        const float uA = pairP.uA, uB = pairP.uB;
+        sl.site = second ? sB : sA;
+        sl.u = second ? uB : uA;
+        load_row(sl.row, sl.site);
+        sl.h = hvec[sl.site];
+        sl.d = need_d ? dvec[sl.site] : 0.0f;
+        if (++tP == n) {
+            tP = 0;
+            ++kP;
         }
-        for (int b = 0; b < nb; ++b) {
-            const bool last = (b + 1 == nb);
-            const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
-            const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
-            const bool hasB = (2 * b + 1) < n;
-            const int sY = hasB ? cur.sB : nxt.sA;
-            load_row(Y, sY);  // in flight while X is reduced
-            float hY = hvec[sY], dY = need_d ? dvec[sY] : 0.0f;
-            step(X, cur.sA, cur.uA, hX, dX, (long long)k * n + 2 * b);
-            if (hasB) {
-                load_row(X, nxt.sA);
-                hX = hvec[nxt.sA];
-                dX = need_d ? dvec[nxt.sA] : 0.0f;
-                step(Y, cur.sB, cur.uB, hY, dY, (long long)k * n + 2 * b + 1);
-            } else {  // odd n: the prefetched row is the next sweep's first
+    };
 #pragma unroll
-                for (int q = 0; q < NBUF; ++q) X[q] = Y[q];
-                hX = hY;
-                dX = dY;
+    for (int j = 0; j + 1 < NB; ++j) produce(ring[j]);
+
+    const long long total = (long long)a.n_sweeps * n;
+    int k = 0, t = 0;  // consumer cursor
+    for (long long g0 = 0; g0 < total; g0 += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (g0 + j >= total) break;  // wave-uniform
+            if (t == 0) {                // sweep start: temperature, accept table
+                T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+                if (use_tab) {
+                    __syncthreads();  // nobody still reads last sweep's table
+                    for (int q = tid; q <= a.table_m; q += blockDim.x)
+                        ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+                    __syncthreads();
+                }
             }
-            cur = nxt;
-        }
-        // sweep boundary: energy record and best tracking (annealing/gpu_annealer.py:151-153)
-        if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
-        if (E < bestE && !a.no_best) {
-            bestE = E;
-            __syncthreads();
-            store_spins(a.best_spins + (long long)r * a.sstride);
-            __syncthreads();
+            produce(ring[(j + NB - 1) % NB]);  // the buffer update g - 1 just released
+            step(ring[j].row, ring[j].site, ring[j].u, ring[j].h, ring[j].d, g0 + j);
+            if (++t == n) {
+                // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)
+                if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+                if (E < bestE && !a.no_best) {
+                    bestE = E;
+                    __syncthreads();
+                    store_spins(a.best_spins + (long long)r * a.sstride);
+                    __syncthreads();
+                }
+                t = 0;
+                ++k;
+            }
         }
     }
 
