@@ -170,6 +170,10 @@ def main():
                          "c4: 50k-spin scheduling penalties (CSR), 1024 replicas/GPU; "
                          "c5: 100-city TSP QUBO (CSR), 2048 replicas in 32 ladders")
     ap.add_argument("--spins", type=int, default=10000)
+    ap.add_argument("--cities", type=int, default=100,
+                    help="c5 only: TSP size (spins = cities^2; above 400 the spins are held as bits "
+                         "in LDS; 1000 = BASELINE configs[4] at full size, 32 GB of CSR, use with "
+                         "--replicas 256 = one GPU's share of the 2048)")
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0 = workload default)")
     ap.add_argument("--storage", default="f32", choices=["f32", "i8", "t2"])
     ap.add_argument("--exchange-interval", type=int, default=10)
@@ -218,14 +222,15 @@ def main():
                                        time_discretization=100, objective="total_time",
                                        penalty_weights={"assignment": 100.0, "capacity": 50.0})
             t_hot, t_cold, label = 500.0, 5.0, "C4: 50000-spin scheduling Ising (500 tasks x 100 slots)"
-        else:                   # BASELINE configs[4] at 100 cities: n = 10^4, degree ~ 4(n_c - 1)
+        else:                   # BASELINE configs[4]: n = cities^2, degree 4(cities - 1)
             rs = np.random.RandomState(5)
-            xy = rs.rand(100, 2) * 100.0
+            xy = rs.rand(a.cities, 2) * 100.0
             dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
-            bld = enc.tsp_ising(dmat, city_visit=200.0, position_fill=200.0)
+            bld = None
+            tsp = enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
             n_ladders, t_hot, t_cold = 32, 200.0, 2.0
-            label = "C5: 100-city TSP QUBO (10000 spins)"
-        n = bld.n
+            label = f"C5: {a.cities}-city TSP QUBO ({a.cities ** 2} spins)"
+        n = bld.n if bld is not None else a.cities ** 2
     Rg = R * world
     h = torch.zeros(n, device=dev)
     eng = sg.AnnealEngine(local_rank)
@@ -238,10 +243,20 @@ def main():
     elif a.workload == "c3":
         csr = make_sparse_instance(n, 16, 3)
         eng.set_csr(*csr, h)
-    else:
+    elif bld is not None:
         csr = bld.to_csr()
         h = torch.from_numpy(bld.fields()).to(dev)
         eng.set_csr(*csr, h)
+    else:  # rows written on the device (int64 extents); host copy only while it is small
+        h = tsp[3]
+        eng.set_csr(tsp[0], tsp[1], tsp[2], h)
+        nnz = int(tsp[1].numel())
+        if nnz <= 200_000_000:
+            csr = (tsp[0].cpu().numpy().astype(np.int32), tsp[1].cpu().numpy(), tsp[2].cpu().numpy())
+        else:
+            csr = (None, np.broadcast_to(np.int32(0), (nnz,)), None)  # length only
+        del tsp
+        torch.cuda.empty_cache()
     ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
                           slot_temps=ladder, n_ladders=n_ladders, dist=dist, device=comm_dev)
@@ -356,6 +371,8 @@ def main():
                 "note": "exact arithmetic, bit-identical chain to the fp32 layout" +
                         ("" if st == "i8" else "; 2 bits per coupling, popcount row sums "
                                                "(latency bound, not HBM bound)")}
+    if csr is not None and csr[0] is None:
+        a.no_cpu_baseline = True  # no host copy of an instance this large
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr,
                                            h=None if csr is None else h.cpu().numpy(), eng=eng)

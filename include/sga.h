@@ -97,6 +97,12 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 /* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]. */
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
                 const float *h, int n, int64_t nnz);
+/* Same with 64-bit row extents, for nnz >= 2^31 (BASELINE config 5 at 1000 cities: n = 10^6,
+ * nnz ~ 4e9; the reference's COO `couplings` tensor of core/ising_model.py:69-76 has no such
+ * limit).  Problems whose int8 spins do not fit LDS (n > ~160k) keep them as bits, up to
+ * n ~ 1.3e6; both cases are picked up automatically by sga_init_replicas. */
+int sga_set_csr64(sga_engine *e, const int64_t *rowptr, const int32_t *colidx, const float *val,
+                  const float *h, int n, int64_t nnz);
 
 /* ---- replicas ------------------------------------------------------------------------- */
 /* R_local replicas live on this engine; they are replicas [replica0, replica0+R_local) of a

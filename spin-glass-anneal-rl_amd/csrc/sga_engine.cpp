@@ -134,7 +134,9 @@ struct sga_engine {
     void *J_packed = nullptr;  // [n][ld] float | int8
     long long ld = 0;
     int waves = 0, cpw = 0;
-    int32_t *rowptr = nullptr, *colidx = nullptr;
+    int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while nnz < 2^31
+    long long *rowptr64 = nullptr;                  // always (energy / single-site kernels, big form)
+    bool big = false;  // CSR sweeps with bit spins in LDS + 64-bit extents (decided per replica set)
     float *val = nullptr;
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
@@ -177,6 +179,7 @@ struct sga_engine {
         dev_free(row_nnz);
         use_t2 = false;
         dev_free(rowptr);
+        dev_free(rowptr64);
         dev_free(colidx);
         dev_free(val);
         dev_free(h);
@@ -241,7 +244,7 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
 int recompute_energy_range(sga_engine *e, int r0, int count) {
     sga::EnergyArgs a{};
     a.J = e->J_packed;
-    a.rowptr = e->rowptr;
+    a.rowptr = e->rowptr64;
     a.colidx = e->colidx;
     a.val = e->val;
     a.h = e->h;
@@ -446,8 +449,12 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     return ensure_packed(e);
 }
 
-int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
-                const float *h, int n, int64_t nnz) {
+// CSR problem from 32- or 64-bit row extents (host or device pointers).  The structure is
+// checked on the device -- a bad extent or column would fault in the sweep kernels -- and the
+// same pass classifies the problem: integer valued (accept table, fp32-exact row sums),
+// symmetric with zero diagonal (dE of the rule == energy change).
+static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, const int32_t *colidx,
+                          const float *val, const float *h, int n, int64_t nnz) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (!rowptr || !h || n <= 0 || nnz < 0 || (nnz > 0 && (!colidx || !val)))
         return fail(SGA_ERR_INVALID, "bad CSR problem arguments");
@@ -459,9 +466,20 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
     e->n = n;
     e->n_models = 1;
     e->nnz = nnz;
-    HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * (size_t)(n + 1)));
-    HIPCHK(hipMemcpyAsync(e->rowptr, rowptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDefault,
-                          e->stream));
+    const size_t np1 = (size_t)n + 1;
+    const bool narrow_ok = nnz < (int64_t)INT32_MAX;
+    HIPCHK(hipMalloc(&e->rowptr64, sizeof(long long) * np1));
+    if (narrow_ok) HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * np1));
+    if (wide_extents) {
+        HIPCHK(hipMemcpyAsync(e->rowptr64, rowptr, sizeof(long long) * np1, hipMemcpyDefault, e->stream));
+    } else {
+        if (!narrow_ok) {
+            e->free_problem();
+            return fail(SGA_ERR_INVALID, "nnz >= 2^31 needs 64-bit row extents (sga_set_csr64)");
+        }
+        HIPCHK(hipMemcpyAsync(e->rowptr, rowptr, sizeof(int32_t) * np1, hipMemcpyDefault, e->stream));
+        HIPCHK(sga::launch_widen_rowptr(e->rowptr, e->rowptr64, (long long)np1, e->stream));
+    }
     const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
     HIPCHK(hipMalloc(&e->colidx, sizeof(int32_t) * nz));
     HIPCHK(hipMalloc(&e->val, sizeof(float) * nz));
@@ -472,78 +490,64 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
     HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)n));
     HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
     HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)n));
-    // validate the structure on the host copy of rowptr (cheap) -- a bad extent would fault
-    std::vector<int32_t> rp((size_t)n + 1);
-    HIPCHK(hipMemcpyAsync(rp.data(), e->rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost,
-                          e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (rp[0] != 0 || rp[n] != nnz) {
+
+    int *d_flags = nullptr;
+    int flags[sga::CSR_FLAG_COUNT] = {0};
+    HIPCHK(hipMalloc(&d_flags, sizeof(flags)));
+    auto read_flags = [&]() -> hipError_t {
+        hipError_t he = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, e->stream);
+        return he == hipSuccess ? hipStreamSynchronize(e->stream) : he;
+    };
+    auto bail = [&](int code, const char *msg) {
+        dev_free(d_flags);
         e->free_problem();
-        return fail(SGA_ERR_INVALID, "CSR rowptr does not span [0, nnz]");
+        return fail(code, msg);
+    };
+    hipError_t he = hipMemsetAsync(d_flags, 0, sizeof(flags), e->stream);
+    if (he == hipSuccess) he = sga::launch_csr_check_rowptr(e->rowptr64, n, nnz, d_flags, e->stream);
+    if (he == hipSuccess) he = read_flags();
+    if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    if (flags[sga::CSR_BAD_ROWPTR])
+        return bail(SGA_ERR_INVALID, "CSR rowptr is not monotone or does not span [0, nnz]");
+    if (wide_extents && narrow_ok)
+        HIPCHK(sga::launch_narrow_rowptr(e->rowptr64, e->rowptr, (long long)np1, e->stream));
+    he = sga::launch_csr_scan(e->rowptr64, e->colidx, e->val, e->h, n, d_flags, e->stream);
+    if (he == hipSuccess) he = read_flags();
+    if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    if (flags[sga::CSR_BAD_COLUMN]) return bail(SGA_ERR_INVALID, "CSR column index out of range");
+    // symmetric with zero diagonal?  Sorted rows: one binary search per entry; unsorted rows are
+    // compared by linear scans while that stays cheap, else treated as asymmetric (exact-energy
+    // mode: slower, never wrong)
+    const bool sorted = !flags[sga::CSR_UNSORTED];
+    const double avg_deg = (double)nnz / n;
+    if (sorted || (double)nnz * avg_deg <= 4.0e10) {
+        he = sga::launch_csr_symmetry(e->rowptr64, e->colidx, e->val, n, sorted, d_flags, e->stream);
+        if (he == hipSuccess) he = read_flags();
+        if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    } else {
+        flags[sga::CSR_ASYMMETRIC] = 1;
     }
-    for (int i = 0; i < n; ++i)
-        if (rp[i + 1] < rp[i]) {
-            e->free_problem();
-            return fail(SGA_ERR_INVALID, "CSR rowptr is not monotone");
-        }
-    if (nnz > 0) {
-        std::vector<int32_t> ci((size_t)nnz);
-        HIPCHK(hipMemcpy(ci.data(), e->colidx, sizeof(int32_t) * ci.size(), hipMemcpyDeviceToHost));
-        for (int32_t c : ci)
-            if (c < 0 || c >= n) {
-                e->free_problem();
-                return fail(SGA_ERR_INVALID, "CSR column index out of range");
-            }
-    }
-    HIPCHK(sga::launch_gather_diag_csr(e->rowptr, e->colidx, e->val, n, e->diag, e->stream));
+    dev_free(d_flags);
+    e->consistent_dE = !flags[sga::CSR_ASYMMETRIC] && !flags[sga::CSR_DIAGONAL];
     // integer-valued problem?  then dE takes at most M = max_i(sum_j |J_ij| + |h_i|) even values
+    float m;
+    std::memcpy(&m, &flags[sga::CSR_ROW_ABS_MAX], sizeof(m));
     e->table_m = 0;
-    {
-        std::vector<float> hv((size_t)nnz), hh((size_t)n);
-        if (nnz > 0) HIPCHK(hipMemcpy(hv.data(), e->val, sizeof(float) * hv.size(), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hh.data(), e->h, sizeof(float) * hh.size(), hipMemcpyDeviceToHost));
-        bool integral = true;
-        double m = 0.0;
-        for (int i = 0; i < n && integral; ++i) {
-            double row = std::fabs((double)hh[i]);
-            if (hh[i] != std::rint(hh[i])) integral = false;
-            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
-                if (hv[k] != std::rint(hv[k])) { integral = false; break; }
-                row += std::fabs((double)hv[k]);
-            }
-            m = std::max(m, row);
-        }
-        if (integral && m >= 1.0 && m < 16777216.0) e->table_m = (int)std::min(m, 2048.0);
-        // symmetric with zero diagonal?  (value of (i,j) must equal value of (j,i))
-        e->consistent_dE = true;
-        if (nnz > 0 && nnz <= 200000000) {
-            std::vector<int32_t> ci((size_t)nnz);
-            HIPCHK(hipMemcpy(ci.data(), e->colidx, sizeof(int32_t) * ci.size(), hipMemcpyDeviceToHost));
-            std::vector<std::pair<long long, float>> fwd((size_t)nnz), rev((size_t)nnz);
-            size_t q = 0;
-            for (int i = 0; i < n; ++i)
-                for (int32_t k = rp[i]; k < rp[i + 1]; ++k, ++q) {
-                    fwd[q] = {(long long)i * n + ci[k], hv[k]};
-                    rev[q] = {(long long)ci[k] * n + i, hv[k]};
-                    if (ci[k] == i && hv[k] != 0.0f) e->consistent_dE = false;
-                }
-            std::sort(fwd.begin(), fwd.end());
-            std::sort(rev.begin(), rev.end());
-            // duplicates are summed by the kernels; compare the merged entries
-            auto merged = [](std::vector<std::pair<long long, float>> &v) {
-                size_t w = 0;
-                for (size_t r = 0; r < v.size(); ++r) {
-                    if (w > 0 && v[w - 1].first == v[r].first) v[w - 1].second += v[r].second;
-                    else v[w++] = v[r];
-                }
-                v.resize(w);
-            };
-            merged(fwd);
-            merged(rev);
-            if (fwd != rev) e->consistent_dE = false;
-        }
-    }
+    if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f)
+        e->table_m = (int)std::min(m, 2048.0f);
+    HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, e->colidx, e->val, n, e->diag, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return SGA_OK;
+}
+
+int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                const float *h, int n, int64_t nnz) {
+    return set_csr_common(e, rowptr, false, colidx, val, h, n, nnz);
+}
+
+int sga_set_csr64(sga_engine *e, const int64_t *rowptr, const int32_t *colidx, const float *val,
+                  const float *h, int n, int64_t nnz) {
+    return set_csr_common(e, rowptr, true, colidx, val, h, n, nnz);
 }
 
 int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
@@ -570,17 +574,33 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         e->sstride = (int)e->ld;
     } else {
         e->sstride = (e->n + 15) / 16 * 16;
-        if (sga::csr_waves_per_block(e->sstride, 0) < 1)
-            return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
-        if (sga::csr_waves_per_block(e->sstride, e->table_m) < 1)
-            e->table_m = 0;  // no room for the probability table: general path
-        // Long rows AND too few replicas to give every SIMD a wave: deal each row to two waves
-        // (one replica per workgroup).  The kernel is issue bound, so with >= 2048 replicas the
-        // extra waves only repeat the per-update work (measured: C4, R = 1024: 1 / 2 / 4 / 8
-        // waves -> 2.98 / 3.69 / 3.67 / 3.34 e8 attempts/s; C5, R = 2048: 1.55 vs 1.19 e9).
+        // beyond the int8 LDS capacity (or the 32-bit extents): spins as bits, one replica per
+        // workgroup (sweep_csr.hip, BIG)
+        // (SGA_FORCE_CSR_BIG: parity tests run the small cases through the same form)
+        e->big = sga::csr_waves_per_block(e->sstride, 0) < 1 || !e->rowptr ||
+                 std::getenv("SGA_FORCE_CSR_BIG") != nullptr;
         const double deg = (double)e->nnz / e->n;
-        const int wpr = e->tune_waves > 0 ? e->tune_waves : ((deg >= 192.0 && R_local <= 1024) ? 2 : 1);
-        e->waves = std::min(wpr, 8);
+        if (e->big) {
+            e->sstride = (e->n + 127) / 128 * 128;
+            if (!sga::csr_big_fits(e->sstride, 0))
+                return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
+            if (!sga::csr_big_fits(e->sstride, e->table_m)) e->table_m = 0;
+            // one workgroup per CU at these sizes: deal a long row to as many waves as it can
+            // feed with a 64-entry slice each
+            // measured (profiles/r01_experiments.md): best where the 8 entries per lane requested
+            // ahead cover the row -- 500 cities (degree 1996): 4 waves, 1000 (3996): 8
+            const int wpr = e->tune_waves > 0 ? e->tune_waves : (int)std::ceil(deg / 512.0);
+            e->waves = std::max(1, std::min(wpr, 8));
+        } else {
+            if (sga::csr_waves_per_block(e->sstride, e->table_m) < 1)
+                e->table_m = 0;  // no room for the probability table: general path
+            // Long rows AND too few replicas to give every SIMD a wave: deal each row to two waves
+            // (one replica per workgroup).  The kernel is issue bound, so with >= 2048 replicas the
+            // extra waves only repeat the per-update work (measured: C4, R = 1024: 1 / 2 / 4 / 8
+            // waves -> 2.98 / 3.69 / 3.67 / 3.34 e8 attempts/s; C5, R = 2048: 1.55 vs 1.19 e9).
+            const int wpr = e->tune_waves > 0 ? e->tune_waves : ((deg >= 192.0 && R_local <= 1024) ? 2 : 1);
+            e->waves = std::min(wpr, 8);
+        }
         e->cpw = 0;
     }
     const size_t sb = (size_t)R_local * e->sstride;
@@ -731,6 +751,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         sga::SweepArgs a{};
         a.J = e->J_packed;
         a.rowptr = e->rowptr;
+        a.rowptr64 = e->rowptr64;
+        a.big = e->big ? 1 : 0;
         a.colidx = e->colidx;
         a.val = e->val;
         a.h = e->h;
@@ -860,7 +882,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         const long long model = e->n_models > 1 ? (e->replica0 + r) / (e->Rg / e->n_models) : 0;
         a.J = e->J_packed;
         a.model_offset_j = model * e->n * e->ld;
-        a.rowptr = e->rowptr;
+        a.rowptr = e->rowptr64;
         a.colidx = e->colidx;
         a.val = e->val;
         a.h = e->h + model * e->n;
@@ -1306,11 +1328,11 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (e->csr)
         std::snprintf(tmp, sizeof(tmp),
                       "csr n=%d nnz=%lld R=%d waves_per_replica=%d replicas_per_block=%d sstride=%d "
-                      "path=%s table_m=%d%s",
+                      "path=%s table_m=%d spins=%s",
                       e->n, e->nnz, e->R, e->waves,
-                      e->waves > 1 ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m), e->sstride,
-                      e->table_m > 0 ? "integer-fast" : "general", e->table_m,
-                      e->consistent_dE ? "" : " energy=recomputed-per-sweep");
+                      (e->waves > 1 || e->big) ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m),
+                      e->sstride, e->table_m > 0 ? "integer-fast" : "general", e->table_m,
+                      e->big ? "lds-bits" : "lds-int8");
     else
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "

@@ -16,7 +16,8 @@ constexpr int CSR_WAVES_PER_BLOCK = 4;
 struct SweepArgs {
     // couplings
     const void *J;           // dense: [n][ld] of float | int8, zero padded rows
-    const int32_t *rowptr;   // CSR
+    const int32_t *rowptr;   // CSR, nnz < 2^31 (null otherwise)
+    const long long *rowptr64;  // CSR, always present
     const int32_t *colidx;
     const float *val;
     const float *h;          // [n]
@@ -49,6 +50,7 @@ struct SweepArgs {
     long long model_stride_j;
     int no_best;  // 1: leave best tracking to the host-driven pass (asymmetric / diagonal J)
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
+    int big;      // CSR: spins held as bits in LDS, 64-bit row extents (n > ~160k or nnz >= 2^31)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -56,7 +58,8 @@ struct EnergyArgs {
     int reps_per_model, replica_base;  // many-model batches, as in SweepArgs
     long long model_stride_j;
     const void *J;
-    const int32_t *rowptr, *colidx;
+    const long long *rowptr;
+    const int32_t *colidx;
     const float *val;
     const float *h;
     const int8_t *spins;
@@ -88,6 +91,7 @@ hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long
                                float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
+bool csr_big_fits(int sstride, int table_m);         // spins as bits: one replica per workgroup
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
@@ -104,15 +108,33 @@ hipError_t launch_pad_spins(const int8_t *src, int n, int8_t *dst, int sstride, 
                             hipStream_t st);
 hipError_t launch_unpad_spins(const int8_t *src, int sstride, int8_t *dst, int n, int R,
                               hipStream_t st);
-hipError_t launch_gather_diag_csr(const int32_t *rowptr, const int32_t *colidx, const float *val,
+hipError_t launch_gather_diag_csr(const long long *rowptr, const int32_t *colidx, const float *val,
                                   int n, float *diag, hipStream_t st);
+// CSR row extents between their 32- and 64-bit forms ([n + 1] entries)
+hipError_t launch_widen_rowptr(const int32_t *src, long long *dst, long long count, hipStream_t st);
+hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long count, hipStream_t st);
+// CSR structure checks on the device.  flags (int[8], zeroed by the caller):
+//  [0] rowptr not monotone / not spanning [0, nnz]   [1] column out of range
+//  [2] some J or h not an integer                     [3] rows not strictly sorted by column
+//  [4] non-zero diagonal entry                        [5] J[i][j] != J[j][i]
+//  [6] bits of max_i(sum_j |J_ij| + |h_i|) as float
+enum { CSR_BAD_ROWPTR = 0, CSR_BAD_COLUMN, CSR_NOT_INTEGRAL, CSR_UNSORTED, CSR_DIAGONAL,
+       CSR_ASYMMETRIC, CSR_ROW_ABS_MAX, CSR_FLAG_COUNT = 8 };
+hipError_t launch_csr_check_rowptr(const long long *rowptr, int n, long long nnz, int *flags,
+                                   hipStream_t st);
+hipError_t launch_csr_scan(const long long *rowptr, const int32_t *colidx, const float *val,
+                           const float *h, int n, int *flags, hipStream_t st);
+// sorted = rows strictly sorted by column (binary search); else linear scans of both rows
+hipError_t launch_csr_symmetry(const long long *rowptr, const int32_t *colidx, const float *val,
+                               int n, bool sorted, int *flags, hipStream_t st);
 hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
                             int8_t *best_spins, int sstride, int R, hipStream_t st);
 
 // single-site operators (IsingModel.get_local_field / flip_spin, SpinDynamics.single_spin_update)
 struct PointArgs {
     const void *J;
-    const int32_t *rowptr, *colidx;
+    const long long *rowptr;
+    const int32_t *colidx;
     const float *val;
     const float *h, *diag;
     int8_t *spins;       // the replica's row [sstride]

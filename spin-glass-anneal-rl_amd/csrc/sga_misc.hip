@@ -1,5 +1,7 @@
 // sga_misc.hip -- the kernels around the sweep: coupling repack, spin init, full energy
 // evaluation, replica exchange.
+#include <algorithm>
+
 #include "sweep_common.h"
 
 namespace sga {
@@ -169,19 +171,146 @@ hipError_t launch_update_best(const double *energy, const int8_t *spins, double 
     return hipGetLastError();
 }
 
-__global__ void gather_diag_csr_kernel(const int32_t *rowptr, const int32_t *colidx,
+__global__ void gather_diag_csr_kernel(const long long *rowptr, const int32_t *colidx,
                                        const float *val, int n, float *diag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float d = 0.0f;
-    for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+    for (long long j = rowptr[i]; j < rowptr[i + 1]; ++j)
         if (colidx[j] == i) d += val[j];
     diag[i] = d;
 }
-hipError_t launch_gather_diag_csr(const int32_t *rowptr, const int32_t *colidx, const float *val,
+hipError_t launch_gather_diag_csr(const long long *rowptr, const int32_t *colidx, const float *val,
                                   int n, float *diag, hipStream_t st) {
     hipLaunchKernelGGL(gather_diag_csr_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowptr,
                        colidx, val, n, diag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR structure: row extents in both widths, validation without a round trip of the entries
+// to the host (4e9 entries at the 1000-city TSP instance).
+// ---------------------------------------------------------------------------------------
+__global__ void widen_rowptr_kernel(const int32_t *src, long long *dst, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+__global__ void narrow_rowptr_kernel(const long long *src, int32_t *dst, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = (int32_t)src[i];
+}
+hipError_t launch_widen_rowptr(const int32_t *src, long long *dst, long long count, hipStream_t st) {
+    hipLaunchKernelGGL(widen_rowptr_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                       src, dst, count);
+    return hipGetLastError();
+}
+hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long count, hipStream_t st) {
+    hipLaunchKernelGGL(narrow_rowptr_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                       src, dst, count);
+    return hipGetLastError();
+}
+
+__global__ void csr_check_rowptr_kernel(const long long *rowptr, int n, long long nnz, int *flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    bool bad = false;
+    if (i == 0) bad = rowptr[0] != 0 || rowptr[n] != nnz;
+    if (i < n) bad = bad || rowptr[i + 1] < rowptr[i] || rowptr[i] < 0 || rowptr[i + 1] > nnz;
+    if (bad) flags[CSR_BAD_ROWPTR] = 1;
+}
+hipError_t launch_csr_check_rowptr(const long long *rowptr, int n, long long nnz, int *flags,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(csr_check_rowptr_kernel, dim3(n / 256 + 1), dim3(256), 0, st, rowptr, n, nnz,
+                       flags);
+    return hipGetLastError();
+}
+
+// one wave per row (grid-stride): ranges, integrality, ordering, diagonal, sum of |entries|
+__global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, const int32_t *colidx,
+                                                       const float *val, const float *h, int n,
+                                                       int *flags) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+    int bad_col = 0, non_int = 0, unsorted = 0, diag = 0;
+    float row_max = 0.0f;
+    for (int i = wave; i < n; i += n_waves) {
+        const long long beg = rowptr[i], end = rowptr[i + 1];
+        double acc = 0.0;
+        for (long long j = beg + lane; j < end; j += 64) {
+            const int c = colidx[j];
+            const float v = val[j];
+            if (c < 0 || c >= n) bad_col = 1;
+            if (v != rintf(v)) non_int = 1;
+            if (c == i && v != 0.0f) diag = 1;
+            if (j > beg && colidx[j - 1] >= c) unsorted = 1;
+            acc += (double)fabsf(v);
+        }
+        const float hi = h[i];
+        if (hi != rintf(hi)) non_int = 1;
+        // an upper bound is all the table needs; fp32 rounds it up or down by < 1 ulp
+        const float tot = (float)(wave_sum(acc) + (double)fabsf(hi));
+        row_max = fmaxf(row_max, tot);
+    }
+    if (bad_col) flags[CSR_BAD_COLUMN] = 1;
+    if (non_int) flags[CSR_NOT_INTEGRAL] = 1;
+    if (unsorted) flags[CSR_UNSORTED] = 1;
+    if (diag) flags[CSR_DIAGONAL] = 1;
+    if (lane == 0) atomicMax(&flags[CSR_ROW_ABS_MAX], __float_as_int(row_max));  // >= 0: bits order
+}
+hipError_t launch_csr_scan(const long long *rowptr, const int32_t *colidx, const float *val,
+                           const float *h, int n, int *flags, hipStream_t st) {
+    const int blocks = (int)std::min<long long>(((long long)n + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(blocks), dim3(256), 0, st, rowptr, colidx, val, h, n,
+                       flags);
+    return hipGetLastError();
+}
+
+// J[i][j] == J[j][i] for every stored entry (duplicates count summed when rows are unsorted)
+template <bool SORTED>
+__global__ void __launch_bounds__(256) csr_symmetry_kernel(const long long *rowptr,
+                                                           const int32_t *colidx, const float *val,
+                                                           int n, int *flags) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+    int asym = 0;
+    for (int i = wave; i < n; i += n_waves) {
+        const long long beg = rowptr[i], end = rowptr[i + 1];
+        for (long long j = beg + lane; j < end; j += 64) {
+            const int c = colidx[j];
+            if (c == i) continue;
+            const long long cb = rowptr[c], ce = rowptr[c + 1];
+            if constexpr (SORTED) {
+                long long lo = cb, hi = ce;  // first entry of row c with column >= i
+                while (lo < hi) {
+                    const long long mid = (lo + hi) >> 1;
+                    if (colidx[mid] < i) lo = mid + 1;
+                    else hi = mid;
+                }
+                const float other = (lo < ce && colidx[lo] == i) ? val[lo] : 0.0f;
+                if (other != val[j]) asym = 1;
+            } else {
+                float mine = 0.0f, other = 0.0f;
+                for (long long q = beg; q < end; ++q)
+                    if (colidx[q] == c) mine += val[q];
+                for (long long q = cb; q < ce; ++q)
+                    if (colidx[q] == i) other += val[q];
+                if (mine != other) asym = 1;
+            }
+        }
+    }
+    if (asym) flags[CSR_ASYMMETRIC] = 1;
+}
+hipError_t launch_csr_symmetry(const long long *rowptr, const int32_t *colidx, const float *val,
+                               int n, bool sorted, int *flags, hipStream_t st) {
+    const int blocks = (int)std::min<long long>(((long long)n + 3) / 4, 256 * 32);
+    if (sorted)
+        hipLaunchKernelGGL(csr_symmetry_kernel<true>, dim3(blocks), dim3(256), 0, st, rowptr, colidx,
+                           val, n, flags);
+    else
+        hipLaunchKernelGGL(csr_symmetry_kernel<false>, dim3(blocks), dim3(256), 0, st, rowptr,
+                           colidx, val, n, flags);
     return hipGetLastError();
 }
 
@@ -345,23 +474,26 @@ hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st
     return hipGetLastError();
 }
 
+// LDS_SPINS = false: spins gathered from HBM / L2 (problems beyond the int8 LDS capacity)
+template <bool LDS_SPINS>
 __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int8_t *s = reinterpret_cast<int8_t *>(smem);
-    double *red = reinterpret_cast<double *>(smem + a.sstride);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = blockIdx.x;
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
-        int4 *dst = reinterpret_cast<int4 *>(s);
+    const int8_t *s = a.spins + (long long)r * a.sstride;
+    double *red = reinterpret_cast<double *>(smem + (LDS_SPINS ? a.sstride : 0));
+    if constexpr (LDS_SPINS) {
+        const int4 *src = reinterpret_cast<const int4 *>(s);
+        int4 *dst = reinterpret_cast<int4 *>(smem);
         for (int i = tid; i < a.sstride / 16; i += blockDim.x) dst[i] = src[i];
+        s = reinterpret_cast<const int8_t *>(smem);
+        __syncthreads();
     }
-    __syncthreads();
     double e_acc = 0.0, h_acc = 0.0;
     for (int i = w; i < a.n; i += 4) {
         double acc = 0.0;
-        for (int j = a.rowptr[i] + lane; j < a.rowptr[i + 1]; j += 64)
+        for (long long j = a.rowptr[i] + lane; j < a.rowptr[i + 1]; j += 64)
             acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
         const float mv_i = (float)wave_sum(acc);
         const double si = (double)s[i];
@@ -382,12 +514,16 @@ __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
 
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
     const size_t lds = (size_t)a.sstride + 64;
+    if (lds > 160 * 1024 - 256) {
+        hipLaunchKernelGGL(energy_csr_kernel<false>, dim3(a.R), dim3(256), 64, st, a);
+        return hipGetLastError();
+    }
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(energy_csr_kernel, dim3(a.R), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(energy_csr_kernel<true>, dim3(a.R), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -468,7 +604,7 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
         const int site = a.sites[k];
         double acc = 0.0;
         if constexpr (CSR) {
-            for (int j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
+            for (long long j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
                 acc += (double)(a.val[j] * (float)a.spins[a.colidx[j]]);
         } else {
             const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ld;

@@ -155,4 +155,41 @@ __device__ __forceinline__ bool metropolis_accept(int rule, int arith, float dot
     return u < p;
 }
 
+// Replica spins between the int8 HBM layout ([sstride], +-1, pad = 0) and one bit per spin in
+// LDS (1 = spin down).  `first`/`step`: this thread's share of the loop.  sstride % 32 == 0.
+__device__ inline void spins_to_bits(const int8_t *src_row, unsigned int *bits, int sstride,
+                                     int first, int step) {
+    const int4 *src = reinterpret_cast<const int4 *>(src_row);
+    for (int i = first; i < sstride / 32; i += step) {
+        const int4 lo = src[2 * i], hi = src[2 * i + 1];
+        const int wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned int b = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)  // sign bit of each of the 4 bytes of a dword
+            b |= (((unsigned)wds[q] >> 7) & 1u) << (4 * q) | (((unsigned)wds[q] >> 15) & 1u) << (4 * q + 1) |
+                 (((unsigned)wds[q] >> 23) & 1u) << (4 * q + 2) | (((unsigned)wds[q] >> 31) & 1u) << (4 * q + 3);
+        bits[i] = b;
+    }
+}
+__device__ inline void bits_to_spins(const unsigned int *bits, int8_t *dst_row, int sstride, int n,
+                                     int first, int step) {
+    int4 *dst = reinterpret_cast<int4 *>(dst_row);
+    for (int i = first; i < sstride / 16; i += step) {
+        const unsigned int half = (bits[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        int out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned int v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = 16 * i + 4 * q + b;
+                const unsigned int byte = j < n ? (((half >> (4 * q + b)) & 1u) ? 0xFFu : 0x01u) : 0u;
+                v |= byte << (8 * b);
+            }
+            out[q] = (int)v;
+        }
+        dst[i] = make_int4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 }  // namespace sga

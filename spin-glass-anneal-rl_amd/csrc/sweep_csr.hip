@@ -25,16 +25,29 @@
 namespace sga {
 
 constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight together
-constexpr int CSR_MAX_WIDE = 8;  // most waves one replica's row is dealt to
+#ifndef CSR_WIDE_ROWS_AHEAD
+#define CSR_WIDE_ROWS_AHEAD 2    // wide forms: rows requested this many updates before their reduction
+#endif
+constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (16 measured slower)
 
 // WIDE = several waves per replica (long rows, few replicas): one replica per workgroup, the
 // row's entries are dealt to the waves in 64-entry slices, the per-wave sums meet in LDS with
 // one barrier per update (double-buffered slots, as in the dense kernel).  Every wave applies
 // an accepted flip to the shared spin byte itself before its next gather (same value from all
 // waves), so no second barrier is needed.
-template <bool FAST, bool LEAN, bool WIDE>
+//
+// BIG (a WIDE form) = problems beyond the int8 LDS capacity (n > ~160k; BASELINE config 5 at 1000
+// cities is n = 10^6) or with nnz >= 2^31: the replica's spins sit in LDS as one bit each (1 =
+// spin down; 125 KB at n = 10^6), row extents are 64-bit, flips are idempotent LDS atomics
+// (or / and-not) so that every wave can still apply them itself.
+template <bool FAST, bool LEAN, bool WIDE, bool BIG>
 __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
     sweep_csr_kernel(const SweepArgs a) {
+    static_assert(!BIG || WIDE, "the bit-spin form is one replica per workgroup");
+    using rp_t = typename std::conditional<BIG, long long, int>::type;
+    const rp_t *rowptr = nullptr;
+    if constexpr (BIG) rowptr = a.rowptr64;
+    else rowptr = a.rowptr;
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -49,71 +62,102 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     const int me = WIDE ? 0 : w;
     const int stride_lanes = WIDE ? 64 * nw : 64;       // entries between a lane's row elements
     const int first_lane = WIDE ? w * 64 + lane : lane; // this lane's first entry of a row
-    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)me * a.sstride;
-    float *ptab = reinterpret_cast<float *>(smem + (long long)slots * a.sstride) +
+    const long long sbytes = BIG ? a.sstride / 8 : a.sstride;  // LDS bytes of one replica's spins
+    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)me * sbytes;
+    unsigned int *sbits = reinterpret_cast<unsigned int *>(smem);
+    float *ptab = reinterpret_cast<float *>(smem + (long long)slots * sbytes) +
                   (long long)me * (a.table_m + 1);
-    double *part = reinterpret_cast<double *>(smem + (long long)slots * a.sstride +
+    double *part = reinterpret_cast<double *>(smem + (long long)slots * sbytes +
                                               sizeof(float) * ((a.table_m + 2) & ~1) * slots);
     int pp = 0;
-    {
+    const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
+    if constexpr (BIG) {
+        spins_to_bits(a.spins + (long long)r * a.sstride, sbits, a.sstride, cfirst, cstep);
+    } else {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
         int4 *dst = reinterpret_cast<int4 *>(s);
-        const int step = WIDE ? (int)blockDim.x : 64, first = WIDE ? tid : lane;
-        for (int i = first; i < a.sstride / 16; i += step) dst[i] = src[i];
+        for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
     }
     if constexpr (WIDE) __syncthreads();
+    // spin of column c as a float factor / as an int
+    auto spin_f = [&](int c) -> float {
+        if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1.0f : 1.0f;
+        else return (float)s[c];
+    };
+    auto spin_i = [&](int c) -> int {
+        if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1 : 1;
+        else return s[c];
+    };
+    auto store_spins = [&](int8_t *dst_row) {
+        if constexpr (BIG) {
+            bits_to_spins(sbits, dst_row, a.sstride, n, cfirst, cstep);
+        } else {
+            int4 *dst = reinterpret_cast<int4 *>(dst_row);
+            const int4 *src = reinterpret_cast<const int4 *>(s);
+            for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
+        }
+    };
     const bool arith32 = arith == SGA_ARITH_F32;
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
 
     struct Extent {  // what is indexed by the site alone
-        int beg, end;
+        rp_t beg, end;
         float h, d;
     };
-    struct Head {  // first 64 stored entries of the row, one per lane
-        int col;
-        float val;
+    // The entries of a row requested one update ahead: its first 64 (one per lane) in the narrow
+    // form, where that is the whole row at degree ~32; HEAD per lane in the wide forms, so that a
+    // row of up to HEAD * 64 * waves entries is in flight while the previous update is reduced.
+    constexpr int HEAD = WIDE ? TAIL_UNROLL : 1;
+    struct Head {
+        int col[HEAD];
+        float val[HEAD];
     };
     auto load_extent = [&](int site) {
         Extent o;
-        o.beg = a.rowptr[site];
-        o.end = a.rowptr[site + 1];
+        o.beg = rowptr[site];
+        o.end = rowptr[site + 1];
         o.h = a.h[site];
         o.d = arith32 ? a.diag[site] : 0.0f;
         return o;
     };
     auto load_head = [&](const Extent &x) {
         Head o;
-        const int j = x.beg + first_lane;
-        const bool in = j < x.end;
-        o.col = in ? a.colidx[j] : 0;
-        o.val = in ? a.val[j] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < HEAD; ++q) {
+            const rp_t j = x.beg + first_lane + (rp_t)stride_lanes * q;
+            const bool in = j < x.end;
+            o.col[q] = in ? a.colidx[j] : 0;
+            o.val[q] = in ? a.val[j] : 0.0f;
+        }
         return o;
     };
 
     double T = 1.0;
     auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
         // read s_i before any wave can have applied THIS update's flip (WIDE: before the barrier)
-        const int si = s[site];
+        const int si = spin_i(site);
         // J[site,:].s over the stored entries; products val * (+-1) are exact
         float dot;
         if constexpr (FAST) {
-            float acc = hd.val * (float)s[hd.col];
-            // long rows: issue eight (colidx, val) wave-loads before the first gather so the
+            float acc = hd.val[0] * spin_f(hd.col[0]);
+#pragma unroll
+            for (int q = 1; q < HEAD; ++q) acc += hd.val[q] * spin_f(hd.col[q]);
+            // longer rows: issue eight (colidx, val) wave-loads before the first gather so the
             // round trips overlap instead of serialising (degree ~600 at C4)
-            for (int j0 = x.beg + stride_lanes + first_lane; j0 < x.end;
+            for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
                  j0 += stride_lanes * TAIL_UNROLL) {
                 int c[TAIL_UNROLL];
                 float v[TAIL_UNROLL];
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const int j = j0 + stride_lanes * q;
+                    const rp_t j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
                     c[q] = in ? a.colidx[j] : 0;
                     v[q] = in ? a.val[j] : 0.0f;
                 }
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * (float)s[c[q]];
+                for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * spin_f(c[q]);
             }
             dot = wave_sum(acc);
             if constexpr (WIDE) {
@@ -126,20 +170,22 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 pp ^= 1;
             }
         } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
-            double acc = (double)(hd.val * (float)s[hd.col]);
-            for (int j0 = x.beg + stride_lanes + first_lane; j0 < x.end;
+            double acc = (double)(hd.val[0] * spin_f(hd.col[0]));
+#pragma unroll
+            for (int q = 1; q < HEAD; ++q) acc += (double)(hd.val[q] * spin_f(hd.col[q]));
+            for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
                  j0 += stride_lanes * TAIL_UNROLL) {
                 int c[TAIL_UNROLL];
                 float v[TAIL_UNROLL];
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const int j = j0 + stride_lanes * q;
+                    const rp_t j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
                     c[q] = in ? a.colidx[j] : 0;
                     v[q] = in ? a.val[j] : 0.0f;
                 }
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * (float)s[c[q]]);
+                for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * spin_f(c[q]));
             }
             double tot = wave_sum(acc);
             if constexpr (WIDE) {
@@ -168,7 +214,14 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         if (flip) {
             E += dE;
             ++nacc;
-            if (lane == 0) s[site] = (int8_t)(-si);
+            if (lane == 0) {
+                if constexpr (BIG) {  // the same idempotent operation from every wave
+                    if (si > 0) atomicOr(&sbits[site >> 5], 1u << (site & 31));
+                    else atomicAnd(&sbits[site >> 5], ~(1u << (site & 31)));
+                } else {
+                    s[site] = (int8_t)(-si);
+                }
+            }
         }
         if constexpr (!LEAN) {
             if (lane == 0) {
@@ -181,13 +234,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         }
     };
 
-    const int nb = (n + 1) >> 1;
-    PairSource<LEAN> rng;
-    UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
-    Extent xA = load_extent(cur.sA), xB = load_extent(cur.sB);
-    Head hA = load_head(xA);
-
-    for (int k = 0; k < a.n_sweeps; ++k) {
+    auto sweep_start = [&](int k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         if constexpr (FAST) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
             if constexpr (WIDE) __syncthreads();  // nobody still reads last sweep's table
@@ -195,41 +242,100 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 ptab[q] = expf_det((float)(-(double)(2 * q) / T));
             if constexpr (WIDE) __syncthreads();
         }
-        for (int b = 0; b < nb; ++b) {
-            const bool last = (b + 1 == nb);
-            const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
-            const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
-            const bool hasB = (2 * b + 1) < n;
-            const Extent nA = load_extent(nxt.sA), nB = load_extent(nxt.sB);  // a pair ahead
-            Head hB{0, 0.0f};
-            if (hasB) hB = load_head(xB);  // in flight while A is reduced
-            update(cur.sA, cur.uA, xA, hA, (long long)k * n + 2 * b);
-            const Head hN = load_head(nA);  // in flight while B is reduced
-            if (hasB) update(cur.sB, cur.uB, xB, hB, (long long)k * n + 2 * b + 1);
-            cur = nxt;
-            xA = nA;
-            xB = nB;
-            hA = hN;
-        }
-        const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
+    };
+    auto sweep_end = [&](int k) {
         if (lane == 0 && (!WIDE || w == 0) && a.energy_trace)
             a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
             if constexpr (WIDE) __syncthreads();  // every wave has applied the last flip
-            int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
-            const int4 *src = reinterpret_cast<const int4 *>(s);
-            for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
+            store_spins(a.best_spins + (long long)r * a.sstride);
             if constexpr (WIDE) __syncthreads();
+        }
+    };
+
+    PairSource<LEAN> rng;
+    if constexpr (BIG && LEAN) {
+        // HBM-resident structures (C5 at 500 / 1000 cities: 4 / 32 GB): an update lasts ~2 us
+        // (row gather + reduce + barrier), about one loaded HBM round trip, so rows are requested
+        // NH - 1 = 2 updates ahead and their extents NB - 1 updates ahead (two rings, NB a
+        // multiple of NH so that every index is a compile-time constant after unrolling).  The
+        // extent of a row has to be back before its entries can be requested; vmcnt retires in
+        // order, so the gap NB - NH keeps that wait from draining the rows requested in between.
+        // +7 % there; the cache-resident C4 (240 MB) loses 9 % to the same loop and keeps the
+        // pair loop below, as do the traced / replayed variants.
+        constexpr int NH = CSR_WIDE_ROWS_AHEAD + 1, NB = 2 * NH;
+        struct Pending {
+            int site;
+            float u;
+            Extent x;
+        };
+        Pending er[NB];
+        Head hr[NH];
+        UpdatePair pairP{0, 0, 2.0f, 2.0f};
+        int kP = 0, tP = 0;  // producer cursor: next update whose extent is requested
+        auto request_extent = [&](Pending &sl) {
+            const bool second = tP & 1;
+            if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
+            const int sA = pairP.sA, sB = pairP.sB;  // values first, then select (no scratch)
+            const float uA = pairP.uA, uB = pairP.uB;
+            sl.site = second ? sB : sA;
+            sl.u = second ? uB : uA;
+            sl.x = load_extent(sl.site);
+            if (++tP == n) {
+                tP = 0;
+                ++kP;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j + 1 < NB; ++j) request_extent(er[j]);
+#pragma unroll
+        for (int j = 0; j + 1 < NH; ++j) hr[j] = load_head(er[j].x);
+        const long long total = (long long)a.n_sweeps * n;
+        int k = 0, t = 0;
+        for (long long g0 = 0; g0 < total; g0 += NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (g0 + j >= total) break;  // workgroup-uniform
+                if (t == 0) sweep_start(k);
+                request_extent(er[(j + NB - 1) % NB]);
+                hr[(j + NH - 1) % NH] = load_head(er[(j + NH - 1) % NB].x);
+                update(er[j].site, er[j].u, er[j].x, hr[j % NH], g0 + j);
+                if (++t == n) {
+                    sweep_end(k);
+                    t = 0;
+                    ++k;
+                }
+            }
+        }
+    } else {
+        const int nb = (n + 1) >> 1;
+        UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
+        Extent xA = load_extent(cur.sA), xB = load_extent(cur.sB);
+        Head hA = load_head(xA);
+        for (int k = 0; k < a.n_sweeps; ++k) {
+            sweep_start(k);
+            for (int b = 0; b < nb; ++b) {
+                const bool last = (b + 1 == nb);
+                const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
+                const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
+                const bool hasB = (2 * b + 1) < n;
+                const Extent nA = load_extent(nxt.sA), nB = load_extent(nxt.sB);  // a pair ahead
+                Head hB{};
+                if (hasB) hB = load_head(xB);  // in flight while A is reduced
+                update(cur.sA, cur.uA, xA, hA, (long long)k * n + 2 * b);
+                const Head hN = load_head(nA);  // in flight while B is reduced
+                if (hasB) update(cur.sB, cur.uB, xB, hB, (long long)k * n + 2 * b + 1);
+                cur = nxt;
+                xA = nA;
+                xB = nB;
+                hA = hN;
+            }
+            sweep_end(k);
         }
     }
     if constexpr (WIDE) __syncthreads();
-    {
-        int4 *dst = reinterpret_cast<int4 *>(a.spins + (long long)r * a.sstride);
-        const int4 *src = reinterpret_cast<const int4 *>(s);
-        const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
-        for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
-    }
+    store_spins(a.spins + (long long)r * a.sstride);
     if (lane == 0 && (!WIDE || w == 0)) {
         a.energy[r] = E;
         a.best_energy[r] = bestE;
@@ -237,23 +343,31 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     }
 }
 
-static size_t csr_lds_per_replica(int sstride, int table_m) {  // spins + accept table (>= 8 B)
-    return (size_t)sstride + sizeof(float) * (size_t)((table_m + 2) & ~1);
+static size_t csr_lds_per_replica(int sstride, int table_m, bool big = false) {
+    // spins (bytes | bits) + accept table (>= 8 B)
+    return (size_t)(big ? sstride / 8 : sstride) + sizeof(float) * (size_t)((table_m + 2) & ~1);
 }
 
+constexpr size_t CSR_LDS_BUDGET = 160 * 1024 - 256;
+
 int csr_waves_per_block(int sstride, int table_m) {
-    const int wpb = (int)((160 * 1024 - 256) / csr_lds_per_replica(sstride, table_m));
+    const int wpb = (int)(CSR_LDS_BUDGET / csr_lds_per_replica(sstride, table_m));
     return wpb > CSR_WAVES_PER_BLOCK ? CSR_WAVES_PER_BLOCK : wpb;  // 0: does not fit
 }
 
-template <bool WIDE>
+bool csr_big_fits(int sstride, int table_m) {
+    // 128 spins = 16 B of bits: keeps the table and the partial-sum slots behind them aligned
+    return sstride % 128 == 0 && csr_lds_per_replica(sstride, table_m, true) <= CSR_LDS_BUDGET;
+}
+
+template <bool WIDE, bool BIG>
 static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
     const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a);
     const int slots = WIDE ? 1 : waves;
-    const size_t lds = csr_lds_per_replica(a.sstride, a.table_m) * slots +
+    const size_t lds = csr_lds_per_replica(a.sstride, a.table_m, BIG) * slots +
                        2 * CSR_MAX_WIDE * sizeof(double);
-    auto kern = fast ? (lean ? sweep_csr_kernel<true, true, WIDE> : sweep_csr_kernel<true, false, WIDE>)
-                     : (lean ? sweep_csr_kernel<false, true, WIDE> : sweep_csr_kernel<false, false, WIDE>);
+    auto kern = fast ? (lean ? sweep_csr_kernel<true, true, WIDE, BIG> : sweep_csr_kernel<true, false, WIDE, BIG>)
+                     : (lean ? sweep_csr_kernel<false, true, WIDE, BIG> : sweep_csr_kernel<false, false, WIDE, BIG>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -265,16 +379,24 @@ static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
 }
 
 // waves_per_replica == 1: several replicas per workgroup (as many as fit LDS), no barriers;
-// > 1: one replica per workgroup, its rows dealt to that many waves.
+// > 1: one replica per workgroup, its rows dealt to that many waves.  a.big: the bit-spin form,
+// always one replica per workgroup (1..CSR_MAX_WIDE waves).
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st) {
+    if (a.big) {
+        if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !a.rowptr64 ||
+            !csr_big_fits(a.sstride, a.table_m))
+            return hipErrorInvalidValue;
+        return launch_csr<true, true>(a, waves_per_replica, st);
+    }
+    if (!a.rowptr) return hipErrorInvalidValue;
     if (waves_per_replica > 1) {
         if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1)
             return hipErrorInvalidValue;
-        return launch_csr<true>(a, waves_per_replica, st);
+        return launch_csr<true, false>(a, waves_per_replica, st);
     }
     const int wpb = csr_waves_per_block(a.sstride, a.table_m);
     if (wpb < 1) return hipErrorInvalidValue;
-    return launch_csr<false>(a, wpb, st);
+    return launch_csr<false, false>(a, wpb, st);
 }
 
 }  // namespace sga

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         // No early-out past the end of the launch: the last NB - 1 requests read rows nobody
         // uses, but a conditional request makes the compiler drain vmcnt at every update.
         const bool second = tP & 1;
-        if (!second) pairP = rng.get(a, r, kP, tP >> 1, true, lane);
+        if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
         // values first, then the select: a select between the two members' addresses would
         // push the pair into scratch, and scratch loads drain vmcnt -- the whole prefetch ring
         const int sA = pairP.sA, sB = pairP.sB;

@@ -207,6 +207,70 @@ def tsp_ising(distance_matrix, city_visit: float = 100.0, position_fill: float =
     return b
 
 
+def tsp_csr(distance_matrix, city_visit: float = 100.0, position_fill: float = 100.0,
+            auto_scale: bool = True, device=None):
+    """The CSR couplings of `tsp_ising(..., convention="physical")` written row by row from
+    the structure of the encoding instead of assembled from COO triples: every spin
+    (city c, position p) has exactly 4(n-1) neighbours -- the other positions of its city, and
+    for every other city the positions p-1, p, p+1 -- so rowptr is an arithmetic progression
+    and each city's block of rows is three tensor writes.  1000 cities (BASELINE config 5:
+    10^6 spins, 4e9 entries, 32 GB) is ~1000 small tensor programs on the device, where the
+    triple route needs hundreds of GB of host memory.
+
+    Returns torch tensors on `device` (default: CPU): rowptr int64 [n^2+1], colidx int32,
+    val float32 (columns ascending within a row), h float32 [n^2], and the constant with
+    H(s) + constant == tour length + penalties.  Identical to the builder's output
+    (tests/test_encoders.py)."""
+    import torch
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    d = torch.as_tensor(np.asarray(distance_matrix, np.float64), device=dev)
+    n = d.shape[0]
+    if d.shape != (n, n) or n < 3:
+        raise ValueError("distance_matrix must be square with at least 3 cities")
+    if auto_scale and n > 50:  # routing.py:237-241
+        f = np.sqrt(n / 50.0)
+        city_visit, position_fill = city_visit * f, position_fill * f
+    deg = 4 * (n - 1)
+    N = n * n
+    rowptr = torch.arange(N + 1, dtype=torch.int64, device=dev) * deg
+    colidx = torch.empty(N * deg, dtype=torch.int32, device=dev)
+    val = torch.empty(N * deg, dtype=torch.float32, device=dev)
+    p = torch.arange(n, device=dev)
+    # the three positions coupled to position p in another city, ascending, and what each is:
+    # 0 = p-1 (that city precedes: d[c', c]), 1 = p (position one-hot), 2 = p+1 (d[c, c'])
+    trip = torch.stack([(p - 1) % n, p, (p + 1) % n], 1)              # [n, 3]
+    trip, kind = torch.sort(trip, 1)
+    # other positions of the same city, ascending
+    q = torch.arange(n - 1, device=dev)
+    same_pos = q[None, :] + (q[None, :] >= p[:, None]).long()           # [n, n-1]
+    same_val = torch.full((n, n - 1), -city_visit / 2.0, dtype=torch.float64, device=dev)
+    cities = torch.arange(n, device=dev)
+    col_view, val_view = colidx.view(n, n, deg), val.view(n, n, deg)  # [city, position, entry]
+    for c in range(n):
+        others = torch.cat([cities[:c], cities[c + 1:]])               # [n-1]
+        oc = (others[None, :, None] * n + trip[:, None, :])             # [n, n-1, 3]
+        prev_v = (-d[others, c] / 4.0)[None, :, None]                   # d[c', c]
+        next_v = (-d[c, others] / 4.0)[None, :, None]                   # d[c, c']
+        k = kind[:, None, :]
+        ov = torch.where(k == 1, torch.full_like(prev_v, -position_fill / 2.0),
+                         torch.where(k == 0, prev_v, next_v)).expand(n, n - 1, 3)
+        lo = 3 * c
+        col_view[c, :, :lo] = oc[:, :c].reshape(n, lo).int()
+        val_view[c, :, :lo] = ov[:, :c].reshape(n, lo).float()
+        col_view[c, :, lo:lo + n - 1] = (c * n + same_pos).int()
+        val_view[c, :, lo:lo + n - 1] = same_val.float()
+        col_view[c, :, lo + n - 1:] = oc[:, c:].reshape(n, deg - lo - (n - 1)).int()
+        val_view[c, :, lo + n - 1:] = ov[:, c:].reshape(n, deg - lo - (n - 1)).float()
+    off = d.clone()
+    off.fill_diagonal_(0.0)
+    tour_h = -(off.sum(1) + off.sum(0)) / 4.0                           # per city, every position
+    card = 2.0 * (city_visit / 4.0 + position_fill / 4.0) * (2.0 - n)
+    h = (tour_h[:, None] + card).expand(n, n).reshape(N).float().contiguous()
+    constant = float(off.sum()) * n / 4.0 + \
+        n * (city_visit / 4.0 + position_fill / 4.0) * (n + (2.0 - n) ** 2)
+    return rowptr, colidx, val, h, constant
+
+
 def scheduling_ising(durations: Sequence[float], n_agents: int, time_horizon: float,
                      time_discretization: int, due_dates: Optional[Sequence[float]] = None,
                      priorities: Optional[Sequence[float]] = None, objective: str = "makespan",

@@ -142,13 +142,17 @@ class AnnealEngine:
         self.n, self.R, self.n_models = n, 0, M
 
     def set_csr(self, rowptr, colidx, val, h):
-        rp, k1 = _buf(rowptr, np.int32, "int32")
+        """CSR couplings (both triangles).  int64 `rowptr` (numpy / torch) is passed through as
+        64-bit extents -- required once nnz >= 2^31 -- anything else is taken as int32."""
+        wide = getattr(rowptr, "dtype", None) in (np.dtype(np.int64), torch.int64)
+        rp, k1 = _buf(rowptr, np.int64, "int64") if wide else _buf(rowptr, np.int32, "int32")
         ci, k2 = _buf(colidx, np.int32, "int32")
         vp, k3 = _buf(val, np.float32, "float32")
         hp, k4 = _buf(h, np.float32, "float32")
         n = (k1.numel() if _is_tensor(k1) else k1.size) - 1
         nnz = k2.numel() if _is_tensor(k2) else k2.size
-        N.check(self._lib.sga_set_csr(self._h, rp, ci, vp, hp, int(n), int(nnz)), "sga_set_csr")
+        fn, name = (self._lib.sga_set_csr64, "sga_set_csr64") if wide else (self._lib.sga_set_csr, "sga_set_csr")
+        N.check(fn(self._h, rp, ci, vp, hp, int(n), int(nnz)), name)
         self.n, self.R = n, 0
 
     # ------------------------------------------------------------------ replicas

@@ -83,6 +83,28 @@ def test_assignment_and_tsp_physical_instances():
     assert e == pytest.approx(length)
 
 
+@pytest.mark.parametrize("n_cities,asymmetric", [(3, False), (4, True), (9, False), (60, True)])
+def test_structured_tsp_rows_equal_the_assembled_ones(n_cities, asymmetric):
+    """tsp_csr writes each spin's 4(n-1) neighbours straight from the encoding's structure (what
+    a 1000-city instance needs); it must be the builder's CSR entry for entry."""
+    rs = np.random.RandomState(n_cities)
+    xy = rs.rand(n_cities, 2) * 100.0
+    d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+    if asymmetric:
+        d = d + rs.rand(n_cities, n_cities)
+    np.fill_diagonal(d, 0.0)
+    b = enc.tsp_ising(d, city_visit=200.0, position_fill=150.0)
+    rowptr, col, val = b.to_csr()
+    rp2, col2, val2, h2, const = enc.tsp_csr(d, city_visit=200.0, position_fill=150.0)
+    assert rp2.dtype.is_floating_point is False and rp2.element_size() == 8
+    assert np.array_equal(rp2.numpy(), rowptr) and np.array_equal(col2.numpy(), col)
+    assert np.array_equal(val2.numpy(), val)
+    assert np.allclose(h2.numpy(), b.fields(), rtol=1e-6, atol=0)
+    assert const == pytest.approx(b.constant, rel=1e-12)
+    with pytest.raises(ValueError):
+        enc.tsp_csr(d[:2, :2])
+
+
 def test_large_instance_assembly_is_fast_and_consistent():
     # C4-shaped (scaled to keep the CPU suite short): 200 tasks x 1 agent x 50 slots
     dur = np.full(200, 1.0)

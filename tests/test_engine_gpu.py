@@ -386,8 +386,12 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R):
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("integer", [True, False])
-def test_csr_wide_rows_match_oracle(sg, waves, integer):
-    """Rows of a few hundred entries dealt to several waves per replica (C4/C5 shape)."""
+@pytest.mark.parametrize("big", [False, True])
+def test_csr_wide_rows_match_oracle(sg, waves, integer, big, monkeypatch):
+    """Rows of a few hundred entries dealt to several waves per replica (C4/C5 shape); `big`
+    sends the same case through the form for n > 160k (spins as bits in LDS, 64-bit extents)."""
+    if big:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
     n, R = 900, 5
     rng = np.random.RandomState(17)
     mask = np.triu(rng.rand(n, n) < 0.35, 1)
@@ -406,6 +410,7 @@ def test_csr_wide_rows_match_oracle(sg, waves, integer):
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
         assert f"waves_per_replica={waves}" in e.describe()
+        assert ("spins=lds-bits" in e.describe()) == big
         e.set_temperatures(temps)
         out = e.sweep(ns, energy_trace=True)
         assert np.array_equal(out["energy_trace"], ref["energy_trace"])
@@ -418,6 +423,97 @@ def test_csr_wide_rows_match_oracle(sg, waves, integer):
                              trace=True)
         assert np.array_equal(out2["accept_trace"], ref2["accept_trace"])
         assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
+
+
+def random_sparse_pm1(n, deg, seed):
+    """Symmetric +-1 couplings, ~deg entries per row, canonical CSR (sorted, no duplicates)."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    m = n * deg // 2
+    i, j = rng.randint(0, n, m), rng.randint(0, n, m)
+    keep = i != j
+    lo, hi = np.minimum(i, j)[keep], np.maximum(i, j)[keep]
+    _, first = np.unique(lo.astype(np.int64) * n + hi, return_index=True)
+    lo, hi = lo[first], hi[first]
+    v = (rng.randint(0, 2, lo.size) * 2 - 1).astype(np.float32)
+    A = sp.coo_matrix((np.concatenate([v, v]), (np.concatenate([lo, hi]), np.concatenate([hi, lo]))),
+                      shape=(n, n)).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,deg,waves,wide_extents", [(200_000, 12, 0, False), (170_001, 300, 4, True)])
+def test_csr_beyond_int8_lds_capacity_matches_oracle(sg, n, deg, waves, wide_extents):
+    """n > 160k spins (BASELINE config 5's regime): spins live in LDS as bits, picked up
+    automatically; 64-bit row extents through sga_set_csr64."""
+    rowptr, colidx, val = random_sparse_pm1(n, deg, n)
+    rng = np.random.RandomState(3)
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(csr=(rowptr, colidx, val), h=h)
+    R, ns, seed = 3, 2, 77 + n
+    temps = ladder(R, 6.0, 0.8)
+    s = oracle.init_spins(n, R, seed)
+    e0 = np.asarray([oracle.energy(prob, s[r]) for r in range(R)])
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        if waves:
+            e.set_tuning(waves_per_replica=waves)
+        e.set_csr(rowptr.astype(np.int64) if wide_extents else rowptr, colidx, val, h)
+        e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert "spins=lds-bits" in d and "path=integer-fast" in d and "recomputed" not in d
+        assert np.array_equal(e.energies(), e0)
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"])
+        for r in range(R):
+            be, bs, _ = e.best(r)
+            assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+        # single-site operators and a recompute read the same replica from HBM
+        assert e.local_fields(0, [0, n // 2, n - 1]).shape == (3,)
+        e.recompute_energies()
+        assert np.array_equal(e.energies(), ref["energy"])
+
+
+def test_csr_structure_is_validated_on_the_device(sg):
+    n = 500
+    rowptr, colidx, val = random_sparse_pm1(n, 10, 1)
+    h = np.zeros(n, np.float32)
+    with sg.AnnealEngine(0) as e:
+        bad = rowptr.copy()
+        bad[10] = bad[11] + 1
+        with pytest.raises(sg.AnnealingError, match="rowptr"):
+            e.set_csr(bad, colidx, val, h)
+        bad = colidx.copy()
+        bad[5] = n
+        with pytest.raises(sg.AnnealingError, match="column"):
+            e.set_csr(rowptr, bad, val, h)
+        with pytest.raises(sg.AnnealingError, match="rowptr"):
+            e.set_csr(rowptr.astype(np.int64) + 1, colidx, val, h)
+        # symmetric: incremental energies; one entry changed: energies recomputed per sweep
+        e.set_csr(rowptr, colidx, val, h)
+        e.init_replicas(2, seed=1)
+        assert "recomputed" not in e.describe()
+        asym = val.copy()
+        asym[0] = -asym[0]
+        e.set_csr(rowptr, colidx, asym, h)
+        e.init_replicas(2, seed=1)
+        assert "recomputed" in e.describe()
+        # rows in arbitrary column order (and 64-bit extents): still recognised as symmetric
+        perm_c, perm_v = colidx.copy(), val.copy()
+        for i in range(n):
+            b, t = rowptr[i], rowptr[i + 1]
+            p = np.random.RandomState(i).permutation(t - b)
+            perm_c[b:t], perm_v[b:t] = colidx[b:t][p], val[b:t][p]
+        e.set_csr(rowptr.astype(np.int64), perm_c, perm_v, h)
+        e.init_replicas(2, seed=1)
+        assert "recomputed" not in e.describe() and "integer-fast" in e.describe()
+        ea = e.energies()
+        e.set_csr(rowptr, colidx, val, h)
+        e.init_replicas(2, seed=1)
+        assert np.array_equal(e.energies(), ea)
 
 
 # ----------------------------------------------------------------------------- exchange
