@@ -753,6 +753,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
         a.big = e->big ? 1 : 0;
+        // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
+        a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
         a.colidx = e->colidx;
         a.val = e->val;
         a.h = e->h;
@@ -804,6 +806,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             le = sga::launch_sweep_csr(a, e->waves, st);
         } else if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
             a.J = e->J_bits;
+            a.J_aux = e->J_packed;
             a.plane_bytes = (long long)e->n * (e->ld / 8);
             a.diag = e->row_nnz;
             le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2,
@@ -1336,12 +1339,16 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     else
         std::snprintf(tmp, sizeof(tmp),
                       "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "
-                      "chunks_per_wave=%d%s ld=%lld row_bytes=%lld table_m=%d",
+                      "chunks_per_wave=%d%s ld=%lld row_bytes=%lld table_m=%d look_ahead=%d",
                       e->n, e->n_models, e->use_t2 ? "t2" : (e->want_i8 ? "i8" : "f32"),
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
                       (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
-                      e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m);
+                      e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m,
+                      (e->table_m > 0 && std::getenv("SGA_NO_LOOK_AHEAD") == nullptr)
+                          ? sga::dense_look_ahead(e->use_t2, e->want_i8, e->acc64,
+                                                  e->use_t2 ? e->cpw_t2 : e->cpw)
+                          : 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

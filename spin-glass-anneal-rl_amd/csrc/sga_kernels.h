@@ -51,6 +51,8 @@ struct SweepArgs {
     int no_best;  // 1: leave best tracking to the host-driven pass (asymmetric / diagonal J)
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
     int big;      // CSR: spins held as bits in LDS, 64-bit row extents (n > ~160k or nnz >= 2^31)
+    int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
+    const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -84,6 +86,9 @@ struct ExchangeArgs {
 // launchers (defined in the .hip files); all return hipGetLastError() after the launch
 hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
                               hipStream_t st);
+// updates reduced together by the production sweeps of an integer problem with this layout (1 =
+// one at a time): sweep_dense_impl.h, look-ahead form
+int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw);
 // ternary couplings as two bit-planes (production configuration only)
 hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStream_t st);
 // fp32 [n][n] -> sign plane + non-zero plane, each [n][ld/32] words, plus nnz[n] (as float)

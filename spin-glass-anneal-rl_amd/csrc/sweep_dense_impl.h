@@ -71,9 +71,14 @@ struct AccType<int8_t, ACC64> {
 };
 
 constexpr int PART_SLOT_BYTES = 8;
-constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * PART_SLOT_BYTES + 16;
+// Look-ahead form: LOOK updates are reduced together, one barrier for all of them.
+constexpr int LOOK = 4;
+constexpr int LOOK_SLOT_BYTES = 4 * LOOK;  // one wave's LOOK partial sums (float | int)
+// behind the spins: [2][MAX_WAVES] partial-sum slots (8 B, or 16 B in the look-ahead form), then
+// the spin(s) at the update site(s) published by their owner waves
+constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * LOOK_SLOT_BYTES + 2 * LOOK * 4;
 
-template <typename JT, int CPW, bool ACC64, bool LEAN>
+template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false>
 __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
@@ -153,44 +158,77 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     using JE = typename std::conditional<BITS, unsigned char, JT>::type;
     constexpr int LANE_STEP = BITS ? 16 : EPL, CHUNK_STEP = BITS ? 1024 : EPC;
     const long long row_step = BITS ? a.ld / 8 : a.ld;
-    const JE *Jlane = reinterpret_cast<const JE *>(a.J) + (BITS ? 0 : model * a.model_stride_j) +
-                      (w * CHUNK_STEP + lane * LANE_STEP);
+    // A row is addressed as (uniform row base) + (32-bit lane offset): the scalar-base form of
+    // global_load needs one shared offset VGPR instead of a 64-bit address pair per load.
+    const JE *Jbase = reinterpret_cast<const JE *>(a.J) + (BITS ? 0 : model * a.model_stride_j);
+    const unsigned int lane_off = (unsigned int)(w * CHUNK_STEP + lane * LANE_STEP);
     const float *hvec = a.h + (long long)model * n;
     const float *dvec = a.diag + (long long)model * n;
     const long long kstep = (long long)W * CHUNK_STEP;  // address step between a wave's chunks
-    const int8_t *slane = s_lds + (w * CHUNK_STEP + lane * LANE_STEP);
+    const int8_t *slane = s_lds + lane_off;
     const bool arith32 = arith == SGA_ARITH_F32;
 
     constexpr int NBUF = CPW > 0 ? CPW : 1;
     const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
 
-    auto load_chunk = [&](const JE *p, long long k) -> vec_t {
+    // The base of row `site`.  Up to 8 chunks per wave it is pinned to SGPRs and the loads take
+    // the scalar-base form (one 32-bit offset VGPR per load instead of a 64-bit address pair);
+    // with 9-10 chunks every register is spoken for and the plain per-lane pointer does better.
+    constexpr bool SCALAR_BASE = CPW <= 8;
+    auto row_base = [&](int site) -> const JE * {
+        if constexpr (SCALAR_BASE) {
+            const unsigned long long q = (unsigned long long)site * (unsigned long long)row_step;
+            const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)q);
+            const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(q >> 32));
+            return Jbase + (((unsigned long long)hi << 32) | lo);  // (stays a global pointer)
+        } else {
+            return Jbase + (long long)site * row_step + lane_off;
+        }
+    };
+    auto load_chunk = [&](const JE *p, int k) -> vec_t {  // p: row_base(site)
         // default cache policy on purpose: non-temporal loads measured 3-5 % slower here (part
         // of J is re-served by the 256 MB Infinity Cache; profiles/r01_experiments.md)
+        const unsigned char *q = reinterpret_cast<const unsigned char *>(p);
+        unsigned long long off;
+        if constexpr (SCALAR_BASE) {
+            // byte offset in 32 bits, opaque to the optimiser (a hoisted 64-bit zero extension of
+            // it loses the base + zext(VGPR) address form)
+            unsigned int o32 = (lane_off + (unsigned int)k * (unsigned int)kstep) * (unsigned int)sizeof(JE);
+            asm volatile("" : "+v"(o32));
+            off = o32;
+        } else {
+            off = (unsigned long long)((long long)k * kstep) * sizeof(JE);
+        }
         if constexpr (BITS) {
             BitPair o;
-            o.s = *reinterpret_cast<const int4 *>(p + k * kstep);
-            o.z = *reinterpret_cast<const int4 *>(p + a.plane_bytes + k * kstep);
+            o.s = *reinterpret_cast<const int4 *>(q + off);
+            o.z = *reinterpret_cast<const int4 *>(q + a.plane_bytes + off);
             return o;
         } else {
-            return *reinterpret_cast<const vec_t *>(p + k * kstep);
+            return *reinterpret_cast<const vec_t *>(q + off);
         }
     };
 
     auto load_row = [&](vec_t(&buf)[NBUF], int site) {
         if constexpr (CPW == 0) return;  // streaming form loads inside the reduction
-        const JE *p = Jlane + (long long)site * row_step;
+        const JE *p = row_base(site);
 #pragma unroll
         for (int k = 0; k < CPW; ++k) buf[k] = load_chunk(p, k);
     };
 
-    auto accumulate = [&](acc_t &acc, const vec_t &x, long long k) {
+    // the spins under chunk k of this wave, and one chunk's contribution to a row sum
+    using spin_t = typename std::conditional<sizeof(JT) == 4, int, int4>::type;
+    auto load_spins = [&](long long k) -> spin_t {
+        if constexpr (BITS) return *reinterpret_cast<const int4 *>(slane + k * kstep);
+        else if constexpr (sizeof(JT) == 4) return *reinterpret_cast<const int *>(slane + k * kstride);
+        else return *reinterpret_cast<const int4 *>(slane + k * kstride);
+    };
+    auto accumulate_with = [&](acc_t &acc, const vec_t &x, const spin_t &sv) {
         if constexpr (BITS) {  // count the stored couplings whose product with the spin is -1
-            const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstep);
             acc += __builtin_popcount(x.z.x & (x.s.x ^ sv.x)) + __builtin_popcount(x.z.y & (x.s.y ^ sv.y)) +
                    __builtin_popcount(x.z.z & (x.s.z ^ sv.z)) + __builtin_popcount(x.z.w & (x.s.w ^ sv.w));
         } else if constexpr (sizeof(JT) == 4) {  // J * (+-1) is exact in fp32
-            const int sw = *reinterpret_cast<const int *>(slane + k * kstride);
+            const int sw = sv;
             const float s0 = (float)(int8_t)(sw), s1 = (float)(int8_t)(sw >> 8),
                         s2 = (float)(int8_t)(sw >> 16), s3 = (float)(sw >> 24);
             if constexpr (ACC64) {
@@ -205,17 +243,19 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
                 acc = __builtin_fmaf(x.w, s3, acc);
             }
         } else {
-            const int4 sv = *reinterpret_cast<const int4 *>(slane + k * kstride);
             acc = __builtin_amdgcn_sdot4(x.x, sv.x, acc, false);
             acc = __builtin_amdgcn_sdot4(x.y, sv.y, acc, false);
             acc = __builtin_amdgcn_sdot4(x.z, sv.z, acc, false);
             acc = __builtin_amdgcn_sdot4(x.w, sv.w, acc, false);
         }
     };
+    auto accumulate = [&](acc_t &acc, const vec_t &x, long long k) {
+        accumulate_with(acc, x, load_spins(k));
+    };
 
     // streaming reduction of row `site`: batches of four 1-KiB chunks per wave
     auto dot_stream = [&](int site) -> acc_t {
-        const JE *p = Jlane + (long long)site * row_step;
+        const JE *p = row_base(site);
         acc_t acc = 0;
         for (int k0 = 0; k0 < cpw_rt; k0 += 4) {
             vec_t t[4];
@@ -305,66 +345,159 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         }
     };
 
-    // Ring of NB row buffers: update g reads ring[g % NB]; its row was requested NB - 1 updates
-    // earlier (sites come from the counter RNG, not from the chain's state).  Measured at depths
-    // 2, 3 and 6 (profiles/r01_experiments.md): long rows are bandwidth bound and short rows are
-    // bound by the update chain itself (LDS round trips + issue rate of one wave per SIMD), not
-    // by the HBM round trip, so depth 2 -- the smallest code and register footprint -- is kept.
-#ifndef SGA_RING_NB
-#define SGA_RING_NB 2
-#endif
-    constexpr int NB = CPW == 0 ? 1 : SGA_RING_NB;
-    struct Slot {
-        vec_t row[NBUF];
-        int site;
-        float u, h, d;
-    };
-    Slot ring[NB];
-    const bool need_d = arith32 || BITS;  // J_ii for the fp32 rule | row non-zero count (bits)
-
-    PairSource<LEAN> rng;
-    UpdatePair pairP{0, 0, 2.0f, 2.0f};
-    int kP = 0, tP = 0;  // producer cursor: the next update whose row is requested
-    auto produce = [&](Slot &sl) {
-        // No early-out past the end of the launch: the last NB - 1 requests read rows nobody
-        // uses, but a conditional request makes the compiler drain vmcnt at every update.
-        const bool second = tP & 1;
-        if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
-        // values first, then the select: a select between the two members' addresses would
-        // push the pair into scratch, and scratch loads drain vmcnt -- the whole prefetch ring
-        const int sA = pairP.sA, sB = pairP.sB;
-        const float uA = pairP.uA, uB = pairP.uB;
-        sl.site = second ? sB : sA;
-        sl.u = second ? uB : uA;
-        load_row(sl.row, sl.site);
-        sl.h = hvec[sl.site];
-        sl.d = need_d ? dvec[sl.site] : 0.0f;
-        if (++tP == n) {
-            tP = 0;
-            ++kP;
-        }
-    };
+    if constexpr (BATCH) {
+        // Look-ahead form (integer problems, LEAN).  Short rows are bound by the update chain
+        // itself -- three dependent LDS round trips, a wave reduction and ~120 issued
+        // instructions per update with one or two waves per SIMD -- not by memory.  The site
+        // sequence is known ahead, so LOOK consecutive updates are reduced TOGETHER against the
+        // spins as they stand before the first of them (one spin read, LOOK interleaved wave
+        // sums, one barrier), and the chain is then replayed serially on scalars: update m's
+        // row sum is corrected by -2 J[j_m][j_l] s_l for every accepted earlier update l of the
+        // batch, its spin is negated if an accepted l sat on the same site.  All quantities are
+        // integers below 2^24, so the corrected sums are exactly the sequential ones and every
+        // decision, energy and spin is bit-identical to the one-update-at-a-time form.
+        static_assert(LEAN && !ACC64 && CPW >= 1, "look-ahead: production form, exact fp32 / int sums");
+        constexpr int L = LOOK, NX = L * (L - 1) / 2;
+        unsigned char *lpart = part_raw;                                             // [2][MAX_WAVES][L]
+        int *lsi = reinterpret_cast<int *>(part_raw + 2 * MAX_WAVES * LOOK_SLOT_BYTES);  // [2][L]
+        struct Meta {  // what a batch needs besides its rows
+            int site[L];
+            float u[L], h[L], d[L];
+            float x[NX];  // J[site[m]][site[l]], l < m, at m (m - 1) / 2 + l
+            int cnt;      // updates in the batch (a batch never crosses a sweep boundary)
+        };
+        vec_t rows[L][NBUF];
+        PairSource<LEAN> rng;
+        int kP = 0, tP = 0;  // producer cursor: first update of the next batch to request
+        auto cross = [&](int sm, int sl) -> float {  // J[sm][sl]: uniform address, one element
+            if constexpr (BITS) {
+                return (float)reinterpret_cast<const int8_t *>(a.J_aux)[(long long)sm * a.ld + sl];
+            } else {
+                return (float)(Jbase + (long long)sm * a.ld)[sl];
+            }
+        };
+        auto request = [&](Meta &mt) {
+            const bool live = kP < a.n_sweeps;
+            mt.cnt = live ? (n - tP < L ? n - tP : L) : 0;
+            const UpdatePair p0 = rng.get(a, r, kP, tP >> 1, mt.cnt > 0, lane);
+            const UpdatePair p1 = rng.get(a, r, kP, (tP >> 1) + 1, mt.cnt > 2, lane);
+            mt.site[0] = p0.sA, mt.site[1] = p0.sB, mt.site[2] = p1.sA, mt.site[3] = p1.sB;
+            mt.u[0] = p0.uA, mt.u[1] = p0.uB, mt.u[2] = p1.uA, mt.u[3] = p1.uB;
 #pragma unroll
-    for (int j = 0; j + 1 < NB; ++j) produce(ring[j]);
-
-    const long long total = (long long)a.n_sweeps * n;
-    int k = 0, t = 0;  // consumer cursor
-    for (long long g0 = 0; g0 < total; g0 += NB) {
+            for (int m = 0; m < L; ++m) {
+                if (m >= mt.cnt) mt.site[m] = 0;  // the half-used last pair of an odd sweep
+                load_row(rows[m], mt.site[m]);
+                mt.h[m] = hvec[mt.site[m]];
+                mt.d[m] = BITS ? dvec[mt.site[m]] : 0.0f;
+            }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (g0 + j >= total) break;  // wave-uniform
-            if (t == 0) {                // sweep start: temperature, accept table
+            for (int m = 1; m < L; ++m)
+#pragma unroll
+                for (int l = 0; l < m; ++l) mt.x[m * (m - 1) / 2 + l] = cross(mt.site[m], mt.site[l]);
+            tP += mt.cnt;
+            if (tP >= n) {
+                tP = 0;
+                ++kP;
+            }
+        };
+        static_assert(L == 4, "two RNG pairs per batch");
+        Meta cur;
+        request(cur);
+        int k = 0, t = 0, lp = 0;
+        while (k < a.n_sweeps) {
+            if (t == 0) {  // sweep start: temperature, accept table
                 T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-                if (use_tab) {
-                    __syncthreads();  // nobody still reads last sweep's table
-                    for (int q = tid; q <= a.table_m; q += blockDim.x)
-                        ptab[q] = expf_det((float)(-(double)(2 * q) / T));
-                    __syncthreads();
+                __syncthreads();  // nobody still reads last sweep's table
+                for (int q = tid; q <= a.table_m; q += blockDim.x)
+                    ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+                __syncthreads();
+            }
+            // spins at the batch's sites, read by their owner waves before anything flips
+            int owner[L], si[L];
+#pragma unroll
+            for (int m = 0; m < L; ++m) {
+                owner[m] = (cur.site[m] / EPC) % W;
+                si[m] = 0;
+                if (w == owner[m]) {
+                    if constexpr (BITS) si[m] = ((s_bits[cur.site[m] >> 5] >> (cur.site[m] & 31)) & 1u) ? -1 : 1;
+                    else si[m] = s_lds[cur.site[m]];
                 }
             }
-            produce(ring[(j + NB - 1) % NB]);  // the buffer update g - 1 just released
-            step(ring[j].row, ring[j].site, ring[j].u, ring[j].h, ring[j].d, g0 + j);
-            if (++t == n) {
+            // LOOK row sums against the same spins
+            acc_t ls[L];
+#pragma unroll
+            for (int m = 0; m < L; ++m) ls[m] = 0;
+#pragma unroll
+            for (int c = 0; c < NBUF; ++c) {
+                const spin_t sv = load_spins(c);
+#pragma unroll
+                for (int m = 0; m < L; ++m) accumulate_with(ls[m], rows[m][c], sv);
+            }
+            // the rows are consumed: request the next batch into the same registers
+            Meta nxt;
+            request(nxt);
+            acc_t tot[L];
+#pragma unroll
+            for (int m = 0; m < L; ++m) tot[m] = wave_sum(ls[m]);
+            if (W > 1) {
+                acc_t *mine = reinterpret_cast<acc_t *>(lpart + (lp * MAX_WAVES + w) * LOOK_SLOT_BYTES);
+                if (lane == 0) {
+#pragma unroll
+                    for (int m = 0; m < L; ++m) {
+                        mine[m] = tot[m];
+                        if (w == owner[m]) lsi[lp * L + m] = si[m];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < L; ++m) tot[m] = 0;
+                for (int i = 0; i < W; ++i) {
+                    const acc_t *o = reinterpret_cast<const acc_t *>(lpart + (lp * MAX_WAVES + i) * LOOK_SLOT_BYTES);
+#pragma unroll
+                    for (int m = 0; m < L; ++m) tot[m] += o[m];
+                }
+#pragma unroll
+                for (int m = 0; m < L; ++m) si[m] = lsi[lp * L + m];
+                lp ^= 1;
+            }
+            // the chain, replayed on wave-uniform scalars
+            bool took[L];
+            float sused[L];
+#pragma unroll
+            for (int m = 0; m < L; ++m) {
+                took[m] = false;
+                sused[m] = 0.0f;
+                if (m < cur.cnt) {
+                    // bit-plane form: tot counts the -1 products, d carries the row's non-zero count
+                    float dotf = BITS ? cur.d[m] - 2.0f * (float)tot[m] : (float)tot[m];
+                    int sim = si[m];
+#pragma unroll
+                    for (int l = 0; l < m; ++l) {
+                        if (took[l]) {
+                            dotf -= 2.0f * cur.x[m * (m - 1) / 2 + l] * sused[l];
+                            if (cur.site[l] == cur.site[m]) sim = -sim;
+                        }
+                    }
+                    const float fk = (float)sim * (dotf + cur.h[m]);
+                    const double dE = (double)(2.0f * fk);
+                    bool acc;
+                    if (fk <= 0.0f) acc = true;
+                    else if (fk <= (float)a.table_m) acc = cur.u[m] < ptab[(int)fk];
+                    else acc = cur.u[m] < expf_det((float)(-dE / T));
+                    if (acc) {
+                        E += dE;
+                        ++nacc;
+                        if (w == owner[m] && lane == 0) {
+                            if constexpr (BITS) s_bits[cur.site[m] >> 5] ^= 1u << (cur.site[m] & 31);
+                            else s_lds[cur.site[m]] = (int8_t)(-sim);
+                        }
+                    }
+                    took[m] = acc;
+                    sused[m] = (float)sim;
+                }
+            }
+            t += cur.cnt;
+            if (t >= n) {
                 // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)
                 if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
                 if (E < bestE && !a.no_best) {
@@ -375,6 +508,81 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
                 }
                 t = 0;
                 ++k;
+            }
+            cur = nxt;
+        }
+    } else {
+        // Ring of NB row buffers: update g reads ring[g % NB]; its row was requested NB - 1 updates
+        // earlier (sites come from the counter RNG, not from the chain's state).  Measured at depths
+        // 2, 3 and 6 (profiles/r01_experiments.md): long rows are bandwidth bound and short rows are
+        // bound by the update chain itself (LDS round trips + issue rate of one wave per SIMD), not
+        // by the HBM round trip, so depth 2 -- the smallest code and register footprint -- is kept.
+#ifndef SGA_RING_NB
+#define SGA_RING_NB 2
+#endif
+        constexpr int NB = CPW == 0 ? 1 : SGA_RING_NB;
+        struct Slot {
+            vec_t row[NBUF];
+            int site;
+            float u, h, d;
+        };
+        Slot ring[NB];
+        const bool need_d = arith32 || BITS;  // J_ii for the fp32 rule | row non-zero count (bits)
+
+        PairSource<LEAN> rng;
+        UpdatePair pairP{0, 0, 2.0f, 2.0f};
+        int kP = 0, tP = 0;  // producer cursor: the next update whose row is requested
+        auto produce = [&](Slot &sl) {
+            // No early-out past the end of the launch: the last NB - 1 requests read rows nobody
+            // uses, but a conditional request makes the compiler drain vmcnt at every update.
+            const bool second = tP & 1;
+            if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
+            // values first, then the select: a select between the two members' addresses would
+            // push the pair into scratch, and scratch loads drain vmcnt -- the whole prefetch ring
+            const int sA = pairP.sA, sB = pairP.sB;
+            const float uA = pairP.uA, uB = pairP.uB;
+            sl.site = second ? sB : sA;
+            sl.u = second ? uB : uA;
+            load_row(sl.row, sl.site);
+            sl.h = hvec[sl.site];
+            sl.d = need_d ? dvec[sl.site] : 0.0f;
+            if (++tP == n) {
+                tP = 0;
+                ++kP;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j + 1 < NB; ++j) produce(ring[j]);
+
+        const long long total = (long long)a.n_sweeps * n;
+        int k = 0, t = 0;  // consumer cursor
+        for (long long g0 = 0; g0 < total; g0 += NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (g0 + j >= total) break;  // wave-uniform
+                if (t == 0) {                // sweep start: temperature, accept table
+                    T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+                    if (use_tab) {
+                        __syncthreads();  // nobody still reads last sweep's table
+                        for (int q = tid; q <= a.table_m; q += blockDim.x)
+                            ptab[q] = expf_det((float)(-(double)(2 * q) / T));
+                        __syncthreads();
+                    }
+                }
+                produce(ring[(j + NB - 1) % NB]);  // the buffer update g - 1 just released
+                step(ring[j].row, ring[j].site, ring[j].u, ring[j].h, ring[j].d, g0 + j);
+                if (++t == n) {
+                    // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)
+                    if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+                    if (E < bestE && !a.no_best) {
+                        bestE = E;
+                        __syncthreads();
+                        store_spins(a.best_spins + (long long)r * a.sstride);
+                        __syncthreads();
+                    }
+                    t = 0;
+                    ++k;
+                }
             }
         }
     }
@@ -388,18 +596,32 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     }
 }
 
+// look-ahead form: short rows only (longer ones are bandwidth bound, and LOOK of them would not
+// fit the registers)
+template <typename JT, bool ACC64, int CPW>
+constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hip) in step
+    return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 1 : 3);
+}
+
 template <typename JT, bool ACC64, int CPW>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     constexpr bool BITS = std::is_same<JT, Tern2>::value;
     const size_t lds = (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
                        sizeof(float) * (size_t)(a.table_m + 1);
-    void (*kern)(const SweepArgs);
-    if constexpr (BITS) {
-        if (!sweep_args_are_lean(a)) return hipErrorInvalidValue;  // engine falls back to int8
-        kern = sweep_dense_kernel<JT, CPW, ACC64, true>;
-    } else {
-        kern = sweep_args_are_lean(a) ? sweep_dense_kernel<JT, CPW, ACC64, true>
-                                      : sweep_dense_kernel<JT, CPW, ACC64, false>;
+    const bool lean = sweep_args_are_lean(a);
+    void (*kern)(const SweepArgs) = nullptr;
+    if constexpr (has_look_ahead<JT, ACC64, CPW>()) {
+        if (lean && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux))
+            kern = sweep_dense_kernel<JT, CPW, ACC64, true, true>;
+    }
+    if (!kern) {
+        if constexpr (BITS) {
+            if (!lean) return hipErrorInvalidValue;  // engine falls back to int8
+            kern = sweep_dense_kernel<JT, CPW, ACC64, true>;
+        } else {
+            kern = lean ? sweep_dense_kernel<JT, CPW, ACC64, true>
+                        : sweep_dense_kernel<JT, CPW, ACC64, false>;
+        }
     }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -838,6 +838,51 @@ def test_ternary_bit_plane_storage_matches_oracle(sg, n, R, waves, density):
         assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
 
 
+@pytest.mark.parametrize("n,R,storage,waves", [
+    (3, 3, "f32", 0), (7, 5, "i8", 0), (64, 8, "f32", 0), (65, 4, "t2", 0), (257, 6, "f32", 2),
+    (700, 5, "f32", 3), (1023, 4, "i8", 1), (2500, 3, "i8", 3), (3000, 3, "t2", 1), (9000, 2, "t2", 2),
+])
+def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, monkeypatch):
+    """Integer problems with short rows reduce four consecutive updates together and replay the
+    chain on scalars (sweep_dense_impl.h).  Same spins, energies, counters and best states as the
+    oracle's strictly sequential chain and as the kernel's own one-at-a-time form -- including
+    repeated sites inside a batch (tiny n), odd n, fields, and several waves per replica."""
+    rng = np.random.RandomState(n)
+    J = pm1(n, 100 + n)
+    if storage == "t2":
+        J = J * (rng.rand(n, n) < 0.6)
+        J = np.triu(J, 1)
+        J = (J + J.T).astype(np.float32)
+    h = rng.randint(-2, 3, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    ns, seed = 6, 31337 + n
+    temps = ladder(R, 3.0 * np.sqrt(n), 0.3)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    got = {}
+    for look in (True, False):
+        if look:
+            monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+        else:
+            monkeypatch.setenv("SGA_NO_LOOK_AHEAD", "1")
+        with sg.AnnealEngine(0) as e:
+            if waves:
+                e.set_tuning(waves_per_replica=waves)
+            e.set_dense(J, h, storage=storage)
+            e.init_replicas(R, seed=seed)
+            assert ("look_ahead=4" in e.describe()) == look, e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+            assert np.array_equal(e.spins(), s)
+            assert np.array_equal(e.stats()[0], ref["n_accepted"])
+            for r in range(R):
+                be, bs, _ = e.best(r)
+                assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+            got[look] = e.energies()
+    assert np.array_equal(got[True], got[False])
+
+
 def test_bit_plane_storage_needs_ternary_couplings(sg):
     with sg.AnnealEngine(0) as e:
         with pytest.raises(sg.AnnealingError):
