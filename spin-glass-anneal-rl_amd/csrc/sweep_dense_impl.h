@@ -168,6 +168,15 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     const int8_t *slane = s_lds + lane_off;
     const bool arith32 = arith == SGA_ARITH_F32;
 
+    // the wave whose chunks hold `site` (chunk c belongs to wave c mod W).  A general modulo costs
+    // ~20 instructions per update on a lone wave: multiply by a 16-bit reciprocal instead (exact
+    // for c < 4096 chunks and W <= 16)
+    const unsigned int w_recip = (65536u + (unsigned int)W - 1u) / (unsigned int)W;
+    auto owner_of = [&](int site) -> int {
+        const unsigned int c = (unsigned int)site / (unsigned int)EPC;
+        return (int)(c - ((c * w_recip) >> 16) * (unsigned int)W);
+    };
+
     constexpr int NBUF = CPW > 0 ? CPW : 1;
     const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
 
@@ -177,7 +186,8 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
     constexpr bool SCALAR_BASE = CPW <= 8;
     auto row_base = [&](int site) -> const JE * {
         if constexpr (SCALAR_BASE) {
-            const unsigned long long q = (unsigned long long)site * (unsigned long long)row_step;
+            // 32 x 32 -> 64 bit: two scalar multiplies (a 64-bit row_step costs five)
+            const unsigned long long q = (unsigned long long)(unsigned int)site * (unsigned int)row_step;
             const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)q);
             const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(q >> 32));
             return Jbase + (((unsigned long long)hi << 32) | lo);  // (stays a global pointer)
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
         if constexpr (CPW == 0) lane_sum = dot_stream(site);
         else lane_sum = dot_row(buf);
         acc_t tot = wave_sum(lane_sum);
-        const int owner = (site / EPC) % W;
+        const int owner = owner_of(site);
         auto spin_at = [&](int i) -> int {
             if constexpr (BITS) return ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -1 : 1;
             else return s_lds[i];
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
             int owner[L], si[L];
 #pragma unroll
             for (int m = 0; m < L; ++m) {
-                owner[m] = (cur.site[m] / EPC) % W;
+                owner[m] = owner_of(cur.site[m]);
                 si[m] = 0;
                 if (w == owner[m]) {
                     if constexpr (BITS) si[m] = ((s_bits[cur.site[m] >> 5] >> (cur.site[m] & 31)) & 1u) ? -1 : 1;
