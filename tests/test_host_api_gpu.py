@@ -450,6 +450,48 @@ def test_c4_shaped_instance_full_size(sg):
         assert np.array_equal(e.energies(), tracked) and np.array_equal(e.spins(), spins_csr)
 
 
+@pytest.mark.parametrize("n_cities,force_bits", [(40, False), (420, False), (60, True)])
+def test_c5_tsp_rows_written_on_the_device(sg, n_cities, force_bits, monkeypatch):
+    """BASELINE configs[4] shape (TSP QUBO, n = cities^2, degree 4(cities - 1), 32 ladders): the
+    structured CSR is produced on the GPU with 64-bit extents and handed over as device pointers.
+    420 cities = 176 400 spins is past the int8 LDS capacity: spins live as bits (the form the
+    1000-city instance runs in).  First sweep == oracle on the same rows; exchanges stay inside
+    their ladders."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    if force_bits:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    rs = np.random.RandomState(n_cities)
+    xy = rs.rand(n_cities, 2) * 100.0
+    d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+    rowptr, col, val, h, const = enc.tsp_csr(d, city_visit=200.0, position_fill=200.0, device="cuda:0")
+    assert rowptr.is_cuda and rowptr.dtype == torch.int64
+    n, R, seed, n_ladders = n_cities ** 2, 64, 9, 32
+    bits = force_bits or n > 160_000
+    temps = np.tile(np.asarray(sg.temperature_ladder(R // n_ladders, 2.0, 200.0)), n_ladders)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(rowptr, col, val, h)
+        e.init_replicas(R, seed=seed)
+        assert ("spins=lds-bits" in e.describe()) == bits and "recomputed" not in e.describe()
+        e.set_ladder(temps, n_ladders)
+        e0 = e.energies()
+        out = e.sweep(1, energy_trace=True)
+        e.exchange()
+        e.exchange()
+        att, acc = e.exchange_stats()
+        slots = e.slot_map()
+        assert 0 < att.sum() <= 2 * n_ladders and acc.sum() <= att.sum()
+        assert sorted(slots) == list(range(R))
+        assert np.array_equal(slots // (R // n_ladders), np.arange(R) // (R // n_ladders))  # ladders stay apart
+    csr = (rowptr.cpu().numpy().astype(np.int32), col.cpu().numpy(), val.cpu().numpy())
+    prob = oracle.Problem(csr=csr, h=h.cpu().numpy())
+    k = 3
+    s = oracle.init_spins(n, k, seed)
+    assert np.array_equal(e0[:k], [oracle.energy(prob, s[r]) for r in range(k)])
+    # the rule's temperatures are the replicas' current ones: slot i of the ladder at start
+    ref = oracle.sweeps(prob, s, temps[:k], 1, seed=seed, n_threads=k)
+    assert np.array_equal(out["energy_trace"][:, :k], ref["energy_trace"])
+
+
 def test_c2b_assignment_instance_full_size(sg):
     """BASELINE configs[1] parity instance: 100 agents x 100 tasks one-hot
     penalties (lambda = 100), 10 000 spins dense, 1024 replicas."""
