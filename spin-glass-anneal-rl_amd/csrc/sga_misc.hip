@@ -512,9 +512,70 @@ __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
     }
 }
 
+// Problems beyond the int8 LDS capacity: the replica's spins as bits in LDS (as in the sweep
+// kernel's BIG form), 16 waves per replica, one row per wave with eight (colidx, val) loads in
+// flight per lane.  At the 1000-city TSP instance (4e9 entries, 256 replicas) the HBM-spin
+// form above took 10.7 s for the initial energies.
+constexpr int ENERGY_BIG_WAVES = 16, ENERGY_BIG_UNROLL = 8;
+__global__ void __launch_bounds__(64 * ENERGY_BIG_WAVES) energy_csr_bits_kernel(const EnergyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned int *bits = reinterpret_cast<unsigned int *>(smem);
+    double *red = reinterpret_cast<double *>(smem + a.sstride / 8);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    spins_to_bits(a.spins + (long long)r * a.sstride, bits, a.sstride, tid, blockDim.x);
+    __syncthreads();
+    auto spin_f = [&](int c) -> float { return ((bits[c >> 5] >> (c & 31)) & 1u) ? -1.0f : 1.0f; };
+    double e_acc = 0.0, h_acc = 0.0;
+    for (int i = w; i < a.n; i += ENERGY_BIG_WAVES) {
+        const long long beg = a.rowptr[i], end = a.rowptr[i + 1];
+        double acc = 0.0;
+        for (long long j0 = beg + lane; j0 < end; j0 += 64 * ENERGY_BIG_UNROLL) {
+            int c[ENERGY_BIG_UNROLL];
+            float v[ENERGY_BIG_UNROLL];
+#pragma unroll
+            for (int q = 0; q < ENERGY_BIG_UNROLL; ++q) {
+                const long long j = j0 + 64 * q;
+                const bool in = j < end;
+                c[q] = in ? a.colidx[j] : 0;
+                v[q] = in ? a.val[j] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < ENERGY_BIG_UNROLL; ++q) acc += (double)(v[q] * spin_f(c[q]));
+        }
+        const float mv_i = (float)wave_sum(acc);
+        const double si = (double)spin_f(i);
+        e_acc += (double)mv_i * si;
+        h_acc += (double)a.h[i] * si;
+    }
+    if (lane == 0) {
+        red[w] = e_acc;
+        red[ENERGY_BIG_WAVES + w] = h_acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0.0, hs = 0.0;
+        for (int q = 0; q < ENERGY_BIG_WAVES; ++q) {
+            e += red[q];
+            hs += red[ENERGY_BIG_WAVES + q];
+        }
+        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+    }
+}
+
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
     const size_t lds = (size_t)a.sstride + 64;
     if (lds > 160 * 1024 - 256) {
+        const size_t lds_bits = (size_t)a.sstride / 8 + 2 * ENERGY_BIG_WAVES * sizeof(double);
+        if (a.sstride % 128 == 0 && lds_bits <= 160 * 1024 - 256) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_bits_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(energy_csr_bits_kernel, dim3(a.R), dim3(64 * ENERGY_BIG_WAVES), lds_bits,
+                               st, a);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(energy_csr_kernel<false>, dim3(a.R), dim3(256), 64, st, a);
         return hipGetLastError();
     }
