@@ -87,7 +87,7 @@ def host_cores():
     return int(os.environ.get("SGA_CPU_THREADS", cores))
 
 
-def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None, h=None, eng=None):
+def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=None, h=None, eng=None):
     """Time the CPU port on a bounded sample and, with `eng` (already loaded with the same
     couplings), replay the identical sample -- same seed, replica ids, temperatures -- on the GPU:
     the energy gap between the two is the metric's "best-energy gap vs ref" (0 = bit-identical)."""
@@ -96,7 +96,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=8, csr=None
     R = max(cores * budget_replicas_per_core, 1)
     if csr is not None:
         # sparse sweeps are cheap: scale the sample to seconds of CPU work
-        sweeps = max(1, int(sweeps * 40 * 32 * n / max(len(csr[1]), 1) * 10000 / n))
+        sweeps = max(1, int(sweeps * 100 * 32 * n / max(len(csr[1]), 1) * 10000 / n))
         prob = oracle.Problem(csr=csr, h=np.zeros(n, np.float32) if h is None else h)
     else:
         prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
