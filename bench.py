@@ -141,19 +141,18 @@ def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
-def pmc_traffic(storage, n, R):
+def pmc_traffic(tag, kernel):
     """HBM bytes per sweep-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json, written by profiles/summarize_rocprof.py), or None."""
+    (profiles/r*_<tag>_pmc.json, written by profiles/summarize_rocprof.py), or None."""
     import glob
-    tag = f"c2a_{storage}"
-    if (n, R) != (10000, 1024):
+    if tag is None:
         return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
             for name, e in d["kernels"].items():
-                if "sweep_dense_kernel" in name and "hbm_bytes" in e:
+                if kernel in name and "hbm_bytes" in e:
                     return e["hbm_bytes"], os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError):
             continue
@@ -305,7 +304,17 @@ def main():
         bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
     achieved = per_launch_attempts * bytes_per_attempt / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
-    traffic, traffic_src = pmc_traffic(a.storage, n, R) if csr is None else (None, None)
+    # the committed PMC passes were taken on exactly these configurations
+    pmc_tag = None
+    if a.workload == "c2a" and (n, R) == (10000, 1024):
+        pmc_tag = f"c2a_{a.storage}"
+    elif a.workload == "c3" and (n, R) == (10000, 4096):
+        pmc_tag = "c3_csr"
+    elif a.workload == "c4" and R == 1024:
+        pmc_tag = "c4_csr"
+    elif a.workload == "c5" and (a.cities, R) in ((100, 2048), (1000, 256)):
+        pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
+    traffic, traffic_src = pmc_traffic(pmc_tag, "sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
     copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
 
     out = {
