@@ -1347,7 +1347,8 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m,
                       (e->table_m > 0 && std::getenv("SGA_NO_LOOK_AHEAD") == nullptr)
                           ? sga::dense_look_ahead(e->use_t2, e->want_i8, e->acc64,
-                                                  e->use_t2 ? e->cpw_t2 : e->cpw)
+                                                  e->use_t2 ? e->cpw_t2 : e->cpw,
+                                                  e->use_t2 ? e->waves_t2 : e->waves, e->R)
                           : 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);

@@ -88,7 +88,7 @@ hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int 
                               hipStream_t st);
 // updates reduced together by the production sweeps of an integer problem with this layout (1 =
 // one at a time): sweep_dense_impl.h, look-ahead form
-int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw);
+int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R);
 // ternary couplings as two bit-planes (production configuration only)
 hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStream_t st);
 // fp32 [n][n] -> sign plane + non-zero plane, each [n][ld/32] words, plus nnz[n] (as float)

@@ -14,9 +14,11 @@ hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int 
     return acc64 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
                  : launch_sweep_dense_f32(a, waves, cpw, st);
 }
-int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw) {
+int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R) {
     if (acc64 || cpw < 1) return 1;
-    return cpw <= (t2 ? 1 : 3) ? LOOK : 1;  // = has_look_ahead<JT, ACC64, CPW>()
+    const int top = t2 ? 2 : 4;  // = has_look_ahead<JT, ACC64, CPW>() and launch_one's test
+    if (cpw > top || (cpw == top && (waves > 4 || (long long)R * waves > 3 * 1024))) return 1;
+    return LOOK;
 }
 size_t sweep_dense_lds_bytes(long long ld, int table_m) {
     return (size_t)ld + DENSE_LDS_EXTRA + sizeof(float) * (size_t)(table_m + 1);

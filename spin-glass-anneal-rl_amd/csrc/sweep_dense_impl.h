@@ -78,8 +78,15 @@ constexpr int LOOK_SLOT_BYTES = 4 * LOOK;  // one wave's LOOK partial sums (floa
 // the spin(s) at the update site(s) published by their owner waves
 constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * LOOK_SLOT_BYTES + 2 * LOOK * 4;
 
+// Look-ahead kernels whose four rows do not fit the 128 VGPRs of a 1024-thread workgroup (4 chunks
+// per wave, 2 for bit-planes) are built for at most 4 waves per replica instead.
+template <typename JT, int CPW, bool BATCH>
+constexpr int dense_max_threads() {
+    return (BATCH && CPW == (std::is_same<JT, Tern2>::value ? 2 : 4)) ? 256 : 1024;
+}
+
 template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false>
-__global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
+__global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_dense_kernel(const SweepArgs a) {
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     using TR = JTraits<JT>;
@@ -610,7 +617,7 @@ __global__ void __launch_bounds__(1024) sweep_dense_kernel(const SweepArgs a) {
 // fit the registers)
 template <typename JT, bool ACC64, int CPW>
 constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hip) in step
-    return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 1 : 3);
+    return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 2 : 4);
 }
 
 template <typename JT, bool ACC64, int CPW>
@@ -621,7 +628,11 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     const bool lean = sweep_args_are_lean(a);
     void (*kern)(const SweepArgs) = nullptr;
     if constexpr (has_look_ahead<JT, ACC64, CPW>()) {
-        if (lean && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux))
+        // the 256-thread builds use up to 170 VGPRs = 3 waves per SIMD: only while the launch does
+        // not want more than that (n = 1024 fp32: +31 % at 1024 replicas, -5 % at 8192)
+        constexpr bool fat = dense_max_threads<JT, CPW, true>() < 1024;
+        if (lean && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
+            (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024)))
             kern = sweep_dense_kernel<JT, CPW, ACC64, true, true>;
     }
     if (!kern) {

@@ -841,6 +841,8 @@ def test_ternary_bit_plane_storage_matches_oracle(sg, n, R, waves, density):
 @pytest.mark.parametrize("n,R,storage,waves", [
     (3, 3, "f32", 0), (7, 5, "i8", 0), (64, 8, "f32", 0), (65, 4, "t2", 0), (257, 6, "f32", 2),
     (700, 5, "f32", 3), (1023, 4, "i8", 1), (2500, 3, "i8", 3), (3000, 3, "t2", 1), (9000, 2, "t2", 2),
+    # four chunks per wave (two for bit-planes): the 256-thread builds
+    (1000, 3, "f32", 1), (2040, 2, "f32", 2), (4000, 3, "i8", 1), (9000, 2, "t2", 1), (30000, 2, "t2", 2),
 ])
 def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, monkeypatch):
     """Integer problems with short rows reduce four consecutive updates together and replay the
