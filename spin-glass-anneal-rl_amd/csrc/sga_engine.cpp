@@ -207,6 +207,7 @@ namespace {
 
 int elems_per_chunk(bool i8) { return i8 ? 1024 : 256; }
 constexpr int T2_ELEMS_PER_CHUNK = 8192;  // 1 KiB of one bit-plane
+long long t2_row_bits(int n) { return ((long long)n + 127) / 128 * 128; }  // 16-byte granules
 
 // Pick waves-per-replica W and chunks-per-wave CPW for a dense row of C chunks.  Measured on
 // MI355X at n = 10^4, R = 1024 (profiles/r01_geometry_sweep.md): full occupancy (R*W ~ 32
@@ -298,9 +299,13 @@ int ensure_packed(sga_engine *e) {
     HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ld, e->want_i8,
                                     e->diag, e->stream));
     if (e->use_t2) {
-        HIPCHK(hipMalloc(&e->J_bits, sizeof(unsigned int) * 2 * (size_t)e->n * (size_t)(ld / 32)));
+        // a plane's rows are packed at 16-byte granularity, not padded to the kernel's 1-KiB chunks
+        // (n = 10^4: 1264 B instead of 2048 B per row and plane -- this form is bound by the bytes
+        // it pulls through the cache hierarchy); the kernel masks the lanes past a row's end
+        const long long row_bits = t2_row_bits(e->n);
+        HIPCHK(hipMalloc(&e->J_bits, sizeof(unsigned int) * 2 * (size_t)e->n * (size_t)(row_bits / 32)));
         HIPCHK(hipMalloc(&e->row_nnz, sizeof(float) * (size_t)e->n));
-        HIPCHK(sga::launch_repack_tern2(e->J_raw, e->n, e->J_bits, ld, e->row_nnz, e->stream));
+        HIPCHK(sga::launch_repack_tern2(e->J_raw, e->n, e->J_bits, row_bits, e->row_nnz, e->stream));
     }
     e->waves = W;
     e->cpw = CPW;
@@ -807,7 +812,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         } else if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
             a.J = e->J_bits;
             a.J_aux = e->J_packed;
-            a.plane_bytes = (long long)e->n * (e->ld / 8);
+            a.plane_row_bytes = t2_row_bits(e->n) / 8;
+            a.plane_bytes = (long long)e->n * a.plane_row_bytes;
             a.diag = e->row_nnz;
             le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2,
                                             st);
@@ -1344,7 +1350,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
                       (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
-                      e->use_t2 ? e->ld / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m,
+                      e->use_t2 ? t2_row_bits(e->n) / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m,
                       (e->table_m > 0 && std::getenv("SGA_NO_LOOK_AHEAD") == nullptr)
                           ? sga::dense_look_ahead(e->use_t2, e->want_i8, e->acc64,
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,

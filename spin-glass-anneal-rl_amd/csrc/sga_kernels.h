@@ -42,6 +42,7 @@ struct SweepArgs {
     double *dE_trace;            // [R][replay_stride]
     long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
     long long plane_bytes;       // bit-plane form: byte offset of the non-zero plane from the sign plane
+    long long plane_row_bytes;   // bit-plane form: bytes of one row of one plane = round_up(n, 128) / 8
     int n, sstride, R, n_sweeps;
     int site_mode, arith, rule;
     // many-model batches (dense): replica r belongs to model (replica0 + r) / reps_per_model;
@@ -91,8 +92,8 @@ hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int 
 int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R);
 // ternary couplings as two bit-planes (production configuration only)
 hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStream_t st);
-// fp32 [n][n] -> sign plane + non-zero plane, each [n][ld/32] words, plus nnz[n] (as float)
-hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long ld,
+// fp32 [n][n] -> sign plane + non-zero plane, each [n][row_bits/32] words, plus nnz[n] (as float)
+hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long row_bits,
                                float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)

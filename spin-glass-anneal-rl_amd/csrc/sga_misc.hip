@@ -105,10 +105,10 @@ hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *
 // fp32 row -> sign plane / non-zero plane words (bit b of word q = coupling 32 q + b)
 __global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restrict__ J, int n,
                                                             unsigned int *__restrict__ planes,
-                                                            long long ld, float *row_nnz) {
+                                                            long long row_bits, float *row_nnz) {
     __shared__ int cnt[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long long words = ld / 32;
+    const long long words = row_bits / 32;
     unsigned int *S = planes + (long long)i * words;
     unsigned int *Z = planes + (long long)gridDim.x * words + (long long)i * words;
     int nnz = 0;
@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restri
     __syncthreads();
     if (tid == 0) row_nnz[i] = (float)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
 }
-hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long ld,
+hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long row_bits,
                                float *row_nnz, hipStream_t st) {
-    hipLaunchKernelGGL(repack_tern2_kernel, dim3(n), dim3(256), 0, st, J, n, planes, ld, row_nnz);
+    hipLaunchKernelGGL(repack_tern2_kernel, dim3(n), dim3(256), 0, st, J, n, planes, row_bits, row_nnz);
     return hipGetLastError();
 }
 
