@@ -131,8 +131,9 @@ struct sga_engine {
     unsigned int *J_bits = nullptr;  // [2][n][ld/32]
     float *row_nnz = nullptr;        // [n]
     int waves_t2 = 0, cpw_t2 = 0;    // bit-plane geometry (waves/cpw then describe the int8 fallback)
-    void *J_packed = nullptr;  // [n][ld] float | int8
-    long long ld = 0;
+    void *J_packed = nullptr;  // [n][ldj] float | int8
+    long long ld = 0;   // spins per replica (whole chunks)
+    long long ldj = 0;  // row stride of J_packed: n rounded up to 128 bytes
     int waves = 0, cpw = 0;
     int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while nnz < 2^31
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels, big form)
@@ -252,12 +253,13 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     a.spins = e->spins + (long long)r0 * e->sstride;
     a.energy = e->energy + r0;
     a.ld = e->ld;
+    a.ldj = e->ldj;
     a.n = e->n;
     a.sstride = e->sstride;
     a.R = count;
     a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
     a.replica_base = e->replica0 + r0;
-    a.model_stride_j = (long long)e->n * e->ld;
+    a.model_stride_j = (long long)e->n * e->ldj;
     HIPCHK(e->csr ? sga::launch_energy_csr(a, e->stream)
                   : sga::launch_energy_dense(a, e->want_i8, e->stream));
     return SGA_OK;
@@ -294,10 +296,15 @@ int ensure_packed(sga_engine *e) {
     dev_free(e->J_bits);
     dev_free(e->row_nnz);
     const long long rows = (long long)e->n_models * e->n;
-    const size_t bytes = (size_t)rows * ld * (e->want_i8 ? 1 : 4);
+    // rows are packed to 128 bytes, not padded to the kernel's whole chunks (2.4 % fewer bytes per
+    // attempt at n = 10^4); lanes past a row's end re-read its first granule
+    const long long elem = e->want_i8 ? 1 : 4;
+    const long long ldj = ((long long)e->n * elem + 127) / 128 * 128 / elem;
+    const size_t bytes = (size_t)rows * ldj * elem;
     HIPCHK(hipMalloc(&e->J_packed, bytes));
-    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ld, e->want_i8,
+    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ldj, e->want_i8,
                                     e->diag, e->stream));
+    e->ldj = ldj;
     if (e->use_t2) {
         // a plane's rows are packed at 16-byte granularity, not padded to the kernel's 1-KiB chunks
         // (n = 10^4: 1264 B instead of 2048 B per row and plane -- this form is bound by the bytes
@@ -738,7 +745,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // sweeps per launch: aim for ~50 ms of estimated work per launch
     int spl = e->tune_spl;
     if (spl <= 0) {
-        const double row_bytes = e->csr ? 264.0 : (double)e->ld * (e->want_i8 ? 1 : 4);
+        const double row_bytes = e->csr ? 264.0 : (double)e->ldj * (e->want_i8 ? 1 : 4);
         const double per_update = std::max(row_bytes * R / 4.0e12, 1.0e-6);
         const double per_sweep = per_update * n;
         spl = (int)std::min<double>(n_sweeps, std::max(1.0, std::floor(0.05 / per_sweep)));
@@ -781,6 +788,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.accept_trace = d_acc.ptr ? d_acc.ptr + off : nullptr;
         a.dE_trace = d_dE.ptr ? d_dE.ptr + off : nullptr;
         a.ld = e->ld;
+        a.ldj = e->ldj;
         a.n = n;
         a.sstride = e->sstride;
         a.R = R;
@@ -791,7 +799,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.table_m = exact_mode ? 0 : e->table_m;
         a.no_best = exact_mode ? 1 : 0;
         a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
-        a.model_stride_j = (long long)e->n * e->ld;
+        a.model_stride_j = (long long)e->n * e->ldj;
         a.seed_lo = (uint32_t)e->seed;
         a.seed_hi = (uint32_t)(e->seed >> 32);
         a.sweep0 = e->sweeps_done + (uint32_t)k0;
@@ -890,7 +898,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         sga::PointArgs a{};
         const long long model = e->n_models > 1 ? (e->replica0 + r) / (e->Rg / e->n_models) : 0;
         a.J = e->J_packed;
-        a.model_offset_j = model * e->n * e->ld;
+        a.model_offset_j = model * e->n * e->ldj;
         a.rowptr = e->rowptr64;
         a.colidx = e->colidx;
         a.val = e->val;
@@ -902,6 +910,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         a.sites = d_sites;
         a.out = d_out;
         a.ld = e->ld;
+        a.ldj = e->ldj;
         a.n = e->n;
         a.count = count;
         a.op = op;
@@ -1350,7 +1359,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
                       (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
-                      e->use_t2 ? t2_row_bits(e->n) / 4 : e->ld * (e->want_i8 ? 1 : 4), e->table_m,
+                      e->use_t2 ? t2_row_bits(e->n) / 4 : e->ldj * (e->want_i8 ? 1 : 4), e->table_m,
                       (e->table_m > 0 && std::getenv("SGA_NO_LOOK_AHEAD") == nullptr)
                           ? sga::dense_look_ahead(e->use_t2, e->want_i8, e->acc64,
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,

@@ -40,7 +40,8 @@ struct SweepArgs {
     double *energy_trace;        // [n_sweeps][R]
     uint8_t *accept_trace;       // [R][replay_stride]
     double *dE_trace;            // [R][replay_stride]
-    long long ld;                // dense row stride in elements (= W * CPW * elems per chunk)
+    long long ld;                // dense: spins per replica in LDS / HBM (= W * CPW * elems per chunk)
+    long long ldj;               // dense: row stride of J in elements (n rounded up to 128 bytes)
     long long plane_bytes;       // bit-plane form: byte offset of the non-zero plane from the sign plane
     long long plane_row_bytes;   // bit-plane form: bytes of one row of one plane = round_up(n, 128) / 8
     int n, sstride, R, n_sweeps;
@@ -67,7 +68,7 @@ struct EnergyArgs {
     const float *h;
     const int8_t *spins;
     double *energy;
-    long long ld;
+    long long ld, ldj;
     int n, sstride, R;
 };
 
@@ -103,7 +104,7 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
 hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
                              uint32_t seed_hi, uint32_t replica0, hipStream_t st);
-// J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded, plus diag[n]
+// J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded (ld = the packed row stride), plus diag[n]
 hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, int n, void *out,
                                long long ld, bool to_i8, float *diag, hipStream_t st);
 // flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is outside
@@ -148,7 +149,7 @@ struct PointArgs {
     unsigned long long *n_accepted;
     const int32_t *sites;  // [count]
     double *out;           // [count] fields (op 0) | out[0] = dE, out[1] = accepted (ops 1, 2)
-    long long ld;
+    long long ld, ldj;
     int n, count, op;      // op 0: fields, 1: flip, 2: metropolis
     int arith, rule;
     double T;

@@ -418,9 +418,9 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
     const float *hvec = a.h + (long long)model * a.n;
     double e_acc = 0.0, h_acc = 0.0;
     for (int i = w; i < a.n; i += 4) {
-        const JT *row = J + (long long)i * a.ld;
+        const JT *row = J + (long long)i * a.ldj;
         double acc = 0.0;
-        for (long long c = lane * EPL; c < a.ld; c += EPC) {
+        for (long long c = lane * EPL; c < a.ldj; c += EPC) {
             if constexpr (sizeof(JT) == 4) {
                 const float4 x = *reinterpret_cast<const float4 *>(row + c);
                 const int sw = *reinterpret_cast<const int *>(s + c);
@@ -668,8 +668,8 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
             for (long long j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
                 acc += (double)(a.val[j] * (float)a.spins[a.colidx[j]]);
         } else {
-            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ld;
-            for (long long c = (long long)tid * EPL; c < a.ld; c += 4 * EPC) {
+            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
+            for (long long c = (long long)tid * EPL; c < a.ldj; c += 4 * EPC) {
                 if constexpr (sizeof(JT) == 4) {
                     const float4 x = *reinterpret_cast<const float4 *>(row + c);
                     const int sw = *reinterpret_cast<const int *>(a.spins + c);

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
     // element-addressed for fp32 / int8; the bit-plane form addresses bytes (two planes)
     using JE = typename std::conditional<BITS, unsigned char, JT>::type;
     constexpr int LANE_STEP = BITS ? 16 : EPL, CHUNK_STEP = BITS ? 1024 : EPC;
-    const long long row_step = BITS ? a.plane_row_bytes : a.ld;
+    const long long row_step = BITS ? a.plane_row_bytes : a.ldj;
     // A row is addressed as (uniform row base) + (32-bit lane offset): the scalar-base form of
     // global_load needs one shared offset VGPR instead of a 64-bit address pair per load.
     const JE *Jbase = reinterpret_cast<const JE *>(a.J) + (BITS ? 0 : model * a.model_stride_j);
@@ -206,26 +206,23 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
         // default cache policy on purpose: non-temporal loads measured 3-5 % slower here (part
         // of J is re-served by the 256 MB Infinity Cache; profiles/r01_experiments.md)
         const unsigned char *q = reinterpret_cast<const unsigned char *>(p);
-        // bit-plane rows are packed to 16 bytes, not to whole chunks: a lane past the row's end
-        // reads the row's first granule instead and its non-zero bits are cleared
+        // Rows are packed to 128 bytes (16 for the bit-planes), not to whole chunks: a lane past
+        // the row's end reads the row's first granule instead -- no extra traffic, and the product
+        // with the zero pad spins is zero (bit-planes: its non-zero bits are cleared)
         bool in = true;
         unsigned long long off;
         if constexpr (SCALAR_BASE) {
             // byte offset in 32 bits, opaque to the optimiser (a hoisted 64-bit zero extension of
             // it loses the base + zext(VGPR) address form)
             unsigned int o32 = (lane_off + (unsigned int)k * (unsigned int)kstep) * (unsigned int)sizeof(JE);
-            if constexpr (BITS) {
-                in = o32 < (unsigned int)row_step;
-                o32 = in ? o32 : 0u;
-            }
+            in = o32 < (unsigned int)row_step * (unsigned int)sizeof(JE);
+            o32 = in ? o32 : 0u;
             asm volatile("" : "+v"(o32));
             off = o32;
         } else {
             off = (unsigned long long)((long long)k * kstep) * sizeof(JE);
-            if constexpr (BITS) {
-                in = (unsigned long long)lane_off + off < (unsigned long long)row_step;
-                off = in ? off : 0ull - (unsigned long long)lane_off;
-            }
+            in = ((unsigned long long)lane_off * sizeof(JE)) + off < (unsigned long long)row_step * sizeof(JE);
+            off = in ? off : 0ull - (unsigned long long)lane_off * sizeof(JE);
         }
         if constexpr (BITS) {
             const int keep = in ? -1 : 0;
@@ -401,9 +398,9 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
         int kP = 0, tP = 0;  // producer cursor: first update of the next batch to request
         auto cross = [&](int sm, int sl) -> float {  // J[sm][sl]: uniform address, one element
             if constexpr (BITS) {
-                return (float)reinterpret_cast<const int8_t *>(a.J_aux)[(long long)sm * a.ld + sl];
+                return (float)reinterpret_cast<const int8_t *>(a.J_aux)[(long long)sm * a.ldj + sl];
             } else {
-                return (float)(Jbase + (long long)sm * a.ld)[sl];
+                return (float)(Jbase + (long long)sm * a.ldj)[sl];
             }
         };
         auto request = [&](Meta &mt) {
