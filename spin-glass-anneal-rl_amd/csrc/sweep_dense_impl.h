@@ -4,19 +4,23 @@
 // fallback :371-398) and SpinDynamics.sweep (core/spin_dynamics.py:73-94) batched over the
 // replicas of ParallelTempering._parallel_sweeps (annealing/parallel_tempering.py:191-203).
 //
-// Mapping (DESIGN.md "Dense sweep kernel"):
+// Mapping:
 //   * one workgroup per replica, W waves (W chosen on the host so R*W waves fill the chip);
 //   * a coupling row J[site,:] is cut into 1-KiB chunks (64 lanes x 16 B, one
 //     global_load_dwordx4 per wave); wave w owns chunks w, w+W, w+2W, ... -- CPW of them --
-//     and keeps them in VGPRs: no LDS round trip for data that is streamed once;
-//   * the replica's spins live in LDS as int8; each wave reads only the bytes under its
-//     own chunks, and only the owning wave ever rewrites them (no cross-wave hazard);
-//   * the single-spin Markov chain is serial, but the SITE sequence is known ahead of
-//     time from the counter RNG, so row t+1 is prefetched into a second register buffer
-//     while row t is reduced: CPW KiB per wave stay in flight across the per-update
-//     barrier (plain loads survive s_barrier);
+//     and keeps them in VGPRs: no LDS round trip for data that is streamed once.  Rows are
+//     packed to 128 bytes in HBM; a lane past a row's end re-reads the row's first granule;
+//   * the replica's spins live in LDS as int8 (bits in the bit-plane form), padded with zeros
+//     to whole chunks; each wave reads only the bytes under its own chunks, and only the owning
+//     wave ever rewrites them (no cross-wave hazard);
+//   * the single-spin Markov chain is serial, but the SITE sequence is known ahead of time
+//     from the counter RNG, so row t+1 is requested into the other slot of a two-slot register
+//     ring while row t is reduced: CPW KiB per wave stay in flight across the per-update
+//     barrier (plain loads survive s_barrier, the waits are counted vmcnt);
 //   * per update: lane partial -> DPP wave sum -> W partials through LDS (one barrier,
 //     double-buffered slots) -> every thread evaluates the same accept rule;
+//   * BATCH = the look-ahead form for short rows of integer problems: four updates reduced
+//     together, the chain replayed on scalars (see the comment at its loop);
 //   * CPW = 0 selects the STREAMING form for rows too long for the register buffers
 //     (n > 40 960 fp32 / 163 840 int8 elements per 16 waves x 10 chunks): each wave walks its
 //     chunks in batches of four loads and reduces them on the fly (no cross-update prefetch;
