@@ -118,6 +118,7 @@ struct DevOut {
 
 struct sga_engine {
     int device = 0;
+    int cus = 256;  // compute units of the device
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
@@ -341,6 +342,11 @@ int sga_create(int device, sga_engine **out) {
     sga_engine *eng = new (std::nothrow) sga_engine();
     if (!eng) return fail(SGA_ERR_MEMORY, "host allocation failed");
     eng->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            eng->cus = cus;
+    }
     e = hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete eng;
@@ -592,6 +598,21 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         e->big = sga::csr_waves_per_block(e->sstride, 0) < 1 || !e->rowptr ||
                  std::getenv("SGA_FORCE_CSR_BIG") != nullptr;
         const double deg = (double)e->nnz / e->n;
+        // ... or when the int8 spins fit, but not for all replicas at once: workgroups beyond the
+        // LDS-resident set run as a second, mostly empty round (C4: 50 KB per replica = 3 per CU
+        // = 768 of 1024 replicas resident, 4.7e8 attempts/s; as bits all are resident: 6.8e8)
+        if (!e->big && std::getenv("SGA_NO_CSR_BITS") == nullptr) {
+            const int bits_stride = (e->n + 127) / 128 * 128;
+            const bool wide_i8 = e->tune_waves > 1 || (e->tune_waves == 0 && deg >= 192.0 && R_local <= 1024);
+            const int rpb = wide_i8 ? 1 : std::max(1, sga::csr_waves_per_block(e->sstride, e->table_m));
+            const size_t wg_i8 = sga::csr_lds_bytes(e->sstride, e->table_m, false) * (size_t)rpb;
+            const size_t wg_bits = sga::csr_lds_bytes(bits_stride, e->table_m, true);
+            const long long budget = 160 * 1024 - 256;
+            const long long res_i8 = (long long)e->cus * rpb * std::min<long long>(8, budget / (long long)wg_i8);
+            const long long res_bits = (long long)e->cus * std::min<long long>(16, budget / (long long)wg_bits);
+            if (R_local > res_i8 && res_bits > res_i8 && sga::csr_big_fits(bits_stride, e->table_m))
+                e->big = true;
+        }
         if (e->big) {
             e->sstride = (e->n + 127) / 128 * 128;
             if (!sga::csr_big_fits(e->sstride, 0))

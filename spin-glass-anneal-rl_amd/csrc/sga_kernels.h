@@ -99,6 +99,7 @@ hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 bool csr_big_fits(int sstride, int table_m);         // spins as bits: one replica per workgroup
+size_t csr_lds_bytes(int sstride, int table_m, bool bits);  // LDS of one replica (spins + table)
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);

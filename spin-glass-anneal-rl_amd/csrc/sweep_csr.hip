@@ -348,6 +348,10 @@ static size_t csr_lds_per_replica(int sstride, int table_m, bool big = false) {
     return (size_t)(big ? sstride / 8 : sstride) + sizeof(float) * (size_t)((table_m + 2) & ~1);
 }
 
+size_t csr_lds_bytes(int sstride, int table_m, bool bits) {
+    return csr_lds_per_replica(sstride, table_m, bits);
+}
+
 constexpr size_t CSR_LDS_BUDGET = 160 * 1024 - 256;
 
 int csr_waves_per_block(int sstride, int table_m) {
