@@ -231,6 +231,9 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
         double cost = 4.0 * pad + 0.05 * std::fabs(std::log2(w / target));
         if (cpw < 4 && w > 1) cost += 0.5 * (4 - cpw);   // too little in flight per wave
         if (w > 2 && (w % 4) != 0) cost += 0.03;          // uneven over the 4 SIMDs
+        // 9-10 chunks: at the edge of the register file, no look-ahead form (n = 10^4 fp32,
+        // 4096 replicas: 4 waves x 10 chunks 1.53e8 attempts/s, 5-16 waves 1.9-2.0e8)
+        if (cpw > 8) cost += 0.2;
         if (cost < best_cost) {
             best_cost = cost;
             W = w;

@@ -17,7 +17,9 @@ hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int 
 int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R) {
     if (acc64 || cpw < 1) return 1;
     const int top = t2 ? 2 : 4;  // = has_look_ahead<JT, ACC64, CPW>() and launch_one's test
-    if (cpw > top || (cpw == top && (waves > 4 || (long long)R * waves > 3 * 1024))) return 1;
+    if (cpw > (t2 ? 4 : 6)) return 1;
+    if (cpw > top) return 2;
+    if (cpw == top && (waves > 4 || (long long)R * waves > 3 * 1024)) return 1;
     return LOOK;
 }
 size_t sweep_dense_lds_bytes(long long ld, int table_m) {

@@ -75,7 +75,7 @@ struct AccType<int8_t, ACC64> {
 };
 
 constexpr int PART_SLOT_BYTES = 8;
-// Look-ahead form: LOOK updates are reduced together, one barrier for all of them.
+// Look-ahead form: up to LOOK updates are reduced together, one barrier for all of them.
 constexpr int LOOK = 4;
 constexpr int LOOK_SLOT_BYTES = 4 * LOOK;  // one wave's LOOK partial sums (float | int)
 // behind the spins: [2][MAX_WAVES] partial-sum slots (8 B, or 16 B in the look-ahead form), then
@@ -84,6 +84,10 @@ constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * LOOK_SLOT_BYTES + 2 * LOOK * 4;
 
 // Look-ahead kernels whose four rows do not fit the 128 VGPRs of a 1024-thread workgroup (4 chunks
 // per wave, 2 for bit-planes) are built for at most 4 waves per replica instead.
+template <typename JT, int CPW>
+constexpr int look_updates() {  // updates per batch of the look-ahead form
+    return CPW <= (std::is_same<JT, Tern2>::value ? 2 : 4) ? 4 : 2;
+}
 template <typename JT, int CPW, bool BATCH>
 constexpr int dense_max_threads() {
     return (BATCH && CPW == (std::is_same<JT, Tern2>::value ? 2 : 4)) ? 256 : 1024;
@@ -388,7 +392,9 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
         // integers below 2^24, so the corrected sums are exactly the sequential ones and every
         // decision, energy and spin is bit-identical to the one-update-at-a-time form.
         static_assert(LEAN && !ACC64 && CPW >= 1, "look-ahead: production form, exact fp32 / int sums");
-        constexpr int L = LOOK, NX = L * (L - 1) / 2;
+        // four updates per batch while four rows fit the registers, two for longer rows
+        constexpr int L = look_updates<JT, CPW>(), NX = L * (L - 1) / 2;
+        static_assert(L == 2 || L == 4, "one or two RNG pairs per batch");
         unsigned char *lpart = part_raw;                                             // [2][MAX_WAVES][L]
         int *lsi = reinterpret_cast<int *>(part_raw + 2 * MAX_WAVES * LOOK_SLOT_BYTES);  // [2][L]
         struct Meta {  // what a batch needs besides its rows
@@ -411,9 +417,13 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
             const bool live = kP < a.n_sweeps;
             mt.cnt = live ? (n - tP < L ? n - tP : L) : 0;
             const UpdatePair p0 = rng.get(a, r, kP, tP >> 1, mt.cnt > 0, lane);
-            const UpdatePair p1 = rng.get(a, r, kP, (tP >> 1) + 1, mt.cnt > 2, lane);
-            mt.site[0] = p0.sA, mt.site[1] = p0.sB, mt.site[2] = p1.sA, mt.site[3] = p1.sB;
-            mt.u[0] = p0.uA, mt.u[1] = p0.uB, mt.u[2] = p1.uA, mt.u[3] = p1.uB;
+            mt.site[0] = p0.sA, mt.site[1] = p0.sB;
+            mt.u[0] = p0.uA, mt.u[1] = p0.uB;
+            if constexpr (L == 4) {
+                const UpdatePair p1 = rng.get(a, r, kP, (tP >> 1) + 1, mt.cnt > 2, lane);
+                mt.site[2] = p1.sA, mt.site[3] = p1.sB;
+                mt.u[2] = p1.uA, mt.u[3] = p1.uB;
+            }
 #pragma unroll
             for (int m = 0; m < L; ++m) {
                 if (m >= mt.cnt) mt.site[m] = 0;  // the half-used last pair of an odd sweep
@@ -431,7 +441,6 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
                 ++kP;
             }
         };
-        static_assert(L == 4, "two RNG pairs per batch");
         Meta cur;
         request(cur);
         int k = 0, t = 0, lp = 0;
@@ -631,7 +640,7 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
 // fit the registers)
 template <typename JT, bool ACC64, int CPW>
 constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hip) in step
-    return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 2 : 4);
+    return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 4 : 6);
 }
 
 template <typename JT, bool ACC64, int CPW>

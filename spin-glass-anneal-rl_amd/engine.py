@@ -23,6 +23,13 @@ def _is_tensor(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+def _producer_done(t):
+    """The engine reads device buffers on its own stream: whatever torch still has queued on its
+    current stream to produce `t` must have finished first (free when use_stream() shares it)."""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def _buf(x, np_dtype, torch_dtype_name):
     """Return (pointer, keepalive) for a numpy array / torch tensor / None."""
     if x is None:
@@ -32,6 +39,7 @@ def _buf(x, np_dtype, torch_dtype_name):
         t = x.detach()
         if t.dtype != want or not t.is_contiguous():
             t = t.to(want).contiguous()
+        _producer_done(t)
         return C.c_void_p(t.data_ptr()), t
     a = np.ascontiguousarray(x, dtype=np_dtype)
     return a.ctypes.data_as(C.c_void_p), a
@@ -107,6 +115,7 @@ class AnnealEngine:
                 Jt = Jt.float()
             if Jt.stride(1) != 1:
                 Jt = Jt.contiguous()
+            _producer_done(Jt)
             n, ld, jp, keep = Jt.shape[0], Jt.stride(0), C.c_void_p(Jt.data_ptr()), Jt
         else:
             Ja = np.ascontiguousarray(J, dtype=np.float32)
@@ -125,6 +134,7 @@ class AnnealEngine:
         sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8, "t2": N.J_T2}[storage]
         if _is_tensor(J):
             Jt = J.detach().float().contiguous()
+            _producer_done(Jt)
             M, n = Jt.shape[0], Jt.shape[1]
             jp, keep = C.c_void_p(Jt.data_ptr()), Jt
         else:
