@@ -843,6 +843,8 @@ def test_ternary_bit_plane_storage_matches_oracle(sg, n, R, waves, density):
     (700, 5, "f32", 3), (1023, 4, "i8", 1), (2500, 3, "i8", 3), (3000, 3, "t2", 1), (9000, 2, "t2", 2),
     # four chunks per wave (two for bit-planes): the 256-thread builds
     (1000, 3, "f32", 1), (2040, 2, "f32", 2), (4000, 3, "i8", 1), (9000, 2, "t2", 1), (30000, 2, "t2", 2),
+    # five / six chunks per wave (three / four for bit-planes): two updates per batch
+    (1500, 3, "f32", 1), (2600, 2, "f32", 2), (5000, 2, "i8", 1), (20000, 2, "t2", 1), (25000, 2, "t2", 1),
 ])
 def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, monkeypatch):
     """Integer problems with short rows reduce four consecutive updates together and replay the
@@ -872,7 +874,8 @@ def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, m
                 e.set_tuning(waves_per_replica=waves)
             e.set_dense(J, h, storage=storage)
             e.init_replicas(R, seed=seed)
-            assert ("look_ahead=4" in e.describe()) == look, e.describe()
+            batched = "look_ahead=4" in e.describe() or "look_ahead=2" in e.describe()
+            assert batched == look, e.describe()
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
             assert np.array_equal(out["energy_trace"], ref["energy_trace"])
