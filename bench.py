@@ -110,6 +110,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
     oracle.set_exact_f32(False)
     gap = None
     if eng is not None:  # outside every timed region
+        eng.set_tuning(waves_per_replica=0, sweeps_per_launch=0)
         eng.init_replicas(R, seed=seed)
         eng.set_temperatures(temps)
         e_start = eng.energies()  # the CPU sample tracked the change from these
@@ -177,6 +178,10 @@ def main():
     ap.add_argument("--storage", default="f32", choices=["f32", "i8", "t2"])
     ap.add_argument("--exchange-interval", type=int, default=10)
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the heuristic launch geometry instead of letting the engine time its "
+                         "feasible geometries on the resident replicas before the warm-up "
+                         "(sga_autotune: part of the set-up, results unaffected)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -259,6 +264,9 @@ def main():
     ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
                           slot_temps=ladder, n_ladders=n_ladders, dist=dist, device=comm_dev)
+    autotuned = (not a.no_autotune) and csr is None and a.waves == 0
+    if autotuned:
+        eng.autotune()  # keeps its winner; sweeps per launch stay as set above
     geometry = eng.describe()
 
     def barrier():
@@ -338,6 +346,7 @@ def main():
                                f"{a.exchange_interval}",
                    "spins": n, "replicas_per_gpu": R, "replicas_total": Rg,
                    "coupling_storage": a.storage if csr is None else "csr", "geometry": geometry,
+                   "geometry_autotuned": autotuned,
                    "best_energy_rank0": best_e},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -358,9 +367,12 @@ def main():
         out["variants"] = {}
         for name, st, bytes_per in (("int8_couplings", "i8", float(n)),
                                     ("bit_plane_couplings", "t2", n / 4.0)):
+            eng.set_tuning(waves_per_replica=0, sweeps_per_launch=1)  # not the fp32 winner
             eng.set_dense(J, h, storage=st)
             pt2 = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder,
                                    n_ladders=1, dist=None, device=comm_dev)
+            if autotuned:
+                eng.autotune()
             pt2.sweep(1)
             torch.cuda.synchronize()
             eng.enable_timing(True)

@@ -209,6 +209,12 @@ int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, in
 int sga_describe(sga_engine *e, char *buf, int buflen);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
+/* Measured choice of the dense launch geometry: times the sweep kernel for every feasible
+ * waves-per-replica on the current replicas (a few sweeps each) and keeps the fastest.  The
+ * chain does not depend on the geometry and the replicas' state, best states and counters are
+ * restored, so results are unaffected; timing statistics are reset.  No-op for CSR problems.
+ * (No reference counterpart: the reference has no launch geometry.) */
+int sga_autotune(sga_engine *e, double *best_ms_per_sweep);
 
 #ifdef __cplusplus
 }

@@ -287,15 +287,24 @@ int ensure_packed(sga_engine *e) {
         CPW = Wb * Cb;
         if (e->J_packed && e->J_bits && e->ld == ld && e->waves_t2 == Wb && e->cpw_t2 == Cb)
             return SGA_OK;
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
+            return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
         e->waves_t2 = Wb;
         e->cpw_t2 = Cb;
     } else {
         choose_geometry(e->n, elems_per_chunk(e->want_i8), std::max(e->R, 1), e->tune_waves, W, CPW);
         ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
         if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
+            return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     }
-    if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
-        return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
+    if (e->J_packed && (!e->use_t2 || e->J_bits)) {
+        // only the launch geometry changed: the packed matrices are laid out by n, not by it
+        e->waves = W;
+        e->cpw = CPW;
+        e->ld = ld;
+        return SGA_OK;
+    }
     dev_free(e->J_packed);
     dev_free(e->J_bits);
     dev_free(e->row_nnz);
@@ -396,6 +405,123 @@ int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch) 
         return fail(SGA_ERR_INVALID, "bad tuning values");
     e->tune_waves = waves_per_replica;
     e->tune_spl = sweeps_per_launch;
+    return SGA_OK;
+}
+
+// Measured choice of the dense launch geometry.  Every candidate (waves per replica) runs the
+// real sweep kernel on the real replicas for a trial; the chain does not depend on the geometry,
+// and spins / energies / best states / counters are put back afterwards, so the run continues
+// exactly as if this call had not happened.
+int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas (call sga_init_replicas)");
+    if (best_ms_per_sweep) *best_ms_per_sweep = 0.0;
+    if (e->csr) return SGA_OK;  // CSR forms are chosen from LDS residency (sga_init_replicas)
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int n = e->n, R = e->R;
+    const size_t cb = (size_t)R * n;
+    // the state, independent of the spin stride
+    int8_t *spins_c = nullptr, *best_c = nullptr;
+    double *en = nullptr, *ben = nullptr;
+    unsigned long long *acc = nullptr;
+    auto release = [&]() {
+        dev_free(spins_c);
+        dev_free(best_c);
+        dev_free(en);
+        dev_free(ben);
+        dev_free(acc);
+    };
+    hipError_t he = hipMalloc(&spins_c, cb);
+    if (he == hipSuccess) he = hipMalloc(&best_c, cb);
+    if (he == hipSuccess) he = hipMalloc(&en, sizeof(double) * R);
+    if (he == hipSuccess) he = hipMalloc(&ben, sizeof(double) * R);
+    if (he == hipSuccess) he = hipMalloc(&acc, sizeof(unsigned long long) * R);
+    if (he == hipSuccess) he = sga::launch_unpad_spins(e->spins, e->sstride, spins_c, n, R, e->stream);
+    if (he == hipSuccess) he = sga::launch_unpad_spins(e->best_spins, e->sstride, best_c, n, R, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(en, e->energy, sizeof(double) * R, hipMemcpyDeviceToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(ben, e->best_energy, sizeof(double) * R, hipMemcpyDeviceToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(acc, e->n_acc, sizeof(unsigned long long) * R, hipMemcpyDeviceToDevice, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) {
+        release();
+        return fail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    }
+    const uint32_t sweeps_done = e->sweeps_done;
+    const long long attempted = e->attempted;
+    const int user_waves = e->tune_waves, user_spl = e->tune_spl;
+    const bool was_timing = e->timing;
+
+    // lay the replicas out for `waves` (0 = heuristic) and put the saved state back
+    auto layout = [&](int waves) -> int {
+        e->tune_waves = waves;
+        int rc = ensure_packed(e);
+        if (rc != SGA_OK) return rc;
+        if (e->sstride != (int)e->ld) {
+            dev_free(e->spins);
+            dev_free(e->best_spins);
+            e->sstride = (int)e->ld;
+            HIPCHK(hipMalloc(&e->spins, (size_t)R * e->sstride));
+            HIPCHK(hipMalloc(&e->best_spins, (size_t)R * e->sstride));
+        }
+        HIPCHK(sga::launch_pad_spins(spins_c, n, e->spins, e->sstride, R, e->stream));
+        HIPCHK(sga::launch_pad_spins(best_c, n, e->best_spins, e->sstride, R, e->stream));
+        HIPCHK(hipMemcpyAsync(e->energy, en, sizeof(double) * R, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->best_energy, ben, sizeof(double) * R, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->n_acc, acc, sizeof(unsigned long long) * R, hipMemcpyDeviceToDevice, e->stream));
+        e->sweeps_done = sweeps_done;
+        e->attempted = attempted;
+        return SGA_OK;
+    };
+    // kernel time of k sweeps in one launch, ms
+    auto timed = [&](int k, double &ms) -> int {
+        e->tune_spl = k;
+        e->timing = true;
+        int64_t launches = 0;
+        double t = 0.0;
+        (void)sga_get_kernel_time(e, &launches, &t, 1);
+        int rc = sga_sweep(e, k, SGA_SITE_RANDOM, SGA_ARITH_F64, nullptr, 0, 0, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
+        if (rc != SGA_OK) return rc;
+        rc = sga_get_kernel_time(e, &launches, &t, 1);
+        ms = t;
+        return rc;
+    };
+
+    const int epc = e->use_t2 ? T2_ELEMS_PER_CHUNK : elems_per_chunk(e->want_i8);
+    const int max_cpw = e->use_t2 ? sga::T2_MAX_CPW : 8;
+    const int C = (n + epc - 1) / epc;
+    int best_w = -1;
+    double best = 1e300;
+    int rc = SGA_OK;
+    for (int w = 0; w <= sga::MAX_WAVES && rc == SGA_OK; ++w) {  // 0 = the heuristic's own choice
+        if (w > 0) {
+            const int cpw = (C + w - 1) / w;
+            if (cpw > max_cpw || (w > C && w > 1)) continue;
+        }
+        rc = layout(w);
+        if (rc != SGA_OK) break;
+        double t1 = 0.0, t = 0.0;
+        rc = timed(1, t1);  // warm-up and scale
+        if (rc != SGA_OK) break;
+        const int k = t1 > 0.0 ? (int)std::min(64.0, std::max(1.0, std::ceil(2.0 / t1))) : 1;
+        rc = timed(k, t);
+        if (rc != SGA_OK) break;
+        const double per = t / k;
+        if (per < best) {
+            best = per;
+            best_w = w;
+        }
+    }
+    // leave with the winner (or the caller's setting if something failed) and the saved state
+    e->timing = was_timing;
+    e->tune_spl = user_spl;
+    const int final_rc = layout(rc == SGA_OK && best_w >= 0 ? best_w : user_waves);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    release();
+    if (rc != SGA_OK) return rc;
+    if (final_rc != SGA_OK) return final_rc;
+    if (best_ms_per_sweep) *best_ms_per_sweep = best;
     return SGA_OK;
 }
 

@@ -104,6 +104,13 @@ class AnnealEngine:
         N.check(self._lib.sga_set_tuning(self._h, int(waves_per_replica), int(sweeps_per_launch)),
                 "sga_set_tuning")
 
+    def autotune(self) -> float:
+        """Time every feasible waves-per-replica on the current replicas and keep the fastest
+        (dense problems; results are unaffected).  Returns the best kernel ms per sweep."""
+        ms = C.c_double(0.0)
+        N.check(self._lib.sga_autotune(self._h, C.byref(ms)), "sga_autotune")
+        return float(ms.value)
+
     # ------------------------------------------------------------------ problem
     def set_dense(self, J, h, storage: str = "auto"):
         sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8, "t2": N.J_T2}[storage]

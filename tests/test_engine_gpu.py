@@ -888,6 +888,43 @@ def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, m
     assert np.array_equal(got[True], got[False])
 
 
+@pytest.mark.parametrize("n,R,storage", [(700, 6, "f32"), (3000, 5, "i8"), (9000, 3, "t2"), (5000, 4, "f32")])
+def test_autotune_keeps_the_chain_and_the_state(sg, n, R, storage):
+    """sga_autotune times every feasible waves-per-replica on the live replicas.  Called in the
+    middle of a run it must leave spins, energies, best states, acceptance counters and the random
+    stream exactly where they were: the continued run equals the oracle's uninterrupted one."""
+    rng = np.random.RandomState(n)
+    J = pm1(n, 7 + n)
+    if storage == "t2":
+        J = np.triu(J * (rng.rand(n, n) < 0.5), 1)
+        J = (J + J.T).astype(np.float32)
+    if storage == "f32" and n == 5000:
+        J = gauss(n, 3)                                   # real couplings: general path
+    h = (rng.randn(n) if n == 5000 else rng.randint(-1, 2, n)).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    seed = 4242 + n
+    temps = ladder(R, 2.0 * np.sqrt(n), 0.5)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, 5, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, h, storage=storage)
+        e.init_replicas(R, seed=seed)
+        e.set_ladder(temps)
+        a = e.sweep(2, energy_trace=True)
+        before = e.describe()
+        ms = e.autotune()
+        assert ms > 0.0
+        b = e.sweep(3, energy_trace=True)
+        assert np.array_equal(np.concatenate([a["energy_trace"], b["energy_trace"]]), ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"])
+        assert e.counters()[0] == 5
+        for r in range(R):
+            be, bs, _ = e.best(r)
+            assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+        assert e.describe().split("waves_per_replica")[0] == before.split("waves_per_replica")[0]
+
+
 def test_bit_plane_storage_needs_ternary_couplings(sg):
     with sg.AnnealEngine(0) as e:
         with pytest.raises(sg.AnnealingError):
