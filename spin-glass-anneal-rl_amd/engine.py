@@ -111,6 +111,16 @@ class AnnealEngine:
         N.check(self._lib.sga_autotune(self._h, C.byref(ms)), "sga_autotune")
         return float(ms.value)
 
+    def maybe_autotune(self, n_sweeps: int, setting: Optional[bool] = None) -> bool:
+        """Host-loop helper: autotune when asked to (`setting=True`), never when `False`, and by
+        default (`None`) only when the run is long enough to pay for the ~30 trial sweeps."""
+        if setting is False or self.R <= 0:
+            return False
+        if setting is None and float(self.n) ** 2 * self.R * n_sweeps < 2e13:
+            return False
+        self.autotune()
+        return True
+
     # ------------------------------------------------------------------ problem
     def set_dense(self, J, h, storage: str = "auto"):
         sel = {"auto": N.J_AUTO, "f32": N.J_F32, "i8": N.J_I8, "t2": N.J_T2}[storage]

@@ -39,6 +39,7 @@ class ParallelTemperingConfig:
     # build-specific
     coupling_storage: str = "auto"
     device_index: Optional[int] = None
+    autotune: Optional[bool] = None       # measured launch geometry (None: for long runs only)
 
 
 class ParallelTempering:
@@ -79,6 +80,7 @@ class ParallelTempering:
             eng.init_replicas(R, seed=fresh_seed(cfg.random_seed),
                               s0=None if _replay is None else _replay["s0"])
             eng.set_ladder(temps, 1)
+            eng.maybe_autotune(cfg.n_sweeps, cfg.autotune)
             slot_to_rep = np.arange(R, dtype=np.int32)
             acc_prev = np.zeros(R, np.int64)
             rnd = ucur = 0

@@ -49,7 +49,8 @@ class SpinGlassScheduler:
     def anneal(self, ising_model: IsingModel, n_replicas: int = 1000, n_sweeps: int = 10000,
                beta_schedule: Union[str, Sequence[float]] = "geometric", beta_min: float = 0.1,
                beta_max: float = 10.0, exchange_interval: int = 10, n_ladders: int = 1,
-               coupling_storage: str = "auto", record_interval: int = 10) -> AnnealingResult:
+               coupling_storage: str = "auto", record_interval: int = 10,
+               autotune: Optional[bool] = None) -> AnnealingResult:
         if n_replicas < 1 or n_sweeps < 1 or n_replicas % n_ladders:
             raise ConfigurationError("bad replica / sweep / ladder counts")
         t0 = time.time()
@@ -67,6 +68,7 @@ class SpinGlassScheduler:
             ising_model.load_into(eng, storage=coupling_storage)
             eng.init_replicas(n_replicas, seed=fresh_seed(self.random_seed))
             eng.set_ladder(temps, n_ladders)
+            eng.maybe_autotune(n_sweeps, autotune)  # measured launch geometry for long runs
             done = 0
             while done < n_sweeps:
                 step = min(exchange_interval, n_sweeps - done)

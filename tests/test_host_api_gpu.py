@@ -492,6 +492,20 @@ def test_c5_tsp_rows_written_on_the_device(sg, n_cities, force_bits, monkeypatch
     assert np.array_equal(out["energy_trace"][:, :k], ref["energy_trace"])
 
 
+def test_scheduler_result_does_not_depend_on_autotune(sg):
+    rng = np.random.RandomState(5)
+    n = 1500
+    J = np.triu(rng.randint(0, 2, (n, n)) * 2 - 1, 1).astype(np.float32)
+    J = J + J.T
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=n, use_sparse=False))
+    m.set_couplings_from_matrix(torch.from_numpy(J))
+    runs = [sg.SpinGlassScheduler(device="cuda", random_seed=11).anneal(
+        m, n_replicas=32, n_sweeps=30, autotune=flag) for flag in (False, True)]
+    assert runs[0].best_energy == runs[1].best_energy
+    assert torch.equal(runs[0].best_configuration, runs[1].best_configuration)
+    assert runs[0].energy_history == runs[1].energy_history
+
+
 def test_c2b_assignment_instance_full_size(sg):
     """BASELINE configs[1] parity instance: 100 agents x 100 tasks one-hot
     penalties (lambda = 100), 10 000 spins dense, 1024 replicas."""
