@@ -739,7 +739,13 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             const long long budget = 160 * 1024 - 256;
             const long long res_i8 = (long long)e->cus * rpb * std::min<long long>(8, budget / (long long)wg_i8);
             const long long res_bits = (long long)e->cus * std::min<long long>(16, budget / (long long)wg_bits);
-            if (R_local > res_i8 && res_bits > res_i8 && sga::csr_big_fits(bits_stride, e->table_m))
+            // (the barrier-free narrow form with 3-4 replicas per workgroup is the more efficient
+            // kernel on short rows: degree 32, 4096 replicas, n = 40k: 2.35e9 attempts/s with a
+            // quarter of the replicas resident against 1.77e9 as bits; n = 50k: 1.60e9 vs 1.76e9,
+            // but 1.20e9 vs 0.94e9 at 1024 replicas; n = 60k (2 per workgroup): 1.17e9 vs 1.74e9;
+            // n = 100k: 0.62e9 vs 1.71e9)
+            if ((wide_i8 || rpb <= 2) && R_local > res_i8 && res_bits > res_i8 &&
+                sga::csr_big_fits(bits_stride, e->table_m))
                 e->big = true;
         }
         if (e->big) {
