@@ -138,7 +138,8 @@ struct sga_engine {
     int waves = 0, cpw = 0;
     int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while nnz < 2^31
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels, big form)
-    bool big = false;  // CSR sweeps with bit spins in LDS + 64-bit extents (decided per replica set)
+    bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
+    int big_form = 0;  // 0 int8 spins | 1 bits, one replica per workgroup, 64-bit extents | 2 bits, narrow
     float *val = nullptr;
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
@@ -721,44 +722,54 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         e->sstride = (int)e->ld;
     } else {
         e->sstride = (e->n + 15) / 16 * 16;
-        // beyond the int8 LDS capacity (or the 32-bit extents): spins as bits, one replica per
-        // workgroup (sweep_csr.hip, BIG)
-        // (SGA_FORCE_CSR_BIG: parity tests run the small cases through the same form)
-        e->big = sga::csr_waves_per_block(e->sstride, 0) < 1 || !e->rowptr ||
-                 std::getenv("SGA_FORCE_CSR_BIG") != nullptr;
         const double deg = (double)e->nnz / e->n;
+        const int bits_stride = (e->n + 127) / 128 * 128;
+        const bool bits_fit = sga::csr_big_fits(bits_stride, 0);
+        const bool long_rows = deg >= 192.0;
+        // the bit-spin form that would be used: narrow (several replicas per workgroup, 32-bit
+        // extents) on short rows, else one replica per workgroup with its row dealt to waves
+        const int rpb_bits = (e->rowptr && !long_rows && e->tune_waves <= 1)
+                                 ? sga::csr_bits_waves_per_block(bits_stride, e->table_m) : 0;
+        const bool narrow_bits = rpb_bits >= 2;
+        // Spins as bits in LDS: beyond the int8 capacity or the 32-bit extents
+        // (SGA_FORCE_CSR_BIG: parity tests run the small cases through the same forms) ...
+        bool bits = sga::csr_waves_per_block(e->sstride, 0) < 1 || !e->rowptr ||
+                    std::getenv("SGA_FORCE_CSR_BIG") != nullptr;
         // ... or when the int8 spins fit, but not for all replicas at once: workgroups beyond the
         // LDS-resident set run as a second, mostly empty round (C4: 50 KB per replica = 3 per CU
         // = 768 of 1024 replicas resident, 4.7e8 attempts/s; as bits all are resident: 6.8e8)
-        if (!e->big && std::getenv("SGA_NO_CSR_BITS") == nullptr) {
-            const int bits_stride = (e->n + 127) / 128 * 128;
-            const bool wide_i8 = e->tune_waves > 1 || (e->tune_waves == 0 && deg >= 192.0 && R_local <= 1024);
+        if (!bits && bits_fit && std::getenv("SGA_NO_CSR_BITS") == nullptr) {
+            const bool wide_i8 = e->tune_waves > 1 || (e->tune_waves == 0 && long_rows && R_local <= 1024);
             const int rpb = wide_i8 ? 1 : std::max(1, sga::csr_waves_per_block(e->sstride, e->table_m));
-            const size_t wg_i8 = sga::csr_lds_bytes(e->sstride, e->table_m, false) * (size_t)rpb;
-            const size_t wg_bits = sga::csr_lds_bytes(bits_stride, e->table_m, true);
             const long long budget = 160 * 1024 - 256;
-            const long long res_i8 = (long long)e->cus * rpb * std::min<long long>(8, budget / (long long)wg_i8);
-            const long long res_bits = (long long)e->cus * std::min<long long>(16, budget / (long long)wg_bits);
-            // (the barrier-free narrow form with 3-4 replicas per workgroup is the more efficient
-            // kernel on short rows: degree 32, 4096 replicas, n = 40k: 2.35e9 attempts/s with a
-            // quarter of the replicas resident against 1.77e9 as bits; n = 50k: 1.60e9 vs 1.76e9,
-            // but 1.20e9 vs 0.94e9 at 1024 replicas; n = 60k (2 per workgroup): 1.17e9 vs 1.74e9;
-            // n = 100k: 0.62e9 vs 1.71e9)
-            if ((wide_i8 || rpb <= 2) && R_local > res_i8 && res_bits > res_i8 &&
-                sga::csr_big_fits(bits_stride, e->table_m))
-                e->big = true;
+            const long long wg_i8 = (long long)sga::csr_lds_bytes(e->sstride, e->table_m, false) * rpb;
+            const long long one_bits = (long long)sga::csr_lds_bytes(bits_stride, e->table_m, true);
+            const long long res_i8 = (long long)e->cus * rpb * std::min<long long>(8, budget / wg_i8);
+            const long long res_bits =
+                narrow_bits ? (long long)e->cus * rpb_bits * std::min<long long>(8, budget / (one_bits * rpb_bits))
+                            : (long long)e->cus * std::min<long long>(16, budget / one_bits);
+            // Against the one-replica-per-workgroup bit form the barrier-free narrow int8 form with
+            // 3-4 replicas per workgroup stays ahead (degree 32, 4096 replicas, n = 40k: 2.35e9 vs
+            // 1.77e9 attempts/s with a quarter of the replicas resident; n = 60k, 2 per workgroup:
+            // 1.17e9 vs 1.74e9); against the narrow bit form residency decides.
+            if (R_local > res_i8 && res_bits > res_i8 && (narrow_bits || wide_i8 || rpb <= 2)) bits = true;
         }
-        if (e->big) {
-            e->sstride = (e->n + 127) / 128 * 128;
-            if (!sga::csr_big_fits(e->sstride, 0))
+        e->big = bits;
+        e->big_form = !bits ? 0 : (narrow_bits ? 2 : 1);
+        if (bits) {
+            e->sstride = bits_stride;
+            if (!bits_fit)
                 return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large for the LDS-resident spins");
             if (!sga::csr_big_fits(e->sstride, e->table_m)) e->table_m = 0;
-            // one workgroup per CU at these sizes: deal a long row to as many waves as it can
-            // feed with a 64-entry slice each
-            // measured (profiles/r01_experiments.md): best where the 8 entries per lane requested
-            // ahead cover the row -- 500 cities (degree 1996): 4 waves, 1000 (3996): 8
-            const int wpr = e->tune_waves > 0 ? e->tune_waves : (int)std::ceil(deg / 512.0);
-            e->waves = std::max(1, std::min(wpr, 8));
+            if (e->big_form == 2) {
+                e->waves = 1;
+            } else {
+                // one workgroup per replica: deal a long row to as many waves as the 8 entries per
+                // lane requested ahead need to cover it (profiles/r01_experiments.md: 500 cities,
+                // degree 1996: 4 waves; 1000 cities, 3996: 8)
+                const int wpr = e->tune_waves > 0 ? e->tune_waves : (int)std::ceil(deg / 512.0);
+                e->waves = std::max(1, std::min(wpr, 8));
+            }
         } else {
             if (sga::csr_waves_per_block(e->sstride, e->table_m) < 1)
                 e->table_m = 0;  // no room for the probability table: general path
@@ -766,7 +777,7 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             // (one replica per workgroup).  The kernel is issue bound, so with >= 2048 replicas the
             // extra waves only repeat the per-update work (measured: C4, R = 1024: 1 / 2 / 4 / 8
             // waves -> 2.98 / 3.69 / 3.67 / 3.34 e8 attempts/s; C5, R = 2048: 1.55 vs 1.19 e9).
-            const int wpr = e->tune_waves > 0 ? e->tune_waves : ((deg >= 192.0 && R_local <= 1024) ? 2 : 1);
+            const int wpr = e->tune_waves > 0 ? e->tune_waves : ((long_rows && R_local <= 1024) ? 2 : 1);
             e->waves = std::min(wpr, 8);
         }
         e->cpw = 0;
@@ -920,7 +931,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.J = e->J_packed;
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
-        a.big = e->big ? 1 : 0;
+        a.big = e->big_form;
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
         a.colidx = e->colidx;
@@ -1504,7 +1515,8 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       "csr n=%d nnz=%lld R=%d waves_per_replica=%d replicas_per_block=%d sstride=%d "
                       "path=%s table_m=%d spins=%s",
                       e->n, e->nnz, e->R, e->waves,
-                      (e->waves > 1 || e->big) ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m),
+                      e->big_form == 2 ? sga::csr_bits_waves_per_block(e->sstride, e->table_m)
+                                       : ((e->waves > 1 || e->big) ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m)),
                       e->sstride, e->table_m > 0 ? "integer-fast" : "general", e->table_m,
                       e->big ? "lds-bits" : "lds-int8");
     else

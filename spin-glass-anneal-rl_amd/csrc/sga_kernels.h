@@ -52,7 +52,9 @@ struct SweepArgs {
     long long model_stride_j;
     int no_best;  // 1: leave best tracking to the host-driven pass (asymmetric / diagonal J)
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
-    int big;      // CSR: spins held as bits in LDS, 64-bit row extents (n > ~160k or nnz >= 2^31)
+    int big;      // CSR: spins held as bits in LDS; 1 = one replica per workgroup with 64-bit row
+                  // extents (n > ~160k, nnz >= 2^31, long rows), 2 = narrow form, several replicas per
+                  // workgroup (short rows)
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
@@ -99,6 +101,7 @@ hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 bool csr_big_fits(int sstride, int table_m);         // spins as bits: one replica per workgroup
+int csr_bits_waves_per_block(int sstride, int table_m);  // spins as bits, narrow form: replicas per workgroup
 size_t csr_lds_bytes(int sstride, int table_m, bool bits);  // LDS of one replica (spins + table)
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);

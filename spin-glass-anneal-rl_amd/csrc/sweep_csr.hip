@@ -43,10 +43,12 @@ constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (1
 template <bool FAST, bool LEAN, bool WIDE, bool BIG>
 __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
     sweep_csr_kernel(const SweepArgs a) {
-    static_assert(!BIG || WIDE, "the bit-spin form is one replica per workgroup");
-    using rp_t = typename std::conditional<BIG, long long, int>::type;
+    // bit spins also come in the narrow form (several replicas per workgroup, 32-bit extents):
+    // short rows on 40k < n <= 1.3M spins, where the int8 spins leave one or two replicas per
+    // workgroup
+    using rp_t = typename std::conditional<BIG && WIDE, long long, int>::type;
     const rp_t *rowptr = nullptr;
-    if constexpr (BIG) rowptr = a.rowptr64;
+    if constexpr (BIG && WIDE) rowptr = a.rowptr64;
     else rowptr = a.rowptr;
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     const int first_lane = WIDE ? w * 64 + lane : lane; // this lane's first entry of a row
     const long long sbytes = BIG ? a.sstride / 8 : a.sstride;  // LDS bytes of one replica's spins
     int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)me * sbytes;
-    unsigned int *sbits = reinterpret_cast<unsigned int *>(smem);
+    unsigned int *sbits = reinterpret_cast<unsigned int *>(smem + (long long)me * sbytes);
     float *ptab = reinterpret_cast<float *>(smem + (long long)slots * sbytes) +
                   (long long)me * (a.table_m + 1);
     double *part = reinterpret_cast<double *>(smem + (long long)slots * sbytes +
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     };
 
     PairSource<LEAN> rng;
-    if constexpr (BIG && LEAN) {
+    if constexpr (BIG && WIDE && LEAN) {
         // HBM-resident structures (C5 at 500 / 1000 cities: 4 / 32 GB): an update lasts ~2 us
         // (row gather + reduce + barrier), about one loaded HBM round trip, so rows are requested
         // NH - 1 = 2 updates ahead and their extents NB - 1 updates ahead (two rings, NB a
@@ -364,6 +366,12 @@ bool csr_big_fits(int sstride, int table_m) {
     return sstride % 128 == 0 && csr_lds_per_replica(sstride, table_m, true) <= CSR_LDS_BUDGET;
 }
 
+int csr_bits_waves_per_block(int sstride, int table_m) {  // narrow bit-spin form
+    if (sstride % 128 != 0) return 0;
+    const int wpb = (int)(CSR_LDS_BUDGET / csr_lds_per_replica(sstride, table_m, true));
+    return wpb > CSR_WAVES_PER_BLOCK ? CSR_WAVES_PER_BLOCK : wpb;
+}
+
 template <bool WIDE, bool BIG>
 static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
     const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a);
@@ -390,6 +398,11 @@ hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream
         if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !a.rowptr64 ||
             !csr_big_fits(a.sstride, a.table_m))
             return hipErrorInvalidValue;
+        if (waves_per_replica == 1 && a.rowptr && a.big == 2) {  // several replicas per workgroup
+            const int wpb = csr_bits_waves_per_block(a.sstride, a.table_m);
+            if (wpb < 1) return hipErrorInvalidValue;
+            return launch_csr<false, true>(a, wpb, st);
+        }
         return launch_csr<true, true>(a, waves_per_replica, st);
     }
     if (!a.rowptr) return hipErrorInvalidValue;

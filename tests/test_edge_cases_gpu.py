@@ -34,8 +34,11 @@ def run_both(sg, prob_args, setter, n, R, temps, ns, seed, rule=0, recompute=Fal
     return got
 
 
+@pytest.mark.parametrize("bits", [False, True])
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
-def test_tiny_problems_dense_and_csr(sg, n):
+def test_tiny_problems_dense_and_csr(sg, n, bits, monkeypatch):
+    if bits:  # the CSR case through the bit-spin form (several replicas per workgroup)
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
     rng = np.random.RandomState(n)
     J = np.triu(rng.randint(-2, 3, (n, n)), 1).astype(np.float32)
     J = J + J.T
@@ -48,7 +51,11 @@ def test_tiny_problems_dense_and_csr(sg, n):
     run_both(sg, dict(J=J, h=h), lambda e: e.set_csr(rowptr, col, val, h), n, 3, temps, 7, seed=n)
 
 
-def test_fields_only_and_empty_rows(sg):
+@pytest.mark.parametrize("bits", [False, True])
+def test_fields_only_and_empty_rows(sg, bits, monkeypatch):
+    """J == 0 almost everywhere (nearly every CSR row empty); `bits`: the bit-spin CSR form."""
+    if bits:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
     n = 70
     J = np.zeros((n, n), np.float32)
     J[3, 40] = J[40, 3] = 2.0          # a single bond; every other row is empty

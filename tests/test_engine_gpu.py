@@ -357,8 +357,13 @@ def test_sequential_order_matches_oracle(sg):
 
 
 # ----------------------------------------------------------------------------- CSR
+@pytest.mark.parametrize("bits", [False, True])
 @pytest.mark.parametrize("n,deg,R", [(200, 6, 9), (3000, 32, 10), (1500, 100, 3)])
-def test_csr_sweeps_match_oracle(sg, n, deg, R):
+def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
+    """Short rows: one replica per wave, several replicas per workgroup; `bits` = the same with the
+    spins as bits in LDS (the form for 53k < n <= 1.3M spins)."""
+    if bits:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
     rng = np.random.RandomState(n)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -375,6 +380,8 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R):
     with sg.AnnealEngine(0) as e:
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert ("spins=lds-bits" in d) == bits and "replicas_per_block=4" in d
         e.set_temperatures(temps)
         out = e.sweep(ns, energy_trace=True)
         assert np.array_equal(out["energy_trace"], ref["energy_trace"])
@@ -382,6 +389,10 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R):
         assert np.array_equal(e.stats()[0], ref["n_accepted"])
         be, bs, idx = e.best()
         assert be == ref["best_energy"].min()
+        out2 = e.sweep(2, energy_trace=True, trace=True)       # general (traced) variant
+        ref2 = oracle.sweeps(prob, s, temps, 2, seed=seed, sweep0=ns, energy=ref["energy"], trace=True)
+        assert np.array_equal(out2["accept_trace"], ref2["accept_trace"])
+        assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
 
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
