@@ -140,7 +140,8 @@ struct sga_engine {
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels, big form)
     bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
     int big_form = 0;  // 0 int8 spins | 1 bits, one replica per workgroup, 64-bit extents | 2 bits, narrow
-    float *val = nullptr;
+    float *val = nullptr;   // colidx / val: only while the structure is being checked
+    int2 *cv = nullptr;     // [nnz] interleaved (column, value bits): what the kernels read
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
     int tune_waves = 0, tune_spl = 0;
@@ -185,6 +186,7 @@ struct sga_engine {
         dev_free(rowptr64);
         dev_free(colidx);
         dev_free(val);
+        dev_free(cv);
         dev_free(h);
         dev_free(diag);
         n = 0;
@@ -252,8 +254,7 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     sga::EnergyArgs a{};
     a.J = e->J_packed;
     a.rowptr = e->rowptr64;
-    a.colidx = e->colidx;
-    a.val = e->val;
+    a.cv = e->cv;
     a.h = e->h;
     a.spins = e->spins + (long long)r0 * e->sstride;
     a.energy = e->energy + r0;
@@ -684,7 +685,12 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f)
         e->table_m = (int)std::min(m, 2048.0f);
     HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, e->colidx, e->val, n, e->diag, e->stream));
+    // the kernels read interleaved entries; the separate arrays are done with
+    HIPCHK(hipMalloc(&e->cv, sizeof(int2) * nz));
+    HIPCHK(sga::launch_pack_cv(e->colidx, e->val, e->cv, nnz, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    dev_free(e->colidx);
+    dev_free(e->val);
     return SGA_OK;
 }
 
@@ -934,8 +940,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.big = e->big_form;
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
-        a.colidx = e->colidx;
-        a.val = e->val;
+        a.cv = e->cv;
         a.h = e->h;
         a.diag = e->diag;
         a.spins = e->spins;
@@ -1067,8 +1072,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         a.J = e->J_packed;
         a.model_offset_j = model * e->n * e->ldj;
         a.rowptr = e->rowptr64;
-        a.colidx = e->colidx;
-        a.val = e->val;
+        a.cv = e->cv;
         a.h = e->h + model * e->n;
         a.diag = e->diag + model * e->n;
         a.spins = e->spins + (long long)r * e->sstride;

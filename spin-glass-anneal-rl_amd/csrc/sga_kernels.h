@@ -18,8 +18,7 @@ struct SweepArgs {
     const void *J;           // dense: [n][ld] of float | int8, zero padded rows
     const int32_t *rowptr;   // CSR, nnz < 2^31 (null otherwise)
     const long long *rowptr64;  // CSR, always present
-    const int32_t *colidx;
-    const float *val;
+    const int2 *cv;          // CSR entries, (column, value bits) interleaved: one 8-byte load each
     const float *h;          // [n]
     const float *diag;       // [n] J_ii (ARITH_F32 only)
     // replica state
@@ -65,8 +64,7 @@ struct EnergyArgs {
     long long model_stride_j;
     const void *J;
     const long long *rowptr;
-    const int32_t *colidx;
-    const float *val;
+    const int2 *cv;
     const float *h;
     const int8_t *spins;
     double *energy;
@@ -121,6 +119,10 @@ hipError_t launch_unpad_spins(const int8_t *src, int sstride, int8_t *dst, int n
                               hipStream_t st);
 hipError_t launch_gather_diag_csr(const long long *rowptr, const int32_t *colidx, const float *val,
                                   int n, float *diag, hipStream_t st);
+// (colidx, val) -> interleaved entries {column, value bits}: a row is one stream of 8-byte loads
+// (half the memory instructions, one page instead of two per row)
+hipError_t launch_pack_cv(const int32_t *colidx, const float *val, int2 *cv, long long nnz,
+                          hipStream_t st);
 // CSR row extents between their 32- and 64-bit forms ([n + 1] entries)
 hipError_t launch_widen_rowptr(const int32_t *src, long long *dst, long long count, hipStream_t st);
 hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long count, hipStream_t st);
@@ -145,8 +147,7 @@ hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *b
 struct PointArgs {
     const void *J;
     const long long *rowptr;
-    const int32_t *colidx;
-    const float *val;
+    const int2 *cv;
     const float *h, *diag;
     int8_t *spins;       // the replica's row [sstride]
     double *energy;      // the replica's tracked energy

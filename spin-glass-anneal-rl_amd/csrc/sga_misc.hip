@@ -191,6 +191,20 @@ hipError_t launch_gather_diag_csr(const long long *rowptr, const int32_t *colidx
 // CSR structure: row extents in both widths, validation without a round trip of the entries
 // to the host (4e9 entries at the 1000-city TSP instance).
 // ---------------------------------------------------------------------------------------
+__global__ void pack_cv_kernel(const int32_t *__restrict__ colidx, const float *__restrict__ val,
+                               int2 *__restrict__ cv, long long nnz) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz;
+         i += (long long)gridDim.x * blockDim.x)
+        cv[i] = make_int2(colidx[i], __float_as_int(val[i]));
+}
+hipError_t launch_pack_cv(const int32_t *colidx, const float *val, int2 *cv, long long nnz,
+                          hipStream_t st) {
+    if (nnz <= 0) return hipSuccess;
+    const int blocks = (int)std::min<long long>((nnz + 255) / 256, 65536);
+    hipLaunchKernelGGL(pack_cv_kernel, dim3(blocks), dim3(256), 0, st, colidx, val, cv, nnz);
+    return hipGetLastError();
+}
+
 __global__ void widen_rowptr_kernel(const int32_t *src, long long *dst, long long count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i];
@@ -494,7 +508,10 @@ __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
     for (int i = w; i < a.n; i += 4) {
         double acc = 0.0;
         for (long long j = a.rowptr[i] + lane; j < a.rowptr[i + 1]; j += 64)
-            acc += (double)(a.val[j] * (float)s[a.colidx[j]]);
+        {
+            const int2 ent = a.cv[j];
+            acc += (double)(__int_as_float(ent.y) * (float)s[ent.x]);
+        }
         const float mv_i = (float)wave_sum(acc);
         const double si = (double)s[i];
         e_acc += (double)mv_i * si;
@@ -538,8 +555,9 @@ __global__ void __launch_bounds__(64 * ENERGY_BIG_WAVES) energy_csr_bits_kernel(
             for (int q = 0; q < ENERGY_BIG_UNROLL; ++q) {
                 const long long j = j0 + 64 * q;
                 const bool in = j < end;
-                c[q] = in ? a.colidx[j] : 0;
-                v[q] = in ? a.val[j] : 0.0f;
+                const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                c[q] = ent.x;
+                v[q] = __int_as_float(ent.y);
             }
 #pragma unroll
             for (int q = 0; q < ENERGY_BIG_UNROLL; ++q) acc += (double)(v[q] * spin_f(c[q]));
@@ -666,7 +684,10 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
         double acc = 0.0;
         if constexpr (CSR) {
             for (long long j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
-                acc += (double)(a.val[j] * (float)a.spins[a.colidx[j]]);
+            {
+                const int2 ent = a.cv[j];
+                acc += (double)(__int_as_float(ent.y) * (float)a.spins[ent.x]);
+            }
         } else {
             const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
             for (long long c = (long long)tid * EPL; c < a.ldj; c += 4 * EPC) {

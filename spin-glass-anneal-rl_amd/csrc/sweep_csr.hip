@@ -129,8 +129,9 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         for (int q = 0; q < HEAD; ++q) {
             const rp_t j = x.beg + first_lane + (rp_t)stride_lanes * q;
             const bool in = j < x.end;
-            o.col[q] = in ? a.colidx[j] : 0;
-            o.val[q] = in ? a.val[j] : 0.0f;
+            const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+            o.col[q] = ent.x;
+            o.val[q] = __int_as_float(ent.y);
         }
         return o;
     };
@@ -155,8 +156,9 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
                     const rp_t j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
-                    c[q] = in ? a.colidx[j] : 0;
-                    v[q] = in ? a.val[j] : 0.0f;
+                    const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                    c[q] = ent.x;
+                    v[q] = __int_as_float(ent.y);
                 }
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * spin_f(c[q]);
@@ -183,8 +185,9 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 for (int q = 0; q < TAIL_UNROLL; ++q) {
                     const rp_t j = j0 + stride_lanes * q;
                     const bool in = j < x.end;
-                    c[q] = in ? a.colidx[j] : 0;
-                    v[q] = in ? a.val[j] : 0.0f;
+                    const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                    c[q] = ent.x;
+                    v[q] = __int_as_float(ent.y);
                 }
 #pragma unroll
                 for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * spin_f(c[q]));
