@@ -81,10 +81,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
     }
     if constexpr (WIDE) __syncthreads();
-    // spin of column c as a float factor / as an int
-    auto spin_f = [&](int c) -> float {
-        if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1.0f : 1.0f;
-        else return (float)s[c];
+    // value * spin of column c: with bit spins the sign bit is XORed in (3 VALU ops instead of a
+    // compare, a select and a multiply -- the wide forms spend most of their time here)
+    auto term = [&](float v, int c) -> float {
+        if constexpr (BIG) {
+            const unsigned int sign = (sbits[c >> 5] >> (c & 31)) << 31;
+            return __int_as_float(__float_as_int(v) ^ (int)sign);
+        } else {
+            return v * (float)s[c];
+        }
     };
     auto spin_i = [&](int c) -> int {
         if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1 : 1;
@@ -114,6 +119,25 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     struct Head {
         int col[HEAD];
         float val[HEAD];
+        int len;                  // wide forms: the row's entry count (wave-uniform)
+        const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer)
+    };
+    // wave-uniform value -> SGPRs
+    auto uniform = [&](rp_t v) -> rp_t {
+        if constexpr (sizeof(rp_t) == 8) {
+            const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)v);
+            const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)v >> 32));
+            return (rp_t)(((unsigned long long)hi << 32) | lo);
+        } else {
+            return (rp_t)__builtin_amdgcn_readfirstlane((int)v);
+        }
+    };
+    // entry `idx` of a row (wide forms): uniform row pointer + 32-bit byte offset = the scalar-base
+    // load form; past the row's end the lane re-reads entry 0 and the caller zeroes its value
+    auto row_entry = [&](const int2 *row, int idx, int len) -> int2 {
+        unsigned int off = (unsigned int)(idx < len ? idx : 0) * 8u;
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
     };
     auto load_extent = [&](int site) {
         Extent o;
@@ -125,6 +149,23 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     };
     auto load_head = [&](const Extent &x) {
         Head o;
+        o.len = 0;
+        o.row = nullptr;
+        if constexpr (WIDE) {
+            // 8 entries per lane: per-entry 64-bit index arithmetic and predication were a third
+            // of the kernel's VALU work at degree 4000 (PMC: 27 VALU per entry); the extent arrived
+            // updates ago, so pin it to SGPRs and address entries by a 32-bit index from the row
+            const rp_t beg = uniform(x.beg);
+            o.len = (int)(uniform(x.end) - beg);
+            o.row = a.cv + beg;
+#pragma unroll
+            for (int q = 0; q < HEAD; ++q) {
+                const int2 ent = row_entry(o.row, first_lane + stride_lanes * q, o.len);
+                o.col[q] = ent.x;
+                o.val[q] = __int_as_float(ent.y);  // zeroed past the end when used
+            }
+            return o;
+        }
 #pragma unroll
         for (int q = 0; q < HEAD; ++q) {
             const rp_t j = x.beg + first_lane + (rp_t)stride_lanes * q;
@@ -136,6 +177,13 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         return o;
     };
 
+    // value q of the requested head; the wide forms zero it past the row's end here, not right
+    // behind the load (a select there would put the wait directly behind the load)
+    auto head_val = [&](const Head &hd, int q) -> float {
+        if constexpr (WIDE) return (first_lane + stride_lanes * q) < hd.len ? hd.val[q] : 0.0f;
+        else return hd.val[q];
+    };
+
     double T = 1.0;
     auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
         // read s_i before any wave can have applied THIS update's flip (WIDE: before the barrier)
@@ -143,25 +191,41 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         // J[site,:].s over the stored entries; products val * (+-1) are exact
         float dot;
         if constexpr (FAST) {
-            float acc = hd.val[0] * spin_f(hd.col[0]);
+            float acc = term(head_val(hd, 0), hd.col[0]);
 #pragma unroll
-            for (int q = 1; q < HEAD; ++q) acc += hd.val[q] * spin_f(hd.col[q]);
-            // longer rows: issue eight (colidx, val) wave-loads before the first gather so the
-            // round trips overlap instead of serialising (degree ~600 at C4)
-            for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                 j0 += stride_lanes * TAIL_UNROLL) {
-                int c[TAIL_UNROLL];
-                float v[TAIL_UNROLL];
+            for (int q = 1; q < HEAD; ++q) acc += term(head_val(hd, q), hd.col[q]);
+            // longer rows: issue eight entry wave-loads before the first gather so the round trips
+            // overlap instead of serialising (degree ~600 at C4)
+            if constexpr (WIDE) {
+                for (int i0 = stride_lanes * HEAD; i0 < hd.len; i0 += stride_lanes * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const rp_t j = j0 + stride_lanes * q;
-                    const bool in = j < x.end;
-                    const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-                    c[q] = ent.x;
-                    v[q] = __int_as_float(ent.y);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const int idx = i0 + first_lane + stride_lanes * q;
+                        const int2 ent = row_entry(hd.row, idx, hd.len);
+                        c[q] = ent.x;
+                        v[q] = idx < hd.len ? __int_as_float(ent.y) : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += term(v[q], c[q]);
                 }
+            } else {
+                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
+                     j0 += stride_lanes * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) acc += v[q] * spin_f(c[q]);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const rp_t j = j0 + stride_lanes * q;
+                        const bool in = j < x.end;
+                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                        c[q] = ent.x;
+                        v[q] = __int_as_float(ent.y);
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += term(v[q], c[q]);
+                }
             }
             dot = wave_sum(acc);
             if constexpr (WIDE) {
@@ -174,23 +238,39 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 pp ^= 1;
             }
         } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
-            double acc = (double)(hd.val[0] * spin_f(hd.col[0]));
+            double acc = (double)term(head_val(hd, 0), hd.col[0]);
 #pragma unroll
-            for (int q = 1; q < HEAD; ++q) acc += (double)(hd.val[q] * spin_f(hd.col[q]));
-            for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                 j0 += stride_lanes * TAIL_UNROLL) {
-                int c[TAIL_UNROLL];
-                float v[TAIL_UNROLL];
+            for (int q = 1; q < HEAD; ++q) acc += (double)term(head_val(hd, q), hd.col[q]);
+            if constexpr (WIDE) {
+                for (int i0 = stride_lanes * HEAD; i0 < hd.len; i0 += stride_lanes * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) {
-                    const rp_t j = j0 + stride_lanes * q;
-                    const bool in = j < x.end;
-                    const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-                    c[q] = ent.x;
-                    v[q] = __int_as_float(ent.y);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const int idx = i0 + first_lane + stride_lanes * q;
+                        const int2 ent = row_entry(hd.row, idx, hd.len);
+                        c[q] = ent.x;
+                        v[q] = idx < hd.len ? __int_as_float(ent.y) : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
                 }
+            } else {
+                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
+                     j0 += stride_lanes * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
 #pragma unroll
-                for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)(v[q] * spin_f(c[q]));
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const rp_t j = j0 + stride_lanes * q;
+                        const bool in = j < x.end;
+                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                        c[q] = ent.x;
+                        v[q] = __int_as_float(ent.y);
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                }
             }
             double tot = wave_sum(acc);
             if constexpr (WIDE) {
