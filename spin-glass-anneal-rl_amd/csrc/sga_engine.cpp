@@ -686,7 +686,10 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
         e->table_m = (int)std::min(m, 2048.0f);
     HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, e->colidx, e->val, n, e->diag, e->stream));
     // the kernels read interleaved entries; the separate arrays are done with
-    HIPCHK(hipMalloc(&e->cv, sizeof(int2) * nz));
+    // (+1 zeroed entry: a lane of the wide forms that falls past its row's end re-reads the row's
+    // first entry, which for an empty last row is the slot behind the array)
+    HIPCHK(hipMalloc(&e->cv, sizeof(int2) * (nz + 1)));
+    HIPCHK(hipMemsetAsync(e->cv + std::max<int64_t>(nnz, 0), 0, sizeof(int2), e->stream));
     HIPCHK(sga::launch_pack_cv(e->colidx, e->val, e->cv, nnz, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     dev_free(e->colidx);
