@@ -12,11 +12,17 @@ exchange round runs (default 10, the reference's default).  With N > 1 GPUs ever
 its own 1024 replicas of one global ladder (weak scaling, J replicated); the exchange step
 all-gathers the R_global energies over RCCL and every rank applies the same decisions.
 
+Set-up (untimed): couplings to HBM, replicas, ladder, then `sga_autotune` -- the engine times
+its feasible launch geometries on the resident replicas and keeps the fastest; the chain and the
+state are unaffected (`--no-autotune` keeps the heuristic geometry) -- then W warm-up steps.
+
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the dense sweep):
 algorithmic bytes = attempts x N x sizeof(J element) (one coupling-row read per attempt,
 SURVEY.md 8(d)) divided by its HIP-event-timed launch duration.  `cpu_baseline` times the CPU
 oracle (oracle/, a C restatement of the reference's algorithm; OpenMP over replicas) on a
-bounded sample of the same workload on the host cores.
+bounded sample of the same workload on the host cores, replays that sample on the GPU and
+reports the energy gap between the two (`energy_gap_vs_gpu`; 0 = bit-identical).
+`--workload c3 | c4 | c5 [--cities N]` run the CSR configurations of BASELINE.json.
 """
 import argparse
 import json
