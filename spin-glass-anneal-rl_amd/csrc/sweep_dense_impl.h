@@ -93,8 +93,11 @@ constexpr int dense_max_threads() {
     return (BATCH && CPW == (std::is_same<JT, Tern2>::value ? 2 : 4)) ? 256 : 1024;
 }
 
-template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false>
-__global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_dense_kernel(const SweepArgs a) {
+// SINGLE = built for one wave per replica: the wave count, the owner-wave tests and the partial-sum
+// exchange fold away (small problems run one wave per SIMD and are bound by the length of the
+// instruction stream).
+template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false, bool SINGLE = false>
+__global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATCH>())) sweep_dense_kernel(const SweepArgs a) {
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     using TR = JTraits<JT>;
@@ -116,8 +119,8 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
     const bool use_tab = LEAN && a.table_m > 0;
 
     const int tid = threadIdx.x;
-    const int W = blockDim.x >> 6;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = SINGLE ? 1 : (int)(blockDim.x >> 6);
+    const int w = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int r = blockIdx.x;
     const int n = a.n;
@@ -188,6 +191,7 @@ __global__ void __launch_bounds__((dense_max_threads<JT, CPW, BATCH>())) sweep_d
     // for c < 4096 chunks and W <= 16)
     const unsigned int w_recip = (65536u + (unsigned int)W - 1u) / (unsigned int)W;
     auto owner_of = [&](int site) -> int {
+        if constexpr (SINGLE) return 0;
         const unsigned int c = (unsigned int)site / (unsigned int)EPC;
         return (int)(c - ((c * w_recip) >> 16) * (unsigned int)W);
     };
@@ -656,7 +660,8 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         constexpr bool fat = dense_max_threads<JT, CPW, true>() < 1024;
         if (lean && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
             (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024)))
-            kern = sweep_dense_kernel<JT, CPW, ACC64, true, true>;
+            kern = waves == 1 ? sweep_dense_kernel<JT, CPW, ACC64, true, true, true>
+                              : sweep_dense_kernel<JT, CPW, ACC64, true, true>;
     }
     if (!kern) {
         if constexpr (BITS) {
