@@ -670,6 +670,10 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         } else {
             kern = lean ? sweep_dense_kernel<JT, CPW, ACC64, true>
                         : sweep_dense_kernel<JT, CPW, ACC64, false>;
+            // real-valued small problems: the one-wave build of the one-update-at-a-time form
+            if constexpr (CPW >= 1 && CPW <= 4) {
+                if (lean && waves == 1) kern = sweep_dense_kernel<JT, CPW, ACC64, true, false, true>;
+            }
         }
     }
     if (lds > 48 * 1024) {
