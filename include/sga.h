@@ -94,7 +94,11 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
  * use n_ladders = n_models so that exchanges stay inside a model. */
 int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
                         int n_models, int storage);
-/* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]. */
+/* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]; host or
+ * device pointers.  The structure is checked on the device (SGA_ERR_INVALID for extents that are
+ * not monotone / do not span [0, nnz], or a column outside [0, n)); rows need not be sorted and
+ * duplicates add up.  The arrays are copied (interleaved into (column, value) entries); the
+ * caller's buffers are not referenced after the call. */
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
                 const float *h, int n, int64_t nnz);
 /* Same with 64-bit row extents, for nnz >= 2^31 (BASELINE config 5 at 1000 cities: n = 10^6,
