@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two ranks over gloo, each holding half of the replicas of one ladder,
+"""N > 1 path on CPU: two (and four) ranks over gloo, each holding its share of the replicas,
 must reproduce the single-rank run bit for bit (decisions are a pure function of the gathered
 energies and the shared Philox key; spins never move between ranks)."""
 import os
@@ -58,11 +58,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_ranks(n_ladders):
+def _ranks(world, n_ladders):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ladders, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ladders, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in procs)
@@ -72,13 +72,13 @@ def _two_ranks(n_ladders):
     return got
 
 
-def _check(n_ladders):
+def _check(n_ladders, world=2):
     single = {}
     _run(0, 1, n_ladders, single, None)
     assert sum(single["swaps"]) > 0
-    got = _two_ranks(n_ladders)
-    half = R_GLOBAL // 2
-    for rank in (0, 1):
+    got = _ranks(world, n_ladders)
+    half = R_GLOBAL // world
+    for rank in range(world):
         o = got[rank]
         assert o["swaps"] == single["swaps"]
         assert np.array_equal(o["energies"], single["energies"])
@@ -96,3 +96,8 @@ def test_two_rank_run_equals_single_rank_one_ladder():
 
 def test_two_rank_run_equals_single_rank_three_ladders():
     _check(3)
+
+
+def test_four_rank_run_equals_single_rank_ladders_straddling_ranks():
+    # 3 ladders of 4 replicas over 4 ranks of 3 replicas: every ladder spans two ranks
+    _check(3, world=4)
