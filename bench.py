@@ -113,6 +113,13 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
     t0 = time.perf_counter()
     res = oracle.sweeps(prob, s, temps, sweeps, seed=seed, energy=e0, n_threads=cores)
     dt = time.perf_counter() - t0
+    # the faithful single-thread figure beside it, on a slice of the sample
+    R1 = max(1, min(R, 8))
+    sw1 = max(1, sweeps // 8)
+    s1 = oracle.init_spins(n, R1, seed)
+    t1 = time.perf_counter()
+    oracle.sweeps(prob, s1, temps[:R1], sw1, seed=seed, energy=np.zeros(R1), n_threads=1)
+    dt1 = time.perf_counter() - t1
     oracle.set_exact_f32(False)
     gap = None
     if eng is not None:  # outside every timed region
@@ -127,6 +134,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
                "spins_identical": bool(np.array_equal(eng.spins(), s))}
     return {"value": R * n * sweeps / dt, "unit": "spin-flip attempts/s", "cores": cores,
             "kind": "port", "energy_gap_vs_gpu": gap,
+            "single_thread_value": R1 * n * sw1 / dt1,
             "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin "
                       f"{'CSR' if csr is not None else 'dense'} instance, OpenMP over replicas"
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
