@@ -1,0 +1,131 @@
+"""Randomised parity hunt (not part of the test suite): random small problems, storages, waves per
+replica, replica counts, sweep counts, dense / CSR, forced forms -- GPU engine vs the CPU oracle,
+bit for bit.  usage: fuzz_parity.py <seconds> [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import oracle
+import spin_glass_anneal_rl_amd as sg
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+n_cases = n_fail = 0
+while time.time() < t_end:
+    kind = rng.choice(["dense", "dense", "csr"])
+    n = int(rng.choice([1, 2, 3, 5, 8, 17, 64, 65, 200, 255, 256, 257, 700, 1023, 1025, 2049, 3000, 5000]))
+    if kind == "csr":
+        n = max(n, 2)
+    R = int(rng.choice([1, 2, 3, 7, 16, 33]))
+    ns = int(rng.choice([1, 2, 3, 5]))
+    integer = rng.rand() < 0.7
+    dens = rng.choice([0.05, 0.3, 1.0]) if kind == "dense" else min(1.0, rng.choice([4, 30, 200, 700]) / n)
+    J = np.triu((rng.randint(-2, 3, (n, n)) if integer else rng.randn(n, n)) * (rng.rand(n, n) < dens), 1).astype(np.float32)
+    J = J + J.T
+    h = (rng.randint(-2, 3, n) if integer else rng.randn(n)).astype(np.float32)
+    if rng.rand() < 0.2:
+        h[:] = 0
+    storage = "auto"
+    if kind == "dense" and integer:
+        storage = str(rng.choice(["auto", "f32", "i8"]))
+        if np.abs(J).max() <= 1 and rng.rand() < 0.5:
+            storage = "t2"
+    waves = int(rng.choice([0, 0, 1, 2, 3, 4, 8, 16]))
+    env = {}
+    if rng.rand() < 0.3:
+        env["SGA_NO_LOOK_AHEAD"] = "1"
+    if kind == "csr" and rng.rand() < 0.5:
+        env["SGA_FORCE_CSR_BIG"] = "1"
+    seed = int(rng.randint(1, 1 << 30))
+    temps = np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R) if R > 1 else np.asarray([1.5])
+    mode = str(rng.choice(["plain", "plain", "rules", "pt"]))
+    rule = int(rng.choice([0, 1, 2]))
+    site_mode = int(rng.choice([0, 1]))
+    arith = int(rng.choice([0, 1])) if rule == 0 else 0
+    n_lad = int(rng.choice([1, 2, 3]))
+    if mode == "pt":
+        R = n_lad * int(rng.choice([2, 3, 4, 7]))
+        temps = np.tile(np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R // n_lad), n_lad)
+    slot_temps = temps.copy()
+    desc = f"{mode} rule={rule} site={site_mode} arith={arith} lad={n_lad} {kind} n={n} R={R} ns={ns} int={integer} dens={dens:.3g} storage={storage} waves={waves} env={env} seed={seed}"
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        if kind == "csr":
+            rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
+            col = np.concatenate([np.nonzero(J[i])[0] for i in range(n)] + [np.zeros(0, int)]).astype(np.int32)
+            val = np.concatenate([J[i][J[i] != 0] for i in range(n)] + [np.zeros(0)]).astype(np.float32)
+            prob = oracle.Problem(csr=(rowptr, col, val), h=h)
+        else:
+            prob = oracle.Problem(J=J, h=h)
+        s = oracle.init_spins(n, R, seed)
+        if mode == "plain":
+            ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=4)
+        elif mode == "rules":
+            u_seq = rng.rand(R, ns * n).astype(np.float32) if site_mode == 1 else None
+            ref = oracle.sweeps(prob, s, temps, ns, site_mode=site_mode, arith=arith, rule=rule, seed=seed,
+                                replay_u=u_seq, trace=True, n_threads=4)
+        with sg.AnnealEngine(0) as e:
+            if waves:
+                try:
+                    e.set_tuning(waves_per_replica=min(waves, 8 if kind == "csr" else 16))
+                except Exception:
+                    pass
+            if kind == "csr":
+                e.set_csr(rowptr, col, val, h)
+            else:
+                e.set_dense(J, h, storage=storage)
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            if rng.rand() < 0.3 and kind == "dense":
+                e.autotune()
+            if mode == "plain":
+                out = e.sweep(ns, energy_trace=True)
+                ok = (np.array_equal(out["energy_trace"], ref["energy_trace"]) and np.array_equal(e.spins(), s)
+                      and np.array_equal(e.stats()[0], ref["n_accepted"]))
+                for r in range(R):
+                    be, bs, _ = e.best(r)
+                    ok = ok and be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+            elif mode == "rules":  # other rule / sequential sites / fp32 operator arithmetic
+                e.set_update_rule(rule)
+                out = e.sweep(ns, site_mode=site_mode, arith=arith, replay_u=u_seq, energy_trace=True, trace=True)
+                ok = (np.array_equal(out["accept_trace"], ref["accept_trace"])
+                      and np.array_equal(out["dE_trace"], ref["dE_trace"]) and np.array_equal(e.spins(), s))
+            else:  # tempering: sweeps and exchange rounds on 1-3 ladders
+                e.set_ladder(slot_temps, n_lad)
+                slot = np.arange(R, dtype=np.int32)
+                rep_T = slot_temps.copy()
+                s2 = oracle.init_spins(n, R, seed)
+                energy = None
+                ok, done = True, 0
+                for rnd in range(3):
+                    res = oracle.sweeps(prob, s2, rep_T, ns, seed=seed, sweep0=done, energy=energy, n_threads=4)
+                    energy, done = res["energy"], done + ns
+                    e.sweep(ns)
+                    L = R // n_lad
+                    acc = 0
+                    for lad in range(n_lad):
+                        sub = slot[lad * L:(lad + 1) * L].copy()
+                        acc += oracle.pt_exchange_round(slot_temps[lad * L:(lad + 1) * L], energy, sub,
+                                                        seed=seed, round_=rnd, ladder=lad)
+                        slot[lad * L:(lad + 1) * L] = sub
+                    rep_T[slot] = slot_temps
+                    got = e.exchange()
+                    ok = ok and got == acc and np.array_equal(e.slot_map(), slot) and np.array_equal(e.energies(), energy)
+                ok = ok and np.array_equal(e.spins(), s2) and np.array_equal(e.temperatures(), rep_T)
+            if not ok:
+                n_fail += 1
+                print("MISMATCH", desc, "|", e.describe(), flush=True)
+    except Exception as ex:
+        msg = str(ex)
+        if "not integer" in msg or "ternary" in msg or "waves" in msg or "tuning" in msg:
+            pass  # an impossible request (e.g. t2 for non-ternary), not a parity failure
+        else:
+            n_fail += 1
+            print("ERROR", desc, "|", msg[:200], flush=True)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    n_cases += 1
+print(f"{n_cases} cases, {n_fail} failures")
