@@ -14,7 +14,10 @@ t_end = time.time() + budget
 n_cases = n_fail = 0
 while time.time() < t_end:
     kind = rng.choice(["dense", "dense", "csr"])
-    n = int(rng.choice([1, 2, 3, 5, 8, 17, 64, 65, 200, 255, 256, 257, 700, 1023, 1025, 2049, 3000, 5000]))
+    sizes = [1, 2, 3, 5, 8, 17, 64, 65, 200, 255, 256, 257, 700, 1023, 1025, 2049, 3000, 5000]
+    if os.environ.get("FUZZ_BIG"):
+        sizes = [1500, 2049, 3000, 4097, 5000, 7000, 9000, 12000]
+    n = int(rng.choice(sizes))
     if kind == "csr":
         n = max(n, 2)
     R = int(rng.choice([1, 2, 3, 7, 16, 33]))
@@ -39,7 +42,7 @@ while time.time() < t_end:
         env["SGA_FORCE_CSR_BIG"] = "1"
     seed = int(rng.randint(1, 1 << 30))
     temps = np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R) if R > 1 else np.asarray([1.5])
-    mode = str(rng.choice(["plain", "plain", "rules", "pt"]))
+    mode = str(rng.choice(["plain", "plain", "rules", "pt", "batch"]))
     rule = int(rng.choice([0, 1, 2]))
     site_mode = int(rng.choice([0, 1]))
     arith = int(rng.choice([0, 1])) if rule == 0 else 0
@@ -51,6 +54,42 @@ while time.time() < t_end:
     desc = f"{mode} rule={rule} site={site_mode} arith={arith} lad={n_lad} {kind} n={n} R={R} ns={ns} int={integer} dens={dens:.3g} storage={storage} waves={waves} env={env} seed={seed}"
     for k, v in env.items():
         os.environ[k] = v
+    if mode == "batch" and kind == "dense" and n >= 2:
+        try:
+            M, kk = int(rng.choice([2, 3, 5])), int(rng.choice([1, 2, 4]))
+            Js = np.stack([np.triu(rng.randint(-1, 2, (n, n)) if integer else rng.randn(n, n), 1) for _ in range(M)]).astype(np.float32)
+            Js = Js + Js.transpose(0, 2, 1)
+            hs = (rng.randint(-1, 2, (M, n)) if integer else rng.randn(M, n)).astype(np.float32)
+            Rb = M * kk
+            tb = np.tile(np.geomspace(4.0, 0.3, kk) if kk > 1 else np.asarray([1.0]), M)
+            with sg.AnnealEngine(0) as e:
+                if waves:
+                    e.set_tuning(waves_per_replica=waves)
+                e.set_dense_batch(Js, hs, storage="auto" if storage == "t2" else storage)
+                e.init_replicas(Rb, seed=seed)
+                e.set_temperatures(tb)
+                out = e.sweep(ns, energy_trace=True)
+                spins = e.spins()
+                ok = True
+                for m in range(M):
+                    sl = slice(m * kk, (m + 1) * kk)
+                    sm = oracle.init_spins(n, kk, seed, replica0=m * kk)
+                    ref = oracle.sweeps(oracle.Problem(J=Js[m], h=hs[m]), sm, tb[sl], ns, seed=seed, replica0=m * kk)
+                    ok = ok and np.array_equal(out["energy_trace"][:, sl], ref["energy_trace"]) and np.array_equal(spins[sl], sm)
+                if not ok:
+                    n_fail += 1
+                    print("MISMATCH batch", desc, "|", e.describe(), flush=True)
+        except Exception as ex:
+            if not any(t in str(ex) for t in ("not integer", "ternary", "waves", "tuning")):
+                n_fail += 1
+                print("ERROR batch", desc, "|", str(ex)[:200], flush=True)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        n_cases += 1
+        continue
+    if mode == "batch":
+        mode = "plain"
     try:
         if kind == "csr":
             rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
