@@ -15,6 +15,8 @@ with sg.AnnealEngine(0) as e:
     e.init_replicas(R, seed=1)
     e.set_temperatures(np.geomspace(10.0, 0.1, R))
     e.sweep(2)
+    if len(sys.argv) > 4 and sys.argv[4] == "tune":
+        e.autotune()
     e.enable_timing(True)
     t = time.time()
     e.sweep(S)

@@ -144,6 +144,8 @@ struct sga_engine {
     int2 *cv = nullptr;     // [nnz] interleaved (column, value bits): what the kernels read
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
+    double *epart = nullptr;  // per-slice energy sums (few replicas)
+    size_t epart_bytes = 0;
     int tune_waves = 0, tune_spl = 0;
     int rule = SGA_RULE_METROPOLIS;
     bool consistent_dE = true;  // J symmetric with zero diagonal: dE of the rule == energy change
@@ -189,6 +191,8 @@ struct sga_engine {
         dev_free(cv);
         dev_free(h);
         dev_free(diag);
+        dev_free(epart);
+        epart_bytes = 0;
         n = 0;
         ld = 0;
     }
@@ -266,8 +270,21 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
     a.replica_base = e->replica0 + r0;
     a.model_stride_j = (long long)e->n * e->ldj;
+    // few replicas: spread each replica's rows over several workgroups (one workgroup reading all
+    // of J took 47 ms at n = 10^4 -- longer than the reference's CPU mv)
+    a.slices = count >= 512 ? 1 : std::max(1, std::min({256, (1024 + count - 1) / count, e->n / 8}));
+    if (a.slices > 1) {
+        const size_t need = sizeof(double) * 2 * (size_t)count * a.slices;
+        if (need > e->epart_bytes) {
+            dev_free(e->epart);
+            HIPCHK(hipMalloc(&e->epart, need));
+            e->epart_bytes = need;
+        }
+        a.partial = e->epart;
+    }
     HIPCHK(e->csr ? sga::launch_energy_csr(a, e->stream)
                   : sga::launch_energy_dense(a, e->want_i8, e->stream));
+    HIPCHK(sga::launch_energy_finish(a.partial, a.slices, a.energy, count, e->stream));
     return SGA_OK;
 }
 

@@ -70,7 +70,14 @@ struct EnergyArgs {
     double *energy;
     long long ld, ldj;
     int n, sstride, R;
+    // few replicas: the rows of one replica are cut into `slices` contiguous ranges, one workgroup
+    // each (grid = R x slices); the (J-part, h-part) sums land in partial[R][slices][2] and
+    // launch_energy_finish adds them up in slice order.  slices == 1: one workgroup per replica.
+    int slices;
+    double *partial;
 };
+hipError_t launch_energy_finish(const double *partial, int slices, double *energy, int R,
+                                hipStream_t st);
 
 struct ExchangeArgs {
     const double *energies;   // [R_global] by global replica id

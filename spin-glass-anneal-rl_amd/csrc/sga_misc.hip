@@ -412,6 +412,35 @@ hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *b
 // One workgroup (4 waves) per replica; spins in LDS; each wave takes rows w, w+4, ...,
 // streams the row with 16-B loads, DPP-reduces J[i,:].s, rounds it to fp32 as torch.mv does.
 // ---------------------------------------------------------------------------------------
+// E = -1/2 fp32(sum_i mv_i s_i) - fp32(sum_i h_i s_i) (core/ising_model.py:161-168): written
+// directly, or left as this slice's two sums for energy_finish_kernel
+__device__ inline void energy_out(const EnergyArgs &a, int r, double e, double hs) {
+    if (a.slices <= 1) {
+        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+    } else {
+        double *p = a.partial + ((long long)r * a.slices + blockIdx.y) * 2;
+        p[0] = e;
+        p[1] = hs;
+    }
+}
+__global__ void energy_finish_kernel(const double *partial, int slices, double *energy, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double e = 0.0, hs = 0.0;
+    for (int q = 0; q < slices; ++q) {  // fixed order: deterministic
+        e += partial[((long long)r * slices + q) * 2];
+        hs += partial[((long long)r * slices + q) * 2 + 1];
+    }
+    energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+}
+hipError_t launch_energy_finish(const double *partial, int slices, double *energy, int R,
+                                hipStream_t st) {
+    if (slices <= 1) return hipSuccess;
+    hipLaunchKernelGGL(energy_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, st, partial, slices,
+                       energy, R);
+    return hipGetLastError();
+}
+
 template <typename JT>
 __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
     constexpr int EPL = 16 / sizeof(JT), EPC = 64 * EPL;
@@ -421,6 +450,8 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = blockIdx.x;
+    const int rows_per_slice = (a.n + a.slices - 1) / a.slices;
+    const int row0 = blockIdx.y * rows_per_slice, row1 = min(a.n, row0 + rows_per_slice);
     {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
         int4 *dst = reinterpret_cast<int4 *>(s);
@@ -431,7 +462,7 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
     const JT *J = reinterpret_cast<const JT *>(a.J) + model * a.model_stride_j;
     const float *hvec = a.h + (long long)model * a.n;
     double e_acc = 0.0, h_acc = 0.0;
-    for (int i = w; i < a.n; i += 4) {
+    for (int i = row0 + w; i < row1; i += 4) {
         const JT *row = J + (long long)i * a.ldj;
         double acc = 0.0;
         for (long long c = lane * EPL; c < a.ldj; c += EPC) {
@@ -465,7 +496,7 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
     if (tid == 0) {
         const double e = (red[0] + red[1]) + (red[2] + red[3]);
         const double hs = (red[4] + red[5]) + (red[6] + red[7]);
-        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+        energy_out(a, r, e, hs);
     }
 }
 
@@ -479,11 +510,11 @@ hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st
     if (j_is_i8) {
         hipError_t e = set(reinterpret_cast<const void *>(energy_dense_kernel<int8_t>));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(energy_dense_kernel<int8_t>, dim3(a.R), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(energy_dense_kernel<int8_t>, dim3(a.R, a.slices), dim3(256), lds, st, a);
     } else {
         hipError_t e = set(reinterpret_cast<const void *>(energy_dense_kernel<float>));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(energy_dense_kernel<float>, dim3(a.R), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(energy_dense_kernel<float>, dim3(a.R, a.slices), dim3(256), lds, st, a);
     }
     return hipGetLastError();
 }
@@ -504,8 +535,10 @@ __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
         s = reinterpret_cast<const int8_t *>(smem);
         __syncthreads();
     }
+    const int rows_per_slice = (a.n + a.slices - 1) / a.slices;
+    const int row0 = blockIdx.y * rows_per_slice, row1 = min(a.n, row0 + rows_per_slice);
     double e_acc = 0.0, h_acc = 0.0;
-    for (int i = w; i < a.n; i += 4) {
+    for (int i = row0 + w; i < row1; i += 4) {
         double acc = 0.0;
         for (long long j = a.rowptr[i] + lane; j < a.rowptr[i + 1]; j += 64)
         {
@@ -525,7 +558,7 @@ __global__ void __launch_bounds__(256) energy_csr_kernel(const EnergyArgs a) {
     if (tid == 0) {
         const double e = (red[0] + red[1]) + (red[2] + red[3]);
         const double hs = (red[4] + red[5]) + (red[6] + red[7]);
-        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+        energy_out(a, r, e, hs);
     }
 }
 
@@ -544,8 +577,10 @@ __global__ void __launch_bounds__(64 * ENERGY_BIG_WAVES) energy_csr_bits_kernel(
     spins_to_bits(a.spins + (long long)r * a.sstride, bits, a.sstride, tid, blockDim.x);
     __syncthreads();
     auto spin_f = [&](int c) -> float { return ((bits[c >> 5] >> (c & 31)) & 1u) ? -1.0f : 1.0f; };
+    const int rows_per_slice = (a.n + a.slices - 1) / a.slices;
+    const int row0 = blockIdx.y * rows_per_slice, row1 = min(a.n, row0 + rows_per_slice);
     double e_acc = 0.0, h_acc = 0.0;
-    for (int i = w; i < a.n; i += ENERGY_BIG_WAVES) {
+    for (int i = row0 + w; i < row1; i += ENERGY_BIG_WAVES) {
         const long long beg = a.rowptr[i], end = a.rowptr[i + 1];
         double acc = 0.0;
         for (long long j0 = beg + lane; j0 < end; j0 += 64 * ENERGY_BIG_UNROLL) {
@@ -578,7 +613,7 @@ __global__ void __launch_bounds__(64 * ENERGY_BIG_WAVES) energy_csr_bits_kernel(
             e += red[q];
             hs += red[ENERGY_BIG_WAVES + q];
         }
-        a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+        energy_out(a, r, e, hs);
     }
 }
 
@@ -590,11 +625,11 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_bits_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(energy_csr_bits_kernel, dim3(a.R), dim3(64 * ENERGY_BIG_WAVES), lds_bits,
+            hipLaunchKernelGGL(energy_csr_bits_kernel, dim3(a.R, a.slices), dim3(64 * ENERGY_BIG_WAVES), lds_bits,
                                st, a);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL(energy_csr_kernel<false>, dim3(a.R), dim3(256), 64, st, a);
+        hipLaunchKernelGGL(energy_csr_kernel<false>, dim3(a.R, a.slices), dim3(256), 64, st, a);
         return hipGetLastError();
     }
     if (lds > 48 * 1024) {
@@ -602,7 +637,7 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(energy_csr_kernel<true>, dim3(a.R), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(energy_csr_kernel<true>, dim3(a.R, a.slices), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
