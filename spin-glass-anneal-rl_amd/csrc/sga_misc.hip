@@ -714,7 +714,10 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = 0; k < a.count; ++k) {
+    // fields (op 0) are independent: one workgroup per requested site; flips / updates mutate the
+    // replica and stay one serial chain in one workgroup
+    const int k_begin = a.op == 0 ? (int)blockIdx.x : 0, k_end = a.op == 0 ? k_begin + 1 : a.count;
+    for (int k = k_begin; k < k_end; ++k) {
         const int site = a.sites[k];
         double acc = 0.0;
         if constexpr (CSR) {
@@ -776,12 +779,13 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
 }
 
 hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st) {
+    const dim3 grid(a.op == 0 ? (unsigned)(a.count > 0 ? a.count : 1) : 1u);
     if (csr)
-        hipLaunchKernelGGL((point_op_kernel<float, true>), dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((point_op_kernel<float, true>), grid, dim3(256), 0, st, a);
     else if (j_is_i8)
-        hipLaunchKernelGGL((point_op_kernel<int8_t, false>), dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((point_op_kernel<int8_t, false>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((point_op_kernel<float, false>), dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((point_op_kernel<float, false>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
