@@ -135,6 +135,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
     return {"value": R * n * sweeps / dt, "unit": "spin-flip attempts/s", "cores": cores,
             "kind": "port", "energy_gap_vs_gpu": gap,
             "single_thread_value": R1 * n * sw1 / dt1,
+            "build": "oracle/sg_oracle.c, gcc -O3 -fopenmp -ffp-contract=off -mavx2 -mfma (oracle/Makefile)",
             "sample": f"{R} replicas x {sweeps} sweep(s) of the same {n}-spin "
                       f"{'CSR' if csr is not None else 'dense'} instance, OpenMP over replicas"
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
