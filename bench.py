@@ -339,6 +339,8 @@ def main():
         pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
     traffic, traffic_src = pmc_traffic(pmc_tag, "sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
     copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
+    from spin_glass_anneal_rl_amd.engine import probe_read_bandwidth
+    read_gbs = probe_read_bandwidth(local_rank) if rank == 0 else None  # 4 GiB: beyond the caches
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -366,6 +368,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "measured_stream_copy_GBs": copy_gbs,
+                     "measured_stream_read_GBs": read_gbs,
                      "frac_of_measured_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + "
                                      "WRITE_SIZE, separate --pmc passes)",

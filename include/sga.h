@@ -211,6 +211,9 @@ int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, in
 /* Describes the launch geometry chosen for the current problem (for DESIGN/bench output):
  * writes a NUL-terminated string into buf. */
 int sga_describe(sga_engine *e, char *buf, int buflen);
+/* Measurement aid: GB/s of a plain streaming read (16 bytes per lane) of a fresh `bytes`-byte
+ * device buffer, `reps` passes -- the practical bandwidth of this device beside its spec figure. */
+int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per_s);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
 /* Measured choice of the dense launch geometry: times the sweep kernel for every feasible

@@ -544,6 +544,34 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     return SGA_OK;
 }
 
+int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per_s) {
+    if (!gb_per_s || bytes < (1 << 20) || reps < 1) return fail(SGA_ERR_INVALID, "bad probe arguments");
+    HIPCHK(hipSetDevice(device));
+    bytes &= ~(int64_t)15;
+    void *buf = nullptr;
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipMalloc(&buf, (size_t)bytes);
+    if (he == hipSuccess) he = hipMalloc(&sink, sizeof(float));
+    if (he == hipSuccess) he = hipMemset(buf, 0, (size_t)bytes);
+    if (he == hipSuccess) he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = sga::launch_probe_read(buf, bytes, sink, nullptr);  // warm-up
+    if (he == hipSuccess) he = hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps && he == hipSuccess; ++i) he = sga::launch_probe_read(buf, bytes, sink, nullptr);
+    if (he == hipSuccess) he = hipEventRecord(e1, nullptr);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dev_free(buf);
+    dev_free(sink);
+    if (he != hipSuccess) return fail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    *gb_per_s = (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    return SGA_OK;
+}
+
 int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n, int storage) {
     return sga_set_dense_batch(e, J, ldJ, h, n, 1, storage);
 }

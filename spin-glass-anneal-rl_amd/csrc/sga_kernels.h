@@ -150,6 +150,9 @@ hipError_t launch_csr_symmetry(const long long *rowptr, const int32_t *colidx, c
 hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
                             int8_t *best_spins, int sstride, int R, hipStream_t st);
 
+// streaming read of `bytes` (a multiple of 16) of device memory, for the bandwidth probe
+hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipStream_t st);
+
 // single-site operators (IsingModel.get_local_field / flip_spin, SpinDynamics.single_spin_update)
 struct PointArgs {
     const void *J;

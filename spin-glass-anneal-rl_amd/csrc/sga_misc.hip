@@ -850,3 +850,32 @@ hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, co
 }
 
 }  // namespace sga
+
+namespace sga {
+// ---------------------------------------------------------------------------------------
+// Streaming-read probe: what this box delivers to a plain 16-byte-per-lane read of a buffer far
+// larger than the caches -- the practical denominator beside the 8 TB/s spec figure.  (Eight
+// loads in flight per lane and half the workgroups measured 2-4 % lower.)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) probe_read_kernel(const float4 *__restrict__ x, long long n4,
+                                                         float *sink) {
+    float acc = 0.0f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent loads in flight per lane
+        const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) +
+               (d.x + d.y + d.z + d.w);
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = x[i];
+        acc += a.x + a.y + a.z + a.w;
+    }
+    if (acc == 123456.789f) *sink = acc;  // keeps the loads alive
+}
+hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipStream_t st) {
+    hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 32), dim3(256), 0, st,
+                       static_cast<const float4 *>(buf), bytes / 16, sink);
+    return hipGetLastError();
+}
+}  // namespace sga

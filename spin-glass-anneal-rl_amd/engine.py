@@ -45,6 +45,14 @@ def _buf(x, np_dtype, torch_dtype_name):
     return a.ctypes.data_as(C.c_void_p), a
 
 
+def probe_read_bandwidth(device_index: int = 0, nbytes: int = 1 << 32, reps: int = 4) -> float:
+    """GB/s of a plain streaming read of a fresh device buffer (sga_probe_read_bandwidth)."""
+    out = C.c_double(0.0)
+    N.check(N.lib().sga_probe_read_bandwidth(int(device_index), int(nbytes), int(reps), C.byref(out)),
+            "sga_probe_read_bandwidth")
+    return float(out.value)
+
+
 class _SerialisedLib:
     """Calls on one handle must not overlap (include/sga.h); ctypes releases the GIL during a
     call, so the reference's habit of driving sweeps from a thread pool
