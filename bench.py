@@ -378,6 +378,14 @@ def main():
                      "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
+    if csr is not None:
+        nbytes = float(len(csr[1])) * 8.0
+        out["roofline"]["note"] = (
+            f"CSR structure = {nbytes / 1e6:.0f} MB: " +
+            ("cache resident (PMC traffic far below the algorithmic bytes), the sweep is bound by "
+             "instruction issue, not by HBM" if nbytes < 2.0e8 else
+             "streamed from HBM; the wide-row forms are instruction bound (~200 VALU instructions per "
+             "wave and update at degree 4000), DESIGN.md 4.2"))
     # the same workload with the couplings held as int8 / as two bit-planes (what
     # coupling_storage="auto" picks for integer / ternary J; exact arithmetic, identical
     # chain): reported beside the fp32 headline
