@@ -15,14 +15,15 @@ struct UpdatePair {
     float uA, uB;
 };
 
-// Kernels are compiled twice: LEAN = the production configuration (Philox random sites,
-// Metropolis rule in the reference's fp64/fp32 arithmetic, no per-update traces) with every
-// mode test folded away at compile time -- fewer live scalars, no SGPR spills -- and the
-// general variant that also serves the replay / sequential / other-rule / traced modes.
+// Kernels are compiled twice: LEAN = the production configuration (Philox random sites, the
+// reference's fp64/fp32 rule arithmetic, no per-update traces) with the site / arithmetic / trace
+// tests folded away at compile time -- fewer live scalars, no SGPR spills -- and the general
+// variant that also serves the replay / sequential / fp32-operator / traced modes.  The accept
+// table and the look-ahead form are Metropolis only.
 inline bool sweep_args_are_lean(const SweepArgs &a) {
     static const bool force_general = std::getenv("SGA_FORCE_GENERAL") != nullptr;  // A/B switch
     return !force_general && a.site_mode == SGA_SITE_RANDOM && a.arith == SGA_ARITH_F64 &&
-           a.rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
+           !a.accept_trace && !a.dE_trace;  // any rule: it stays a wave-uniform run-time value
 }
 
 // Everything here is wave-uniform (blockIdx / loop counters / kernel arguments).

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     const rp_t *rowptr = nullptr;
     if constexpr (BIG && WIDE) rowptr = a.rowptr64;
     else rowptr = a.rowptr;
-    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
+    const int rule = a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;

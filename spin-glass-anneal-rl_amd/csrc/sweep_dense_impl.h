@@ -98,7 +98,7 @@ constexpr int dense_max_threads() {
 // instruction stream).
 template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false, bool SINGLE = false>
 __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATCH>())) sweep_dense_kernel(const SweepArgs a) {
-    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
+    const int rule = a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     using TR = JTraits<JT>;
     using vec_t = typename TR::vec_t;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // integer problems with few distinct uphill moves: exp(float32(-dE/T)) tabulated per sweep
     // (bit-identical decisions, no fp64 divide / exp on the per-update chain); LEAN only
     float *ptab = reinterpret_cast<float *>(smem + sbytes + DENSE_LDS_EXTRA);  // [table_m + 1]
-    const bool use_tab = LEAN && a.table_m > 0;
+    const bool use_tab = LEAN && a.table_m > 0 && rule == SGA_RULE_METROPOLIS;
 
     const int tid = threadIdx.x;
     const int W = SINGLE ? 1 : (int)(blockDim.x >> 6);
@@ -658,14 +658,14 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         // the 256-thread builds use up to 170 VGPRs = 3 waves per SIMD: only while the launch does
         // not want more than that (n = 1024 fp32: +31 % at 1024 replicas, -5 % at 8192)
         constexpr bool fat = dense_max_threads<JT, CPW, true>() < 1024;
-        if (lean && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
+        if (lean && a.rule == SGA_RULE_METROPOLIS && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
             (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024)))
             kern = waves == 1 ? sweep_dense_kernel<JT, CPW, ACC64, true, true, true>
                               : sweep_dense_kernel<JT, CPW, ACC64, true, true>;
     }
     if (!kern) {
         if constexpr (BITS) {
-            if (!lean) return hipErrorInvalidValue;  // engine falls back to int8
+            if (!lean || a.rule != SGA_RULE_METROPOLIS) return hipErrorInvalidValue;  // engine: int8 copy
             kern = sweep_dense_kernel<JT, CPW, ACC64, true>;
         } else {
             kern = lean ? sweep_dense_kernel<JT, CPW, ACC64, true>
