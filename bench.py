@@ -178,8 +178,8 @@ def pmc_traffic(tag, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2a", choices=["c2a", "c3", "c4", "c5"],
                     help="c2a: dense SK instance (headline); c3: CSR, degree ~32, 4096 replicas; "
                          "c4: 50k-spin scheduling penalties (CSR), 1024 replicas/GPU; "
@@ -300,6 +300,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if a.exchange_interval > 0:
+        pt.exchange()  # one untimed round: first-use allocations of the exchange path happen here
     barrier()
     eng.enable_timing(True)
     eng.kernel_time(reset=True)

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     const rp_t *rowptr = nullptr;
     if constexpr (BIG && WIDE) rowptr = a.rowptr64;
     else rowptr = a.rowptr;
-    const int rule = a.rule;
+    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;  // (a run-time rule costs C3 12 %: issue bound)
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -457,7 +457,7 @@ int csr_bits_waves_per_block(int sstride, int table_m) {  // narrow bit-spin for
 
 template <bool WIDE, bool BIG>
 static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
-    const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a);
+    const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
     const int slots = WIDE ? 1 : waves;
     const size_t lds = csr_lds_per_replica(a.sstride, a.table_m, BIG) * slots +
                        2 * CSR_MAX_WIDE * sizeof(double);
