@@ -303,15 +303,26 @@ def main():
     if a.exchange_interval > 0:
         pt.exchange()  # one untimed round: first-use allocations of the exchange path happen here
     barrier()
-    eng.enable_timing(True)
+    eng.enable_timing(os.environ.get("SGA_BENCH_NOEVENTS") is None)
     eng.kernel_time(reset=True)
+    debug = os.environ.get("SGA_BENCH_DEBUG") is not None
+    marks = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+        if debug:
+            if os.environ.get("SGA_BENCH_DEBUG") == "sync":
+                torch.cuda.synchronize()
+            marks.append(time.perf_counter() - t0)
     barrier()
     dt = time.perf_counter() - t0
+    if debug and rank == 0:
+        print("step end marks (ms): " + " ".join(f"{m * 1e3:.1f}" for m in marks) + f" | total {dt * 1e3:.1f}",
+              file=sys.stderr, flush=True)
     launches, kernel_ms = eng.kernel_time(reset=True)
     eng.enable_timing(False)
+    if debug and rank == 0:
+        print(f"kernel events: {launches} launches, {kernel_ms:.1f} ms", file=sys.stderr, flush=True)
 
     tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
     if dist is not None:

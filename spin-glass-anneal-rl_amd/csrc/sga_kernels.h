@@ -6,6 +6,9 @@
 
 namespace sga {
 
+// Raise a kernel's dynamic-LDS limit once per (device, kernel, size), not on every launch.
+hipError_t ensure_lds_limit(const void *kernel, size_t lds_bytes);
+
 constexpr int MAX_CPW = 10;       // coupling-row chunks a wave holds per buffer (dense)
 constexpr int T2_MAX_CPW = 4;     // same for the bit-plane form (a chunk is two planes = 8 VGPRs)
 constexpr int MAX_WAVES = 16;     // waves per replica workgroup

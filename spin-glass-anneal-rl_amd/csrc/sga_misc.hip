@@ -1,6 +1,9 @@
 // sga_misc.hip -- the kernels around the sweep: coupling repack, spin init, full energy
 // evaluation, replica exchange.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "sweep_common.h"
 
@@ -503,9 +506,7 @@ __global__ void __launch_bounds__(256) energy_dense_kernel(const EnergyArgs a) {
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st) {
     const size_t lds = (size_t)a.sstride + 64;
     auto set = [&](const void *f) {
-        return lds > 48 * 1024
-                   ? hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                   : hipSuccess;
+        return ensure_lds_limit(f, lds);
     };
     if (j_is_i8) {
         hipError_t e = set(reinterpret_cast<const void *>(energy_dense_kernel<int8_t>));
@@ -622,8 +623,7 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
     if (lds > 160 * 1024 - 256) {
         const size_t lds_bits = (size_t)a.sstride / 8 + 2 * ENERGY_BIG_WAVES * sizeof(double);
         if (a.sstride % 128 == 0 && lds_bits <= 160 * 1024 - 256) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_bits_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits);
+            hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(energy_csr_bits_kernel), lds_bits);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(energy_csr_bits_kernel, dim3(a.R, a.slices), dim3(64 * ENERGY_BIG_WAVES), lds_bits,
                                st, a);
@@ -632,9 +632,8 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(energy_csr_kernel<false>, dim3(a.R, a.slices), dim3(256), 64, st, a);
         return hipGetLastError();
     }
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(energy_csr_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(energy_csr_kernel<true>), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(energy_csr_kernel<true>, dim3(a.R, a.slices), dim3(256), lds, st, a);
@@ -877,5 +876,22 @@ hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipS
     hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 32), dim3(256), 0, st,
                        static_cast<const float4 *>(buf), bytes / 16, sink);
     return hipGetLastError();
+}
+}  // namespace sga
+
+namespace sga {
+hipError_t ensure_lds_limit(const void *kernel, size_t lds_bytes) {
+    if (lds_bytes <= 48 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[{dev, kernel}];
+    if (have >= lds_bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) have = lds_bytes;
+    return e;
 }
 }  // namespace sga

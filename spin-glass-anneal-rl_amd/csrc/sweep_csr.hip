@@ -463,9 +463,8 @@ static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
                        2 * CSR_MAX_WIDE * sizeof(double);
     auto kern = fast ? (lean ? sweep_csr_kernel<true, true, WIDE, BIG> : sweep_csr_kernel<true, false, WIDE, BIG>)
                      : (lean ? sweep_csr_kernel<false, true, WIDE, BIG> : sweep_csr_kernel<false, false, WIDE, BIG>);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
     }
     const int blocks = WIDE ? a.R : (a.R + waves - 1) / waves;

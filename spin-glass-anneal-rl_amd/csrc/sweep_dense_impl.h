@@ -676,9 +676,8 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
             }
         }
     }
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
