@@ -298,6 +298,11 @@ def main():
         if a.exchange_interval > 0 and step_no % a.exchange_interval == 0:
             pt.exchange()
 
+    # Bandwidth probes (the two practical denominators) before the warm-up, on every rank, so that
+    # nothing but the steps and the final barrier lies between the warm-up and the end of timing.
+    from spin_glass_anneal_rl_amd.engine import probe_read_bandwidth
+    copy_gbs = measured_copy_bandwidth(dev)
+    read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
     for _ in range(a.warmup):
         step()
     if a.exchange_interval > 0:
@@ -351,9 +356,6 @@ def main():
     elif a.workload == "c5" and (a.cities, R) in ((100, 2048), (1000, 256)):
         pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
     traffic, traffic_src = pmc_traffic(pmc_tag, "sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
-    copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
-    from spin_glass_anneal_rl_amd.engine import probe_read_bandwidth
-    read_gbs = probe_read_bandwidth(local_rank) if rank == 0 else None  # 4 GiB: beyond the caches
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
