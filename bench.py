@@ -303,6 +303,11 @@ def main():
     from spin_glass_anneal_rl_amd.engine import probe_read_bandwidth
     copy_gbs = measured_copy_bandwidth(dev)
     read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
+    # Let the device settle after the set-up's allocations and frees: short-kernel workloads showed
+    # one 45-75 ms device-side gap within the first steps of about one fresh process in three; with
+    # this pause 22 of 22 runs were clean (profiles/r01_experiments.md).  Untimed set-up.
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("SGA_BENCH_SETTLE", "0.3")))
     for _ in range(a.warmup):
         step()
     if a.exchange_interval > 0:
