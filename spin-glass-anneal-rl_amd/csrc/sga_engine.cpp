@@ -171,6 +171,7 @@ struct sga_engine {
     // staging slots: 0 sched, 1 replay sites, 2 replay u, 3 energy trace, 4 accept trace,
     // 5 dE trace, 6 exchange energies, 7 exchange start, 8 exchange u
     Scratch scratch[9];
+    Scratch point_sites, point_out;  // single-site operators
 
     // timing
     bool timing = false;
@@ -405,6 +406,8 @@ void sga_destroy(sga_engine *e) {
     e->free_replicas();
     e->free_problem();
     for (auto &sl : e->scratch) sl.release();
+    e->point_sites.release();
+    e->point_out.release();
     dev_free(e->d_count);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -1108,12 +1111,12 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         std::memcpy(hs.data(), sites, sizeof(int32_t) * hs.size());
     for (int32_t v : hs)
         if (v < 0 || v >= e->n) return fail(SGA_ERR_INVALID, "site index out of range");
-    int32_t *d_sites = nullptr;
-    double *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_sites, sizeof(int32_t) * hs.size()));
-    hipError_t he = hipMalloc(&d_out, sizeof(double) * (size_t)std::max(out_count, 2));
-    if (he == hipSuccess)
-        he = hipMemcpyAsync(d_sites, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st);
+    // staging in grow-only scratch slots (no allocation / free per call)
+    HIPCHK(e->point_sites.reserve(sizeof(int32_t) * hs.size()));
+    HIPCHK(e->point_out.reserve(sizeof(double) * (size_t)std::max(out_count, 2)));
+    int32_t *d_sites = static_cast<int32_t *>(e->point_sites.ptr);
+    double *d_out = static_cast<double *>(e->point_out.ptr);
+    hipError_t he = hipMemcpyAsync(d_sites, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st);
     if (he == hipSuccess) {
         sga::PointArgs a{};
         const long long model = e->n_models > 1 ? (e->replica0 + r) / (e->Rg / e->n_models) : 0;
@@ -1142,8 +1145,6 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
     if (he == hipSuccess)
         he = hipMemcpyAsync(out_host, d_out, sizeof(double) * (size_t)out_count, hipMemcpyDeviceToHost, st);
     if (he == hipSuccess) he = hipStreamSynchronize(st);
-    (void)hipFree(d_sites);
-    (void)hipFree(d_out);
     HIPCHK(he);
     if (op != 0 && !e->consistent_dE) {  // the rule's dE is not the energy change here
         int rc = recompute_energy_range(e, r, 1);
