@@ -131,6 +131,12 @@ while time.time() < t_end:
                 out = e.sweep(ns, site_mode=site_mode, arith=arith, replay_u=u_seq, energy_trace=True, trace=True)
                 ok = (np.array_equal(out["accept_trace"], ref["accept_trace"])
                       and np.array_equal(out["dE_trace"], ref["dE_trace"]) and np.array_equal(e.spins(), s))
+                if not ok:
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez("gpurun_out/fuzz_fail.npz", J=J, h=h, temps=temps, u=u_seq if u_seq is not None else np.zeros(0),
+                             acc_gpu=out["accept_trace"], acc_ref=ref["accept_trace"], dE_gpu=out["dE_trace"],
+                             dE_ref=ref["dE_trace"], spins_gpu=e.spins(), spins_ref=s,
+                             meta=np.asarray([n, R, ns, rule, site_mode, arith, waves, seed]))
             else:  # tempering: sweeps and exchange rounds on 1-3 ladders
                 e.set_ladder(slot_temps, n_lad)
                 slot = np.arange(R, dtype=np.int32)
