@@ -175,6 +175,38 @@ def pmc_traffic(tag, kernel):
     return None, None
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without torchrun: this process has made no GPU call yet; it
+    starts N child processes of the same command line, one rank per GPU, with the rendezvous in
+    the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relays rank 0's
+    JSON line and fails if any rank fails.  (Children are started, never exec'ed into.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:  # a rank left behind by a failed peer: stop exactly it
+            p.kill()
+            codes.append(p.wait())
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,10 +238,12 @@ def main():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)  # before anything here has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
@@ -315,6 +349,7 @@ def main():
     barrier()
     eng.enable_timing(os.environ.get("SGA_BENCH_NOEVENTS") is None)
     eng.kernel_time(reset=True)
+    pt.gather_calls, pt.gather_ms = 0, 0.0
     debug = os.environ.get("SGA_BENCH_DEBUG") is not None
     marks = []
     t0 = time.perf_counter()
@@ -375,6 +410,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if (a.storage == "f32" or csr is not None) else ("i8" if a.storage == "i8" else "b2"),
         "data": "synthetic",
+        "ranks_seen": dist.get_world_size() if dist is not None else 1,
+        "backend": (dist.get_backend() if dist is not None else None),
+        "exchange": {"rounds_timed": pt.gather_calls, "allgather_ms_per_round":
+                     (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
+                     "bytes_per_rank": 8 * R},
         "config": {"workload": (f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
                                 (label or f"C3: {n}-spin CSR +-1 Ising") +
                                 f", CSR mean degree {len(csr[1]) / n:.1f}") +

@@ -164,19 +164,54 @@ static inline float row_dot_f32(int n, const float *J, int64_t ld, const int32_t
             for (; j < n; ++j) acc += row[j] * (float)s[j];
             return acc;
         }
-        double lane[8] = {0};
-        int j = 0;
-        for (; j + 8 <= n; j += 8)
-            for (int q = 0; q < 8; ++q) lane[q] += (double)(row[j + q] * (float)s[j + q]);
-        double acc = ((lane[0] + lane[1]) + (lane[2] + lane[3])) +
-                     ((lane[4] + lane[5]) + (lane[6] + lane[7]));
-        for (; j < n; ++j) acc += (double)(row[j] * (float)s[j]);
-        return (float)acc;
+        /* Real-valued J: fp32 products (exact), summed in double in the CANONICAL ORDER the HIP
+         * kernels use for every launch geometry (sweep_dense_impl.h): 256-element chunks; within
+         * a chunk lane l of 64 adds its four products ((e0 + e1) + e2) + e3 starting from +0,
+         * the 64 lane sums are folded by an adjacent-pairs tree, and the chunk sums are added in
+         * chunk order.  The double sum is rounded to fp32 once (torch.dot returns fp32). */
+        double total = 0.0;
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            double lane[64];
+            for (int l = 0; l < 64; ++l) {
+                double p = 0.0;
+                for (int q = 0; q < 4; ++q) {
+                    int j = c0 + 4 * l + q;
+                    if (j < n) p += (double)(row[j] * (float)s[j]);
+                }
+                lane[l] = p;
+            }
+            for (int stride = 1; stride < 64; stride *= 2)
+                for (int l = 0; l < 64; l += 2 * stride) lane[l] = lane[l] + lane[l + stride];
+            total = (c0 == 0) ? lane[0] : total + lane[0];
+        }
+        return (float)total;
     }
-    double acc = 0.0;
-    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-        acc += (double)(val[k] * (float)s[colidx[k]]);
-    return (float)acc;
+    /* CSR, same idea with the entries of the row in storage order: entry e belongs to lane e % 64
+     * of virtual wave (e / 64) % 8; a virtual lane adds its entries in storage order, each
+     * virtual wave folds its 64 lanes by the adjacent-pairs tree, and the 8 wave sums are added
+     * in order (sweep_csr.hip: 1, 2, 4 or 8 real waves per replica all reproduce it). */
+    double lanes[8][64];
+    int used = 0;
+    const int32_t beg = rowptr[i], len = rowptr[i + 1] - rowptr[i];
+    for (int e = 0; e < len; ++e) {
+        int v = (e >> 6) & 7, l = e & 63;
+        double t = (double)(val[beg + e] * (float)s[colidx[beg + e]]);
+        if ((e >> 9) == 0) {
+            lanes[v][l] = t;
+            if (v + 1 > used) used = v + 1;
+        } else {
+            lanes[v][l] += t;
+        }
+    }
+    double total = 0.0;
+    for (int v = 0; v < used; ++v) {
+        int filled = len - 64 * v; /* lanes of the first pass that hold an entry */
+        for (int l = (filled > 64 ? 64 : filled); l < 64; ++l) lanes[v][l] = 0.0;
+        for (int stride = 1; stride < 64; stride *= 2)
+            for (int l = 0; l < 64; l += 2 * stride) lanes[v][l] = lanes[v][l] + lanes[v][l + stride];
+        total = (v == 0) ? lanes[v][0] : total + lanes[v][0];
+    }
+    return (float)total;
 }
 static inline float diag_elem(int n, const float *J, int64_t ld, const int32_t *rowptr,
                               const int32_t *colidx, const float *val, int i) {

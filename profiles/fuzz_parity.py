@@ -90,6 +90,7 @@ while time.time() < t_end:
         continue
     if mode == "batch":
         mode = "plain"
+    out = ref = None
     try:
         if kind == "csr":
             rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
@@ -117,8 +118,10 @@ while time.time() < t_end:
                 e.set_dense(J, h, storage=storage)
             e.init_replicas(R, seed=seed)
             e.set_temperatures(temps)
-            if rng.rand() < 0.3 and kind == "dense":
+            tuned = bool(rng.rand() < 0.3 and kind == "dense")
+            if tuned:
                 e.autotune()
+            geom = e.describe()  # the geometry the case really ran with (autotune picks by timing)
             if mode == "plain":
                 out = e.sweep(ns, energy_trace=True)
                 ok = (np.array_equal(out["energy_trace"], ref["energy_trace"]) and np.array_equal(e.spins(), s)
@@ -131,12 +134,6 @@ while time.time() < t_end:
                 out = e.sweep(ns, site_mode=site_mode, arith=arith, replay_u=u_seq, energy_trace=True, trace=True)
                 ok = (np.array_equal(out["accept_trace"], ref["accept_trace"])
                       and np.array_equal(out["dE_trace"], ref["dE_trace"]) and np.array_equal(e.spins(), s))
-                if not ok:
-                    os.makedirs("gpurun_out", exist_ok=True)
-                    np.savez("gpurun_out/fuzz_fail.npz", J=J, h=h, temps=temps, u=u_seq if u_seq is not None else np.zeros(0),
-                             acc_gpu=out["accept_trace"], acc_ref=ref["accept_trace"], dE_gpu=out["dE_trace"],
-                             dE_ref=ref["dE_trace"], spins_gpu=e.spins(), spins_ref=s,
-                             meta=np.asarray([n, R, ns, rule, site_mode, arith, waves, seed]))
             else:  # tempering: sweeps and exchange rounds on 1-3 ladders
                 e.set_ladder(slot_temps, n_lad)
                 slot = np.arange(R, dtype=np.int32)
@@ -161,7 +158,14 @@ while time.time() < t_end:
                 ok = ok and np.array_equal(e.spins(), s2) and np.array_equal(e.temperatures(), rep_T)
             if not ok:
                 n_fail += 1
-                print("MISMATCH", desc, "|", e.describe(), flush=True)
+                # self-describing record: what ran (geometry after autotune included) and the inputs
+                os.makedirs("gpurun_out", exist_ok=True)
+                dump = f"gpurun_out/fuzz_fail_{n_fail}.npz"
+                np.savez(dump, J=J, h=h, temps=temps, desc=np.asarray(desc), geometry=np.asarray(geom),
+                         autotuned=np.asarray(tuned), spins_gpu=e.spins(), spins_ref=s,
+                         **{k: v for k, v in (out or {}).items() if v is not None},
+                         **{"ref_" + k: v for k, v in (ref or {}).items() if isinstance(v, np.ndarray)})
+                print("MISMATCH", desc, f"autotuned={tuned} |", geom, "| inputs and both results in", dump, flush=True)
     except Exception as ex:
         msg = str(ex)
         if "not integer" in msg or "ternary" in msg or "waves" in msg or "tuning" in msg:

@@ -126,7 +126,6 @@ struct sga_engine {
     int n = 0;
     int n_models = 1;  // dense batches: models stacked row-wise, replicas split evenly
     bool csr = false;
-    float *J_raw = nullptr;  // dense fp32 [n][n], engine copy of the caller's matrix
     bool want_i8 = false, acc64 = false;
     bool use_t2 = false;           // ternary J as two bit-planes for the production sweeps
     unsigned int *J_bits = nullptr;  // [2][n][ld/32]
@@ -167,6 +166,7 @@ struct sga_engine {
     int32_t *slot_to_rep = nullptr;
     long long *ex_attempts = nullptr, *ex_accepts = nullptr;
     int *d_count = nullptr;
+    int *d_flags = nullptr;  // [16] value / structure scan results of the set_* calls (one per engine)
 
     // staging slots: 0 sched, 1 replay sites, 2 replay u, 3 energy trace, 4 accept trace,
     // 5 dE trace, 6 exchange energies, 7 exchange start, 8 exchange u
@@ -180,7 +180,6 @@ struct sga_engine {
     double total_ms = 0.0;
 
     void free_problem() {
-        dev_free(J_raw);
         dev_free(J_packed);
         dev_free(J_bits);
         dev_free(row_nnz);
@@ -226,6 +225,10 @@ long long t2_row_bits(int n) { return ((long long)n + 127) / 128 * 128; }  // 16
 bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
                      int max_cpw = sga::MAX_CPW) {
     const int C = (n + epc - 1) / epc;
+    // A wave beyond the row's last chunk would hold nothing but pad lanes (every lane redirected
+    // to the row's first granule against zero pad spins): a forced count is clamped to the chunk
+    // count, so that no geometry the heuristic itself would refuse is reachable by tuning.
+    if (forced_waves > C) forced_waves = C;
     double target = 8192.0 / std::max(R, 1);
     target = std::min(16.0, std::max(1.0, target));
     double best_cost = 1e30;
@@ -248,8 +251,10 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
             CPW = cpw;
         }
     }
-    if (W == 0) {  // row too long for the register-resident form: streaming kernel, 16 waves
-        W = forced_waves > 0 ? forced_waves : sga::MAX_WAVES;
+    if (W == 0) {
+        // only reached when the row is too long for the register-resident form (more than max_cpw
+        // chunks per wave at the forced / at 16 waves): streaming kernel.  forced_waves <= C here.
+        W = forced_waves > 0 ? forced_waves : std::min(sga::MAX_WAVES, C);
         CPW = (C + W - 1) / W;
     }
     return true;
@@ -289,10 +294,12 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
     return SGA_OK;
 }
 
-// (Re)build the packed dense layout(s) for the current replica count / tuning.
+// Launch geometry of the dense kernels for the current replica count / tuning.  The packed
+// matrices are laid out by n alone (pack_dense, at set time), so a change of geometry never
+// touches them.
 int ensure_packed(sga_engine *e) {
     if (e->csr) return SGA_OK;
-    if (!e->J_raw) return fail(SGA_ERR_INVALID, "no couplings set");
+    if (!e->J_packed) return fail(SGA_ERR_INVALID, "no couplings set");
     int W, CPW;
     long long ld;
     if (e->use_t2) {
@@ -305,38 +312,35 @@ int ensure_packed(sga_engine *e) {
         ld = (long long)Wb * Cb * T2_ELEMS_PER_CHUNK;
         W = 8;
         CPW = Wb * Cb;
-        if (e->J_packed && e->J_bits && e->ld == ld && e->waves_t2 == Wb && e->cpw_t2 == Cb)
-            return SGA_OK;
-        if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
+        if (e->ld == ld && e->waves_t2 == Wb && e->cpw_t2 == Cb) return SGA_OK;
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m, false) > 160 * 1024)
             return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
         e->waves_t2 = Wb;
         e->cpw_t2 = Cb;
     } else {
         choose_geometry(e->n, elems_per_chunk(e->want_i8), std::max(e->R, 1), e->tune_waves, W, CPW);
         ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
-        if (e->J_packed && e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
-        if (sga::sweep_dense_lds_bytes(ld, e->table_m) > 160 * 1024)
+        if (e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m, e->acc64) > 160 * 1024)
             return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     }
-    if (e->J_packed && (!e->use_t2 || e->J_bits)) {
-        // only the launch geometry changed: the packed matrices are laid out by n, not by it
-        e->waves = W;
-        e->cpw = CPW;
-        e->ld = ld;
-        return SGA_OK;
-    }
-    dev_free(e->J_packed);
-    dev_free(e->J_bits);
-    dev_free(e->row_nnz);
+    e->waves = W;
+    e->cpw = CPW;
+    e->ld = ld;
+    return SGA_OK;
+}
+
+// Pack the caller's fp32 matrix (device pointer `src`, row stride ld_src) into the engine's
+// layout(s): rows packed to 128 bytes, not padded to the kernel's whole chunks (2.4 % fewer bytes
+// per attempt at n = 10^4); lanes past a row's end re-read its first granule.
+int pack_dense(sga_engine *e, const float *src, long long ld_src) {
     const long long rows = (long long)e->n_models * e->n;
-    // rows are packed to 128 bytes, not padded to the kernel's whole chunks (2.4 % fewer bytes per
-    // attempt at n = 10^4); lanes past a row's end re-read its first granule
     const long long elem = e->want_i8 ? 1 : 4;
     const long long ldj = ((long long)e->n * elem + 127) / 128 * 128 / elem;
     const size_t bytes = (size_t)rows * ldj * elem;
     HIPCHK(hipMalloc(&e->J_packed, bytes));
-    HIPCHK(sga::launch_repack_dense(e->J_raw, e->n, rows, e->n, e->J_packed, ldj, e->want_i8,
-                                    e->diag, e->stream));
+    HIPCHK(sga::launch_repack_dense(src, ld_src, rows, e->n, e->J_packed, ldj, e->want_i8, e->diag,
+                                    e->stream));
     e->ldj = ldj;
     if (e->use_t2) {
         // a plane's rows are packed at 16-byte granularity, not padded to the kernel's 1-KiB chunks
@@ -345,11 +349,8 @@ int ensure_packed(sga_engine *e) {
         const long long row_bits = t2_row_bits(e->n);
         HIPCHK(hipMalloc(&e->J_bits, sizeof(unsigned int) * 2 * (size_t)e->n * (size_t)(row_bits / 32)));
         HIPCHK(hipMalloc(&e->row_nnz, sizeof(float) * (size_t)e->n));
-        HIPCHK(sga::launch_repack_tern2(e->J_raw, e->n, e->J_bits, row_bits, e->row_nnz, e->stream));
+        HIPCHK(sga::launch_repack_tern2(src, ld_src, e->n, e->J_bits, row_bits, e->row_nnz, e->stream));
     }
-    e->waves = W;
-    e->cpw = CPW;
-    e->ld = ld;
     return SGA_OK;
 }
 
@@ -386,7 +387,9 @@ int sga_create(int device, sga_engine **out) {
     }
     eng->stream = eng->own_stream;
     e = hipMalloc(&eng->d_count, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&eng->d_flags, 16 * sizeof(int));
     if (e != hipSuccess) {
+        dev_free(eng->d_count);
         (void)hipStreamDestroy(eng->own_stream);
         delete eng;
         return fail(SGA_ERR_MEMORY, "hipMalloc failed");
@@ -409,6 +412,7 @@ void sga_destroy(sga_engine *e) {
     e->point_sites.release();
     e->point_out.release();
     dev_free(e->d_count);
+    dev_free(e->d_flags);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -595,38 +599,37 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     e->n = n;
     e->n_models = n_models;
     const long long rows = (long long)n_models * n;
-    HIPCHK(hipMalloc(&e->J_raw, sizeof(float) * (size_t)rows * n));
-    HIPCHK(hipMemcpy2DAsync(e->J_raw, sizeof(float) * (size_t)n, J, sizeof(float) * (size_t)ldJ,
-                            sizeof(float) * (size_t)n, (size_t)rows, hipMemcpyDefault, e->stream));
+    // A device matrix is scanned and packed where it lies; a host matrix is staged first.  Either
+    // way nothing but the packed layout(s) stays resident (400 MB, not 800, at n = 10^4 fp32).
+    const float *src = J;
+    long long ld_src = ldJ;
+    struct Staged {
+        float *p = nullptr;
+        ~Staged() { dev_free(p); }
+    } staged;
+    if (!is_device_ptr(J)) {
+        HIPCHK(hipMalloc(&staged.p, sizeof(float) * (size_t)rows * n));
+        HIPCHK(hipMemcpy2DAsync(staged.p, sizeof(float) * (size_t)n, J, sizeof(float) * (size_t)ldJ,
+                                sizeof(float) * (size_t)n, (size_t)rows, hipMemcpyHostToDevice, e->stream));
+        src = staged.p;
+        ld_src = n;
+    }
     HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)rows));
     HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)rows, hipMemcpyDefault, e->stream));
     HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)rows));
     // value scans over all models: can J live in int8; is fp32 accumulation exact; is the
-    // problem integer valued with few possible uphill moves (per-sweep accept table)?
-    int *flags = nullptr;
-    HIPCHK(hipMalloc(&flags, 4 * sizeof(int)));
+    // problem integer valued with few possible uphill moves (per-sweep accept table); is J
+    // symmetric with a zero diagonal (dE of the rule == energy change)?
+    int *flags = e->d_flags;  // [0..3] value scans, [4] symmetry / diagonal
     unsigned int *uflags = reinterpret_cast<unsigned int *>(flags) + 2;
-    int hflags[4] = {1, 1, 0, 1};
-    hipError_t le = hipMemsetAsync(flags, 0, 4 * sizeof(int), e->stream);
-    if (le == hipSuccess) le = sga::launch_scan_values(e->J_raw, rows, n, n, flags, e->stream);
-    if (le == hipSuccess)
-        le = sga::launch_dense_row_abs_max(e->J_raw, n, e->h, rows, n, uflags, e->stream);
-    if (le == hipSuccess)
-        le = hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, e->stream);
-    if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
-    (void)hipFree(flags);
-    HIPCHK(le);
-    {
-        int *d_bad = nullptr, h_bad = 0;
-        HIPCHK(hipMalloc(&d_bad, sizeof(int)));
-        hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(int), e->stream);
-        if (he == hipSuccess) he = sga::launch_check_symmetric(e->J_raw, rows, n, d_bad, e->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-        (void)hipFree(d_bad);
-        HIPCHK(he);
-        e->consistent_dE = h_bad == 0;
-    }
+    int hflags[5] = {1, 1, 0, 1, 1};
+    HIPCHK(hipMemsetAsync(flags, 0, 5 * sizeof(int), e->stream));
+    HIPCHK(sga::launch_scan_values(src, rows, n, ld_src, flags, e->stream));
+    HIPCHK(sga::launch_dense_row_abs_max(src, ld_src, e->h, rows, n, uflags, e->stream));
+    HIPCHK(sga::launch_check_symmetric(src, ld_src, rows, n, flags + 4, e->stream));
+    HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->consistent_dE = hflags[4] == 0;
     const bool fits_i8 = hflags[0] == 0;
     if (storage == SGA_J_I8 && !fits_i8)
         return fail(SGA_ERR_INVALID, "int8 storage requested but J is not integer in [-127,127]");
@@ -643,7 +646,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     e->acc64 = !e->want_i8 && !((nonint & 1u) == 0u && m < 16777216.0f);
     // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
     if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
-    return ensure_packed(e);
+    int rc = pack_dense(e, src, ld_src);
+    if (rc == SGA_OK) rc = ensure_packed(e);
+    // the source (the caller's buffer, or the staging copy about to be released) is done with
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return rc;
 }
 
 // CSR problem from 32- or 64-bit row extents (host or device pointers).  The structure is
@@ -688,15 +695,14 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
     HIPCHK(hipMalloc(&e->diag, sizeof(float) * (size_t)n));
 
-    int *d_flags = nullptr;
+    int *d_flags = e->d_flags;
     int flags[sga::CSR_FLAG_COUNT] = {0};
-    HIPCHK(hipMalloc(&d_flags, sizeof(flags)));
+    static_assert(sga::CSR_FLAG_COUNT <= 16, "engine flag words");
     auto read_flags = [&]() -> hipError_t {
         hipError_t he = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, e->stream);
         return he == hipSuccess ? hipStreamSynchronize(e->stream) : he;
     };
     auto bail = [&](int code, const char *msg) {
-        dev_free(d_flags);
         e->free_problem();
         return fail(code, msg);
     };
@@ -724,7 +730,6 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     } else {
         flags[sga::CSR_ASYMMETRIC] = 1;
     }
-    dev_free(d_flags);
     e->consistent_dE = !flags[sga::CSR_ASYMMETRIC] && !flags[sga::CSR_DIAGONAL];
     // integer-valued problem?  then dE takes at most M = max_i(sum_j |J_ij| + |h_i|) even values
     float m;
@@ -836,6 +841,13 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             // waves -> 2.98 / 3.69 / 3.67 / 3.34 e8 attempts/s; C5, R = 2048: 1.55 vs 1.19 e9).
             const int wpr = e->tune_waves > 0 ? e->tune_waves : ((long_rows && R_local <= 1024) ? 2 : 1);
             e->waves = std::min(wpr, 8);
+        }
+        // real-valued rows are summed in the canonical order of sweep_csr.hip, whose wide builds
+        // exist for 1, 2, 4 and 8 waves per replica
+        if (e->table_m == 0 || !e->consistent_dE) {
+            int p2 = 1;
+            while (p2 < e->waves) p2 *= 2;
+            e->waves = std::min(p2, 8);
         }
         e->cpw = 0;
     }
@@ -1440,18 +1452,23 @@ int sga_set_sweep_counter(sga_engine *e, uint32_t sweeps_done, uint32_t exchange
 }
 
 // ---- checkpoint / resume -------------------------------------------------------------------
+// The blob is independent of the launch geometry: spins travel unpadded ([R][n]), so a state
+// exported after sga_autotune / sga_set_tuning imports into an engine laid out for any other
+// waves-per-replica.  (The chain itself does not depend on the geometry either: integer problems
+// sum exactly, real-valued ones in the canonical chunk order of sweep_dense_impl.h.)
 namespace {
 struct StateHeader {
     uint64_t magic;
-    int32_t n, R, Rg, replica0, sstride, n_ladders;
+    int32_t version, n, R, Rg, replica0, n_ladders;
     uint32_t sweeps_done, rounds;
     uint64_t seed;
     int64_t attempted;
 };
 constexpr uint64_t STATE_MAGIC = 0x5347415354415445ull;  // "SGASTATE"
+constexpr int32_t STATE_VERSION = 2;
 
 uint64_t state_bytes(const sga_engine *e) {
-    const uint64_t R = (uint64_t)e->R, Rg = (uint64_t)e->Rg, sb = R * (uint64_t)e->sstride;
+    const uint64_t R = (uint64_t)e->R, Rg = (uint64_t)e->Rg, sb = R * (uint64_t)e->n;
     uint64_t total = sizeof(StateHeader) + 2 * sb + 3 * R * sizeof(double) + R * sizeof(uint64_t);
     if (e->n_ladders > 0) total += Rg * (sizeof(int32_t) + 2 * sizeof(int64_t));
     return total;
@@ -1468,7 +1485,7 @@ int sga_export_state(sga_engine *e, void *buf, uint64_t capacity, uint64_t *need
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     unsigned char *p = static_cast<unsigned char *>(buf);
-    StateHeader h{STATE_MAGIC, e->n, e->R, e->Rg, e->replica0, e->sstride, e->n_ladders,
+    StateHeader h{STATE_MAGIC, STATE_VERSION, e->n, e->R, e->Rg, e->replica0, e->n_ladders,
                   e->sweeps_done, e->rounds, e->seed, (int64_t)e->attempted};
     std::memcpy(p, &h, sizeof(h));
     p += sizeof(h);
@@ -1477,9 +1494,15 @@ int sga_export_state(sga_engine *e, void *buf, uint64_t capacity, uint64_t *need
         p += bytes;
         return r;
     };
-    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->sstride;
-    HIPCHK(pull(e->spins, sb));
-    HIPCHK(pull(e->best_spins, sb));
+    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->n;
+    // spins leave the padded device layout through a staging slot
+    HIPCHK(e->scratch[1].reserve(sb));
+    int8_t *stage = static_cast<int8_t *>(e->scratch[1].ptr);
+    for (const int8_t *src : {e->spins, e->best_spins}) {
+        HIPCHK(sga::launch_unpad_spins(src, e->sstride, stage, e->n, e->R, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(pull(stage, sb));
+    }
     HIPCHK(pull(e->energy, R * sizeof(double)));
     HIPCHK(pull(e->best_energy, R * sizeof(double)));
     HIPCHK(pull(e->rep_temp, R * sizeof(double)));
@@ -1499,8 +1522,9 @@ int sga_import_state(sga_engine *e, const void *buf, uint64_t size) {
     StateHeader h;
     std::memcpy(&h, buf, sizeof(h));
     if (h.magic != STATE_MAGIC) return fail(SGA_ERR_INVALID, "not an engine state blob");
+    if (h.version != STATE_VERSION) return fail(SGA_ERR_INVALID, "state blob of another engine version");
     if (h.n != e->n || h.R != e->R || h.Rg != e->Rg || h.replica0 != e->replica0 ||
-        h.sstride != e->sstride || h.n_ladders != e->n_ladders)
+        h.n_ladders != e->n_ladders)
         return fail(SGA_ERR_INVALID, "state blob does not match this engine's problem / replicas / ladder");
     if (size != state_bytes(e)) return fail(SGA_ERR_INVALID, "state blob has the wrong size");
     HIPCHK(hipSetDevice(e->device));
@@ -1511,9 +1535,14 @@ int sga_import_state(sga_engine *e, const void *buf, uint64_t size) {
         p += bytes;
         return r;
     };
-    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->sstride;
-    HIPCHK(push(e->spins, sb));
-    HIPCHK(push(e->best_spins, sb));
+    const size_t R = (size_t)e->R, Rg = (size_t)e->Rg, sb = R * (size_t)e->n;
+    HIPCHK(e->scratch[1].reserve(sb));
+    int8_t *stage = static_cast<int8_t *>(e->scratch[1].ptr);
+    for (int8_t *dst : {e->spins, e->best_spins}) {
+        HIPCHK(push(stage, sb));
+        HIPCHK(sga::launch_pad_spins(stage, e->n, dst, e->sstride, e->R, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     HIPCHK(push(e->energy, R * sizeof(double)));
     HIPCHK(push(e->best_energy, R * sizeof(double)));
     HIPCHK(push(e->rep_temp, R * sizeof(double)));

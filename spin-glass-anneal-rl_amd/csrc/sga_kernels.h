@@ -104,8 +104,8 @@ int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int 
 // ternary couplings as two bit-planes (production configuration only)
 hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStream_t st);
 // fp32 [n][n] -> sign plane + non-zero plane, each [n][row_bits/32] words, plus nnz[n] (as float)
-hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long row_bits,
-                               float *row_nnz, hipStream_t st);
+hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned int *planes,
+                               long long row_bits, float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 bool csr_big_fits(int sstride, int table_m);         // spins as bits: one replica per workgroup
@@ -177,7 +177,8 @@ struct PointArgs {
 hipError_t launch_point_op(const PointArgs &a, bool csr, bool j_is_i8, hipStream_t st);
 
 // 1 -> out[0] if some J[i][j] != J[j][i] or J[i][i] != 0 (per model block of n rows)
-hipError_t launch_check_symmetric(const float *J, long long rows, int n, int *out, hipStream_t st);
+hipError_t launch_check_symmetric(const float *J, long long ldJ, long long rows, int n, int *out,
+                                  hipStream_t st);
 // best[r] = min(best[r], energy[r]) with the spins, one workgroup per replica
 hipError_t launch_update_best(const double *energy, const int8_t *spins, double *best_energy,
                               int8_t *best_spins, int sstride, int R, hipStream_t st);
@@ -189,7 +190,7 @@ hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, co
                               hipStream_t st);
 
 // dynamic LDS bytes the dense sweep kernel needs for a given geometry
-size_t sweep_dense_lds_bytes(long long ld, int table_m);
+size_t sweep_dense_lds_bytes(long long ld, int table_m, bool acc64);
 // integrality and max_i(sum_j |J_ij| + |h_i|) of a dense problem: out[0] = float bits of the
 // max, out[1] bit 0 = some J is not an integer, bit 1 = some h is not an integer
 hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, long long rows,

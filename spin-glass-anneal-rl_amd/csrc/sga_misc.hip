@@ -106,8 +106,8 @@ hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *
 }
 
 // fp32 row -> sign plane / non-zero plane words (bit b of word q = coupling 32 q + b)
-__global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restrict__ J, int n,
-                                                            unsigned int *__restrict__ planes,
+__global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restrict__ J, long long ldJ,
+                                                            int n, unsigned int *__restrict__ planes,
                                                             long long row_bits, float *row_nnz) {
     __shared__ int cnt[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restri
         unsigned int sb = 0, zb = 0;
         for (int b = 0; b < 32; ++b) {
             const long long j = q * 32 + b;
-            const float v = j < n ? J[(long long)i * n + j] : 0.0f;
+            const float v = j < n ? J[(long long)i * ldJ + j] : 0.0f;
             sb |= (v < 0.0f ? 1u : 0u) << b;
             zb |= (v != 0.0f ? 1u : 0u) << b;
         }
@@ -132,13 +132,14 @@ __global__ void __launch_bounds__(256) repack_tern2_kernel(const float *__restri
     __syncthreads();
     if (tid == 0) row_nnz[i] = (float)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
 }
-hipError_t launch_repack_tern2(const float *J, int n, unsigned int *planes, long long row_bits,
-                               float *row_nnz, hipStream_t st) {
-    hipLaunchKernelGGL(repack_tern2_kernel, dim3(n), dim3(256), 0, st, J, n, planes, row_bits, row_nnz);
+hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned int *planes,
+                               long long row_bits, float *row_nnz, hipStream_t st) {
+    hipLaunchKernelGGL(repack_tern2_kernel, dim3(n), dim3(256), 0, st, J, ldJ, n, planes, row_bits, row_nnz);
     return hipGetLastError();
 }
 
-__global__ void check_symmetric_kernel(const float *__restrict__ J, long long rows, int n, int *out) {
+__global__ void check_symmetric_kernel(const float *__restrict__ J, long long ldJ, long long rows,
+                                       int n, int *out) {
     const long long total = rows * n;
     int bad = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -146,14 +147,15 @@ __global__ void check_symmetric_kernel(const float *__restrict__ J, long long ro
         const long long row = i / n, col = i - row * n;
         const long long base = (row / n) * n;  // first row of this model's block
         const long long r = row - base;
-        const float a = J[i], b = J[(base + col) * n + r];
+        const float a = J[row * ldJ + col], b = J[(base + col) * ldJ + r];
         if (a != b || (r == col && a != 0.0f)) bad = 1;
     }
     if (bad) atomicOr(out, 1);
 }
-hipError_t launch_check_symmetric(const float *J, long long rows, int n, int *out, hipStream_t st) {
-    hipLaunchKernelGGL(check_symmetric_kernel, dim3(grid_for(rows * n)), dim3(256), 0, st, J, rows,
-                       n, out);
+hipError_t launch_check_symmetric(const float *J, long long ldJ, long long rows, int n, int *out,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(check_symmetric_kernel, dim3(grid_for(rows * n)), dim3(256), 0, st, J, ldJ,
+                       rows, n, out);
     return hipGetLastError();
 }
 
@@ -710,7 +712,9 @@ hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st) {
 template <typename JT, bool CSR>
 __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
     constexpr int EPL = 16 / sizeof(JT), EPC = 64 * EPL;
-    __shared__ double red[4];
+    __shared__ double red[8];
+    // dense fp32: per-chunk sums of the canonical summation order (n <= 163 840: 640 chunks)
+    __shared__ double csum[(!CSR && sizeof(JT) == 4) ? 640 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // fields (op 0) are independent: one workgroup per requested site; flips / updates mutate the
@@ -718,39 +722,70 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
     const int k_begin = a.op == 0 ? (int)blockIdx.x : 0, k_end = a.op == 0 ? k_begin + 1 : a.count;
     for (int k = k_begin; k < k_end; ++k) {
         const int site = a.sites[k];
-        double acc = 0.0;
+        float dot;
+        __syncthreads();  // the previous site's sums have been read
         if constexpr (CSR) {
-            for (long long j = a.rowptr[site] + tid; j < a.rowptr[site + 1]; j += 256)
-            {
-                const int2 ent = a.cv[j];
-                acc += (double)(__int_as_float(ent.y) * (float)a.spins[ent.x]);
-            }
-        } else {
-            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
-            for (long long c = (long long)tid * EPL; c < a.ldj; c += 4 * EPC) {
-                if constexpr (sizeof(JT) == 4) {
-                    const float4 x = *reinterpret_cast<const float4 *>(row + c);
-                    const int sw = *reinterpret_cast<const int *>(a.spins + c);
-                    acc += (double)(x.x * (float)(int8_t)(sw));
-                    acc += (double)(x.y * (float)(int8_t)(sw >> 8));
-                    acc += (double)(x.z * (float)(int8_t)(sw >> 16));
-                    acc += (double)(x.w * (float)(sw >> 24));
-                } else {
-                    const int4 x = *reinterpret_cast<const int4 *>(row + c);
-                    const int4 sv = *reinterpret_cast<const int4 *>(a.spins + c);
-                    int t = __builtin_amdgcn_sdot4(x.x, sv.x, 0, false);
-                    t = __builtin_amdgcn_sdot4(x.y, sv.y, t, false);
-                    t = __builtin_amdgcn_sdot4(x.z, sv.z, t, false);
-                    t = __builtin_amdgcn_sdot4(x.w, sv.w, t, false);
-                    acc += (double)t;
+            // canonical order of sweep_csr.hip: entry e -> lane e % 64 of virtual wave (e / 64) % 8;
+            // thread tid takes e = tid + 256 m, i.e. virtual waves w (m even) and w + 4 (m odd)
+            const long long beg = a.rowptr[site];
+            const int len = (int)(a.rowptr[site + 1] - beg);
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int e0 = tid; e0 < len; e0 += 512) {
+                const int2 ent = a.cv[beg + e0];
+                acc0 += (double)(__int_as_float(ent.y) * (float)a.spins[ent.x]);
+                if (e0 + 256 < len) {
+                    const int2 en2 = a.cv[beg + e0 + 256];
+                    acc1 += (double)(__int_as_float(en2.y) * (float)a.spins[en2.x]);
                 }
             }
+            const double s0 = wave_sum(acc0), s1 = wave_sum(acc1);
+            if (lane == 0) {
+                red[w] = s0;
+                red[w + 4] = s1;
+            }
+            __syncthreads();
+            double t = red[0];
+            for (int v = 1; v < 8; ++v) t += red[v];
+            dot = (float)t;
+        } else if constexpr (sizeof(JT) == 4) {
+            // canonical order of sweep_dense_impl.h: 256-element chunks, lane partial
+            // ((e0 + e1) + e2) + e3, adjacent-pairs tree, chunk sums added in chunk order
+            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
+            const int C = (a.n + EPC - 1) / EPC;
+            for (int c = w; c < C; c += 4) {
+                const long long col = (long long)c * EPC + lane * EPL;
+                double p = 0.0;
+                if (col < a.ldj) {  // J's row pad and the spins' pad are zero
+                    const float4 x = *reinterpret_cast<const float4 *>(row + col);
+                    const int sw = *reinterpret_cast<const int *>(a.spins + col);
+                    p += (double)(x.x * (float)(int8_t)(sw));
+                    p += (double)(x.y * (float)(int8_t)(sw >> 8));
+                    p += (double)(x.z * (float)(int8_t)(sw >> 16));
+                    p += (double)(x.w * (float)(sw >> 24));
+                }
+                const double cs = wave_sum(p);
+                if (lane == 0) csum[c] = cs;
+            }
+            __syncthreads();
+            double t = csum[0];
+            for (int c = 1; c < C; ++c) t += csum[c];
+            dot = (float)t;
+        } else {  // int8: exact in any order
+            const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
+            int acc = 0;
+            for (long long c = (long long)tid * EPL; c < a.ldj; c += 4 * EPC) {
+                const int4 x = *reinterpret_cast<const int4 *>(row + c);
+                const int4 sv = *reinterpret_cast<const int4 *>(a.spins + c);
+                acc = __builtin_amdgcn_sdot4(x.x, sv.x, acc, false);
+                acc = __builtin_amdgcn_sdot4(x.y, sv.y, acc, false);
+                acc = __builtin_amdgcn_sdot4(x.z, sv.z, acc, false);
+                acc = __builtin_amdgcn_sdot4(x.w, sv.w, acc, false);
+            }
+            const int ws = wave_sum(acc);
+            if (lane == 0) red[w] = (double)ws;
+            __syncthreads();
+            dot = (float)((red[0] + red[1]) + (red[2] + red[3]));
         }
-        const double ws = wave_sum(acc);
-        __syncthreads();
-        if (lane == 0) red[w] = ws;
-        __syncthreads();
-        const float dot = (float)((red[0] + red[1]) + (red[2] + red[3]));
         if (a.op == 0) {
             if (tid == 0) a.out[k] = (double)dot + (double)a.h[site];  // ising_model.py:176-185
             continue;

@@ -40,9 +40,19 @@ constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (1
 // cities is n = 10^6) or with nnz >= 2^31: the replica's spins sit in LDS as one bit each (1 =
 // spin down; 125 KB at n = 10^6), row extents are 64-bit, flips are idempotent LDS atomics
 // (or / and-not) so that every wave can still apply them itself.
-template <bool FAST, bool LEAN, bool WIDE, bool BIG>
-__global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
+//
+// Real-valued problems (FAST = false) sum a row in a CANONICAL ORDER that no launch geometry
+// changes: entry e of the row (storage order) belongs to lane e % 64 of virtual wave (e / 64) % 8;
+// a virtual lane adds its entries in storage order (fp64), each virtual wave folds its 64 lanes by
+// the adjacent-pairs tree (wave_sum), and the 8 wave sums are added in order.  A replica dealt to
+// NW = 1, 2, 4 or 8 real waves reproduces that exactly with 8 / NW accumulators per lane (NW is a
+// template parameter of the wide real-valued builds, so every accumulator index is a constant);
+// the CPU checker forms the same sum.
+template <bool FAST, bool LEAN, bool WIDE, bool BIG, int NW = 0>
+__global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CSR_WAVES_PER_BLOCK))
     sweep_csr_kernel(const SweepArgs a) {
+    static_assert(FAST || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
+                  "real-valued wide builds are made per wave count");
     // bit spins also come in the narrow form (several replicas per workgroup, 32-bit extents):
     // short rows on 40k < n <= 1.3M spins, where the int8 spins leave one or two replicas per
     // workgroup
@@ -237,11 +247,17 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 dot = t;
                 pp ^= 1;
             }
-        } else {  // fp64 sum rounded to fp32 once (core/ising_model.py:183)
-            double acc = (double)term(head_val(hd, 0), hd.col[0]);
-#pragma unroll
-            for (int q = 1; q < HEAD; ++q) acc += (double)term(head_val(hd, q), hd.col[q]);
+        } else {  // fp64 sum in the canonical order, rounded to fp32 once (core/ising_model.py:183)
+            constexpr int NV = WIDE ? 8 / (NW > 0 ? NW : 8) : 8;  // virtual waves per real wave
+            double acc[NV];
             if constexpr (WIDE) {
+                // this lane's q'-th entry (q' = 8 t + q) lies in virtual wave w + NW * (q % NV)
+#pragma unroll
+                for (int q = 0; q < HEAD; ++q) {
+                    const double t = (double)term(head_val(hd, q), hd.col[q]);
+                    if (q < NV) acc[q] = t;
+                    else acc[q % NV] += t;
+                }
                 for (int i0 = stride_lanes * HEAD; i0 < hd.len; i0 += stride_lanes * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
                     float v[TAIL_UNROLL];
@@ -253,9 +269,29 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                         v[q] = idx < hd.len ? __int_as_float(ent.y) : 0.0f;
                     }
 #pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NV] += (double)term(v[q], c[q]);
                 }
+                // one tree per virtual wave that holds entries; all 8 slots are written
+                double *slot = part + pp * CSR_MAX_WIDE;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int v = w + (NW > 0 ? NW : 8) * j;
+                    double sv = 0.0;
+                    if (hd.len > 64 * v) sv = wave_sum(acc[j]);  // wave-uniform test
+                    if (lane == 0) slot[v] = sv;
+                }
+                __syncthreads();
+                double t = slot[0];
+#pragma unroll
+                for (int v = 1; v < CSR_MAX_WIDE; ++v) t += slot[v];
+                pp ^= 1;
+                dot = (float)t;
             } else {
+                // one wave: entry q' = 0 is the head, the tail batch t holds q' = 1 + 8 t + q
+                static_assert(TAIL_UNROLL == 8 && HEAD == 1, "virtual wave of a tail entry = (1 + q) % 8");
+                acc[0] = (double)term(head_val(hd, 0), hd.col[0]);
+#pragma unroll
+                for (int j = 1; j < NV; ++j) acc[j] = 0.0;
                 for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
                      j0 += stride_lanes * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
@@ -269,20 +305,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                         v[q] = __int_as_float(ent.y);
                     }
 #pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[(1 + q) % NV] += (double)term(v[q], c[q]);
                 }
+                const int len = (int)(x.end - x.beg);
+                double t = wave_sum(acc[0]);
+#pragma unroll
+                for (int j = 1; j < NV; ++j)
+                    if (len > 64 * j) t += wave_sum(acc[j]);  // wave-uniform test
+                dot = (float)t;
             }
-            double tot = wave_sum(acc);
-            if constexpr (WIDE) {
-                double *slot = part + pp * CSR_MAX_WIDE;
-                if (lane == 0) slot[w] = tot;
-                __syncthreads();
-                double t = slot[0];
-                for (int i = 1; i < nw; ++i) t += slot[i];
-                tot = t;
-                pp ^= 1;
-            }
-            dot = (float)tot;
         }
         double dE;
         bool flip;
@@ -461,8 +492,20 @@ static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
     const int slots = WIDE ? 1 : waves;
     const size_t lds = csr_lds_per_replica(a.sstride, a.table_m, BIG) * slots +
                        2 * CSR_MAX_WIDE * sizeof(double);
-    auto kern = fast ? (lean ? sweep_csr_kernel<true, true, WIDE, BIG> : sweep_csr_kernel<true, false, WIDE, BIG>)
-                     : (lean ? sweep_csr_kernel<false, true, WIDE, BIG> : sweep_csr_kernel<false, false, WIDE, BIG>);
+    void (*kern)(const SweepArgs) = nullptr;
+    if (fast) {
+        kern = lean ? sweep_csr_kernel<true, true, WIDE, BIG> : sweep_csr_kernel<true, false, WIDE, BIG>;
+    } else if constexpr (!WIDE) {
+        kern = lean ? sweep_csr_kernel<false, true, false, BIG> : sweep_csr_kernel<false, false, false, BIG>;
+    } else {  // real-valued wide builds: one per wave count (canonical summation order)
+        switch (waves) {
+            case 1: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 1> : sweep_csr_kernel<false, false, true, BIG, 1>; break;
+            case 2: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 2> : sweep_csr_kernel<false, false, true, BIG, 2>; break;
+            case 4: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 4> : sweep_csr_kernel<false, false, true, BIG, 4>; break;
+            case 8: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 8> : sweep_csr_kernel<false, false, true, BIG, 8>; break;
+            default: return hipErrorInvalidValue;  // the engine rounds the wave count up to a power of two
+        }
+    }
     {
         hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;

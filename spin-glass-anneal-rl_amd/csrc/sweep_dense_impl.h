@@ -81,6 +81,13 @@ constexpr int LOOK_SLOT_BYTES = 4 * LOOK;  // one wave's LOOK partial sums (floa
 // behind the spins: [2][MAX_WAVES] partial-sum slots (8 B, or 16 B in the look-ahead form), then
 // the spin(s) at the update site(s) published by their owner waves
 constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * LOOK_SLOT_BYTES + 2 * LOOK * 4;
+// ACC64 kernels keep two buffers of per-chunk row sums behind the accept table (8-byte aligned)
+__host__ __device__ constexpr long long dense_canon_offset(long long sbytes, int table_m) {
+    return (sbytes + DENSE_LDS_EXTRA + 4ll * (table_m + 1) + 7) & ~7ll;
+}
+__host__ __device__ constexpr long long dense_canon_bytes(long long ld, int epc) {
+    return 2 * (ld / epc) * 8;
+}
 
 // Look-ahead kernels whose four rows do not fit the 128 VGPRs of a 1024-thread workgroup (4 chunks
 // per wave, 2 for bit-planes) are built for at most 4 waves per replica instead.
@@ -117,6 +124,8 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // (bit-identical decisions, no fp64 divide / exp on the per-update chain); LEAN only
     float *ptab = reinterpret_cast<float *>(smem + sbytes + DENSE_LDS_EXTRA);  // [table_m + 1]
     const bool use_tab = LEAN && a.table_m > 0 && rule == SGA_RULE_METROPOLIS;
+    // real-valued couplings (ACC64): per-chunk sums of the canonical summation order, [2][ld / EPC]
+    double *canon = reinterpret_cast<double *>(smem + dense_canon_offset(sbytes, a.table_m));
 
     const int tid = threadIdx.x;
     const int W = SINGLE ? 1 : (int)(blockDim.x >> 6);
@@ -198,6 +207,8 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
 
     constexpr int NBUF = CPW > 0 ? CPW : 1;
     const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
+    const int n_chunks_ld = (int)(a.ld / EPC);       // chunk slots of the layout (W * chunks per wave)
+    const int n_chunks_row = (n + EPC - 1) / EPC;    // chunks that hold elements of a row
 
     // The base of row `site`.  Up to 8 chunks per wave it is pinned to SGPRs and the loads take
     // the scalar-base form (one 32-bit offset VGPR per load instead of a 64-bit address pair);
@@ -324,10 +335,58 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // one Metropolis update at `site` using the row held in `buf`
     auto step = [&](const vec_t(&buf)[NBUF], int site, float u, float h_site, float d_site,
                     long long upd) {
-        acc_t lane_sum;
-        if constexpr (CPW == 0) lane_sum = dot_stream(site);
-        else lane_sum = dot_row(buf);
-        acc_t tot = wave_sum(lane_sum);
+        acc_t tot;
+        if constexpr (ACC64) {
+            // CANONICAL ORDER for real-valued J: each 256-element chunk c is summed by itself --
+            // lane partial ((e0 + e1) + e2) + e3 from +0, adjacent-pairs tree over the 64 lanes
+            // (wave_sum) -- and the chunk sums are added in chunk order c = 0, 1, 2, ...  Which
+            // wave holds a chunk, and how many chunks a wave holds, does not enter: the fp64 sum,
+            // and with it the fp32 row sum and every decision, is the same for every launch
+            // geometry (the CPU checker forms the same sum).
+            double *slot = canon + pp * n_chunks_ld;
+            if constexpr (CPW == 0) {
+                const JE *p = row_base(site);
+                for (int k0 = 0; k0 < cpw_rt; k0 += 4) {
+                    vec_t t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < cpw_rt) t[j] = load_chunk(p, k0 + j);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < cpw_rt) {
+                            acc_t pl = 0;
+                            accumulate(pl, t[j], k0 + j);
+                            const acc_t cs = wave_sum(pl);
+                            if (lane == 0) slot[w + (k0 + j) * W] = cs;
+                        }
+                }
+                tot = 0;
+            } else {
+                acc_t cs[NBUF];
+#pragma unroll
+                for (int k = 0; k < NBUF; ++k) {
+                    acc_t pl = 0;
+                    accumulate(pl, buf[k], k);
+                    cs[k] = wave_sum(pl);
+                }
+                if (W > 1) {
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < NBUF; ++k) slot[w + k * W] = cs[k];
+                    }
+                    tot = 0;
+                } else {
+                    tot = cs[0];
+#pragma unroll
+                    for (int k = 1; k < NBUF; ++k) tot += cs[k];
+                }
+            }
+        } else {
+            acc_t lane_sum;
+            if constexpr (CPW == 0) lane_sum = dot_stream(site);
+            else lane_sum = dot_row(buf);
+            tot = wave_sum(lane_sum);
+        }
         const int owner = owner_of(site);
         auto spin_at = [&](int i) -> int {
             if constexpr (BITS) return ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -1 : 1;
@@ -337,19 +396,32 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
         if (W > 1) {
             acc_t *part = reinterpret_cast<acc_t *>(part_raw + pp * MAX_WAVES * PART_SLOT_BYTES);
             if (lane == 0) {
-                *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
-                                           w * PART_SLOT_BYTES) = tot;
+                if constexpr (!ACC64)
+                    *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
+                                               w * PART_SLOT_BYTES) = tot;
                 if (w == owner) sislot[pp] = spin_at(site);
             }
             __syncthreads();
-            acc_t s = *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part));
-            for (int i = 1; i < W; ++i)
-                s += *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
-                                                i * PART_SLOT_BYTES);
-            tot = s;
+            if constexpr (ACC64) {  // chunk order; chunks past the row's end hold +0
+                const double *slot = canon + pp * n_chunks_ld;
+                acc_t s = slot[0];
+                for (int c = 1; c < n_chunks_row; ++c) s += slot[c];
+                tot = s;
+            } else {
+                acc_t s = *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part));
+                for (int i = 1; i < W; ++i)
+                    s += *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
+                                                    i * PART_SLOT_BYTES);
+                tot = s;
+            }
             si = sislot[pp];
             pp ^= 1;
         } else {
+            if constexpr (ACC64 && CPW == 0) {  // one streaming wave: its own LDS writes, in order
+                acc_t s = canon[0];
+                for (int c = 1; c < n_chunks_row; ++c) s += canon[c];
+                tot = s;
+            }
             si = spin_at(site);
         }
         // bit-plane form: tot counts the -1 products, d_site carries the row's non-zero count
@@ -650,8 +722,10 @@ constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hi
 template <typename JT, bool ACC64, int CPW>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     constexpr bool BITS = std::is_same<JT, Tern2>::value;
-    const size_t lds = (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
-                       sizeof(float) * (size_t)(a.table_m + 1);
+    const size_t lds = ACC64 ? (size_t)(dense_canon_offset(a.ld, a.table_m) +
+                                        dense_canon_bytes(a.ld, 64 * JTraits<JT>::EPL))
+                             : (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
+                                   sizeof(float) * (size_t)(a.table_m + 1);
     const bool lean = sweep_args_are_lean(a);
     void (*kern)(const SweepArgs) = nullptr;
     if constexpr (has_look_ahead<JT, ACC64, CPW>()) {

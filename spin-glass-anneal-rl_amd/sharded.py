@@ -18,6 +18,8 @@ is a validated string, annealing/multi_gpu.py:26,41-43; "multi-GPU" is a thread 
 The engine argument only needs the small surface used below, which lets the coordination
 logic be exercised on CPU with a stand-in engine (tests/test_sharded_gloo.py).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -38,6 +40,7 @@ class ShardedTempering:
             if t.size != self.R_global:
                 raise ValueError("slot_temps must cover the global replica set")
             engine.set_ladder(t, n_ladders)
+        self.gather_calls, self.gather_ms = 0, 0.0  # all-gather rounds and their host wall time
         self._local_E = torch.zeros(self.R_local, dtype=torch.float64, device=self.device)
         self._all_E = torch.zeros(self.R_global, dtype=torch.float64, device=self.device)
 
@@ -51,6 +54,13 @@ class ShardedTempering:
         if self.dist is None:
             self._all_E.copy_(self._local_E)
             return self._all_E
+        t0 = time.perf_counter()
+        self._all_gather()
+        self.gather_calls += 1
+        self.gather_ms += (time.perf_counter() - t0) * 1e3
+        return self._all_E
+
+    def _all_gather(self):
         if self.dist.get_backend() == "nccl":
             self.dist.all_gather_into_tensor(self._all_E, self._local_E)
             # the engine launches on its own HIP stream: the gathered vector must be complete
@@ -59,7 +69,6 @@ class ShardedTempering:
         else:
             parts = list(self._all_E.chunk(self.world))
             self.dist.all_gather(parts, self._local_E)
-        return self._all_E
 
     def exchange(self) -> int:
         """One replica-exchange round over the global ladder(s); identical on every rank."""

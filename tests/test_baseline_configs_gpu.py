@@ -1,0 +1,373 @@
+"""BASELINE.json configs at the size AND in the kernel form bench.py really takes
+(configs[2] at 4096 replicas, configs[3] at 1024 replicas per GPU -- the bit-spin
+wide form picked by LDS residency -- and configs[4] at 1000 cities), plus the regression tests
+for the round-1 parity loose ends: launch geometries with more waves than chunks, real-valued
+couplings under every geometry (canonical summation order), checkpoints across geometries.
+
+Everything goes through the C ABI; the oracle follows a few replicas (Philox streams are keyed
+by the global replica id, so replicas 0..k-1 of a big run are reproduced by a k-replica oracle
+run), the rest is covered by size-independent properties: tracked energy == energy recomputed
+from scratch, acceptance counters within range, exchanges stay inside their ladders.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import spin_glass_anneal_rl_amd as m
+    return m
+
+
+def ladder(R, tmax, tmin):
+    return np.asarray([tmax * (tmin / tmax) ** (i / max(R - 1, 1)) for i in range(R)])
+
+
+def csr_of(J):
+    n = J.shape[0]
+    rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
+    colidx = np.concatenate([np.nonzero(J[i])[0] for i in range(n)]).astype(np.int32)
+    val = np.concatenate([J[i][J[i] != 0] for i in range(n)]).astype(np.float32)
+    return rowptr, colidx, val
+
+
+# ----------------------------------------------------------------------------- configs[2]
+def test_c3_sparse_instance_at_4096_replicas(sg):
+    """10 000 spins, CSR degree ~32, 4096 replicas (bench.py --workload c3)."""
+    import bench
+    csr = bench.make_sparse_instance(10000, 16, 3)
+    n, R, seed, ns = 10000, 4096, 42, 3
+    h = np.zeros(n, np.float32)
+    temps = ladder(R, 10.0, 0.1)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert "R=4096" in d and "path=integer-fast" in d and "spins=lds-int8" in d, d
+        e.set_ladder(temps)
+        out = e.sweep(ns, energy_trace=True)
+        tracked = e.energies()
+        acc, att = e.stats()
+        assert np.all(att == ns * n) and np.all(acc <= att) and acc[0] > acc[-1]  # hot end moves more
+        e.recompute_energies()
+        assert np.array_equal(e.energies(), tracked)            # +-1 couplings: exact
+        swaps = e.exchange()
+        assert 0 < swaps <= R // 2 and sorted(e.slot_map()) == list(range(R))
+        spins = e.spins()
+    k = 4
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, k, seed)
+    ref = oracle.sweeps(prob, s, temps[:k], ns, seed=seed, n_threads=k)
+    assert np.array_equal(out["energy_trace"][:, :k], ref["energy_trace"])
+    assert np.array_equal(spins[:k], s)
+
+
+# ----------------------------------------------------------------------------- configs[3]
+def test_c4_scheduling_instance_at_1024_replicas_per_gpu(sg):
+    """50 000-spin scheduling penalties (degree 598), 1024 replicas = one GPU's share of the 8192:
+    LDS residency makes the engine hold the spins as bits, two waves per replica."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    b = enc.scheduling_ising(np.full(500, 1.0), n_agents=1, time_horizon=100.0,
+                             time_discretization=100, objective="total_time",
+                             penalty_weights={"assignment": 100.0, "capacity": 50.0})
+    csr, h = b.to_csr(), b.fields()
+    n, R, Rg, seed = 50000, 1024, 8192, 31
+    temps_g = ladder(Rg, 500.0, 5.0)
+    runs = {}
+    for replica0 in (0, 3 * R):  # rank 0's and rank 3's share of the global ladder
+        with sg.AnnealEngine(0) as e:
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed, R_global=Rg, replica0=replica0)
+            d = e.describe()
+            assert "spins=lds-bits" in d and "waves_per_replica=2" in d and "R=1024" in d, d
+            e.set_ladder(temps_g)
+            assert np.array_equal(e.temperatures(), temps_g[replica0:replica0 + R])
+            out = e.sweep(1, energy_trace=True)
+            tracked = e.energies()
+            e.recompute_energies()
+            # |E| ~ 1e9: the from-scratch value is rounded to fp32 as torch.dot rounds it
+            # (core/ising_model.py:161-168), the tracked one is a double sum of exact fp32 dE's
+            assert np.allclose(e.energies(), tracked, rtol=1e-6, atol=0)
+            runs[replica0] = (out["energy_trace"], e.spins())
+    prob = oracle.Problem(csr=csr, h=h)
+    k = 3
+    for replica0, (trace, spins) in runs.items():
+        s = oracle.init_spins(n, k, seed, replica0=replica0)
+        ref = oracle.sweeps(prob, s, temps_g[replica0:replica0 + k], 1, seed=seed,
+                            replica0=replica0, n_threads=k)
+        assert np.array_equal(trace[:, :k], ref["energy_trace"])
+        assert np.array_equal(spins[:k], s)
+
+
+# ----------------------------------------------------------------------------- configs[4]
+def _tsp(n_cities, seed, integer, device="cuda:0"):
+    from spin_glass_anneal_rl_amd import encoders as enc
+    rs = np.random.RandomState(seed)
+    xy = rs.rand(n_cities, 2) * 100.0
+    d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+    if integer:  # distances in multiples of 4, integer penalties: every J and h is an integer
+        d = np.rint(d / 4.0) * 4.0
+        return enc.tsp_csr(d, city_visit=200.0, position_fill=200.0, auto_scale=False, device=device)
+    return enc.tsp_csr(d, city_visit=200.0, position_fill=200.0, device=device)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+def test_c5_tsp_1000_cities_full_size(sg, integer):
+    """examples/tsp_example.py at BASELINE size: 1000 cities = 10^6 spins, 3.996e9 entries
+    (32 GB of CSR written on the device, 64-bit extents), spins as bits, 8 waves per replica.
+    16 replicas in 2 ladders, one sweep, on the integer-valued instance (accept-table path, fp32
+    row sums) and on real distances (fp64 row sums in the canonical order): tracked energy ==
+    energy recomputed from scratch to its fp32 rounding."""
+    rowptr, col, val, h, _ = _tsp(1000, 5, integer)
+    n, R, n_ladders, seed = 10 ** 6, 16, 2, 11
+    assert rowptr.dtype == torch.int64 and int(rowptr[-1]) == 3996 * n
+    temps = np.tile(ladder(R // n_ladders, 200.0, 2.0), n_ladders)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(rowptr, col, val, h)
+        del col, val
+        torch.cuda.empty_cache()
+        e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert "nnz=3996000000" in d and "spins=lds-bits" in d and "waves_per_replica=8" in d, d
+        assert ("path=integer-fast" in d) == integer and "recomputed" not in d, d
+        e.set_ladder(temps, n_ladders)
+        e0 = e.energies()
+        assert np.all(np.isfinite(e0)) and len(set(e0)) == R
+        s_init = e.spins(0)
+        e.sweep(1)
+        tracked = e.energies()
+        acc, att = e.stats()
+        assert np.all(att == n) and np.all(acc > 0) and np.all(acc <= att)
+        assert not np.array_equal(e.spins(0), s_init)
+        e.recompute_energies()
+        # |E| ~ 1e11: the from-scratch value is rounded to fp32 as torch.dot rounds it
+        # (core/ising_model.py:161-168); the tracked one is a double sum of the dE's
+        assert np.allclose(e.energies(), tracked, rtol=1e-6, atol=0)
+        e.exchange()
+        slots = e.slot_map()
+        assert sorted(slots) == list(range(R))
+        assert np.array_equal(slots // (R // n_ladders), np.arange(R) // (R // n_ladders))
+
+
+def test_c5_tsp_500_cities_against_the_oracle(sg):
+    """The largest TSP instance whose CSR the oracle can hold (nnz = 5e8 < 2^31): the same
+    bit-spin wide form as the 1000-city run (64-bit extents from the device encoder, 4 waves per
+    replica), initial energies and the first sweep against the oracle on two replicas."""
+    rowptr, col, val, h, _ = _tsp(500, 7, integer=False)
+    n, R, seed = 250000, 8, 23
+    temps = ladder(R, 200.0, 2.0)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(rowptr, col, val, h)
+        e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert "spins=lds-bits" in d and "waves_per_replica=4" in d, d
+        e.set_ladder(temps)
+        e0 = e.energies()
+        out = e.sweep(1, energy_trace=True, trace=False)
+        spins = e.spins()
+    csr = (rowptr.cpu().numpy().astype(np.int32), col.cpu().numpy(), val.cpu().numpy())
+    del rowptr, col, val
+    torch.cuda.empty_cache()
+    prob = oracle.Problem(csr=csr, h=h.cpu().numpy())
+    k = 2
+    s = oracle.init_spins(n, k, seed)
+    # real-valued distances: the initial energies agree to the fp32 rounding of the row sums'
+    # total; the sweep's decisions and spins are bit-identical (canonical summation order)
+    e_ref = np.asarray([oracle.energy(prob, s[r]) for r in range(k)])
+    assert np.allclose(e0[:k], e_ref, rtol=1e-6, atol=0)
+    ref = oracle.sweeps(prob, s, temps[:k], 1, seed=seed, energy=e0[:k].copy(), n_threads=k)
+    assert np.array_equal(spins[:k], s)
+    assert np.array_equal(out["energy_trace"][:, :k], ref["energy_trace"])
+
+
+# ----------------------------------------------------------------------------- round-1 loose ends
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n", [33, 65, 129])
+@pytest.mark.parametrize("waves", [2, 3, 4])
+def test_more_waves_than_chunks_is_clamped(sg, n, waves, integer):
+    """A forced wave count beyond the row's chunk count used to reach, through the streaming
+    fallback of the geometry choice, a launch in which whole waves held nothing but pad lanes
+    (the configuration of the one unreproduced round-1 fuzz mismatch: n = 65, 2 waves, sequential
+    sites, fp32 operator arithmetic, traced general kernel).  It is clamped to the chunk count."""
+    rng = np.random.RandomState(n * 10 + waves)
+    J = np.triu((rng.randint(-2, 3, (n, n)) if integer else rng.randn(n, n)) * (rng.rand(n, n) < 0.3), 1)
+    J = (J + J.T).astype(np.float32)
+    h = (rng.randint(-2, 3, n) if integer else rng.randn(n)).astype(np.float32)
+    R, ns, seed = 7, 2, 1000 + n
+    temps = ladder(R, 3.0 * np.sqrt(n), 0.2)
+    u = rng.rand(R, ns * n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    for site_mode, arith in ((oracle.SITE_SEQUENTIAL, oracle.ARITH_F32),
+                             (oracle.SITE_SEQUENTIAL, oracle.ARITH_F64),
+                             (oracle.SITE_RANDOM, oracle.ARITH_F32)):
+        uu = u if site_mode == oracle.SITE_SEQUENTIAL else None
+        s = oracle.init_spins(n, R, seed)
+        ref = oracle.sweeps(prob, s, temps, ns, site_mode=site_mode, arith=arith, seed=seed,
+                            replay_u=uu, trace=True, n_threads=4)
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_dense(J, h, storage="f32")
+            e.init_replicas(R, seed=seed)
+            assert "waves_per_replica=1 " in e.describe(), e.describe()   # one 256-element chunk
+            e.set_temperatures(temps)
+            out = e.sweep(ns, site_mode=site_mode, arith=arith, replay_u=uu, energy_trace=True,
+                          trace=True)
+            assert np.array_equal(out["accept_trace"], ref["accept_trace"])
+            assert np.array_equal(out["dE_trace"], ref["dE_trace"])
+            assert np.array_equal(e.spins(), s)
+
+
+def test_forced_waves_up_to_the_chunk_count_are_kept(sg):
+    J = np.triu(np.random.RandomState(3).randn(700, 700), 1).astype(np.float32)
+    J = J + J.T
+    for waves, expect in ((2, 2), (3, 3), (4, 3), (16, 3)):  # 700 fp32 = 3 chunks of 256
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_dense(J, np.zeros(700, np.float32))
+            e.init_replicas(4, seed=1)
+            assert f"waves_per_replica={expect} " in e.describe(), e.describe()
+
+
+@pytest.mark.parametrize("n,geometries", [(700, (1, 2, 3)), (2500, (1, 3, 5, 8, 10)),
+                                          (5000, (1, 2, 7, 16)), (6000, (2,))])
+def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
+    """Gaussian couplings: the fp64 row sum is formed in one canonical order (256-element chunks,
+    adjacent-pairs tree, chunk order) whatever the waves-per-replica, so every decision and every
+    dE equals the oracle's bit for bit under each geometry -- including the streaming form (more
+    than 10 chunks per wave: n = 5000 on one wave, n = 6000 on two)."""
+    J = np.triu(np.random.RandomState(n).randn(n, n), 1).astype(np.float32)
+    J = J + J.T
+    h = np.random.RandomState(n + 1).randn(n).astype(np.float32)
+    R, ns, seed = 3, 2, 77 + n
+    temps = ladder(R, 3.0, 0.3)
+    prob = oracle.Problem(J=J, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
+    for g in geometries:
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=g)
+            e.set_dense(J, h)
+            e.init_replicas(R, seed=seed)
+            d = e.describe()
+            assert "acc=f64" in d and f"waves_per_replica={g} " in d, d
+            assert ("(streaming)" in d) == ((n + 255) // 256 > 10 * g), d
+            e.set_temperatures(temps)
+            for traced in (True, False):   # general and production variants
+                if not traced:
+                    e.init_replicas(R, seed=seed)
+                    e.set_temperatures(temps)
+                out = e.sweep(ns, energy_trace=True, trace=traced)
+                if traced:
+                    assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
+                    assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
+                assert np.array_equal(e.spins(), s), d
+                assert np.array_equal(e.stats()[0], ref["n_accepted"])
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big, monkeypatch):
+    """Same for CSR rows of a few hundred real-valued entries dealt to 1, 2, 4 or 8 waves (a
+    request for 3 runs as 4: the canonical order's wide builds exist per power of two)."""
+    if big:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    n, R, ns, seed = 1200, 4, 3, 515
+    rng = np.random.RandomState(8)
+    J = (np.triu(rng.rand(n, n) < 0.5, 1) * rng.randn(n, n)).astype(np.float32)
+    J = J + J.T
+    h = rng.randn(n).astype(np.float32)
+    csr = csr_of(J)
+    assert np.diff(csr[0]).max() > 512          # rows longer than one pass of the 512 virtual lanes
+    prob = oracle.Problem(csr=csr, h=h)
+    temps = ladder(R, 30.0, 3.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
+    for waves, runs_as in ((1, 1), (2, 2), (3, 4), (4, 4), (8, 8)):
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed)
+            assert f"waves_per_replica={runs_as} " in e.describe() and "path=general" in e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True, trace=True)
+            assert np.array_equal(out["accept_trace"], ref["accept_trace"]), e.describe()
+            assert np.array_equal(out["dE_trace"], ref["dE_trace"]), e.describe()
+            assert np.array_equal(e.spins(), s)
+            e.init_replicas(R, seed=seed)       # production variant, untraced
+            e.set_temperatures(temps)
+            e.sweep(ns)
+            assert np.array_equal(e.spins(), s), e.describe()
+            # single-site operators form the same sums
+            f = e.local_fields(0, [0, 5, n - 1])
+            assert np.array_equal(f, [oracle.local_field(prob, s[0], i) for i in (0, 5, n - 1)])
+
+
+def test_single_site_operators_use_the_canonical_order_dense(sg):
+    n = 3000
+    rng = np.random.RandomState(12)
+    J = np.triu(rng.randn(n, n), 1).astype(np.float32)
+    J = J + J.T
+    h = rng.randn(n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    s = oracle.init_spins(n, 2, 5)
+    sites = [0, 1, 255, 256, 1500, n - 1]
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, h)
+        e.init_replicas(2, seed=5)
+        assert np.array_equal(e.local_fields(1, sites), [oracle.local_field(prob, s[1], i) for i in sites])
+        for site, u in ((7, 0.3), (2999, 0.9), (7, 0.01)):
+            acc, dE = e.update(1, site, 1.7, u)
+            ra, rd = oracle.metropolis_update(prob, s[1], site, 1.7, u)
+            assert (acc, dE) == (ra, rd)
+        assert np.array_equal(e.spins(1), s[1])
+
+
+@pytest.mark.parametrize("real", [False, True])
+def test_checkpoint_moves_between_launch_geometries(sg, real):
+    """A state exported after sga_autotune / with one waves-per-replica continues bit-exactly
+    in an engine laid out for another (the blob carries unpadded spins; the chain does not depend
+    on the geometry, for real-valued couplings either)."""
+    n, R = 2600, 6
+    rng = np.random.RandomState(21)
+    J = np.triu(rng.randn(n, n) if real else rng.randint(-1, 2, (n, n)), 1).astype(np.float32)
+    J = J + J.T
+    h = (rng.randn(n) if real else rng.randint(-1, 2, n)).astype(np.float32)
+    temps = ladder(R, 4.0, 0.4)
+
+    def fresh(waves):
+        e = sg.AnnealEngine(0)
+        e.set_tuning(waves_per_replica=waves)
+        e.set_dense(J, h, storage="f32")
+        e.init_replicas(R, seed=9)
+        e.set_ladder(temps)
+        return e
+
+    def advance(e, rounds):
+        for _ in range(rounds):
+            e.sweep(2)
+            e.exchange(count=False)
+
+    a = fresh(0)
+    a.autotune()
+    advance(a, 2)
+    blob = a.export_state()
+    advance(a, 3)
+    seen = set()
+    for waves in (1, 4, 11):
+        b = fresh(waves)
+        seen.add(b.describe())
+        b.import_state(blob)
+        advance(b, 3)
+        assert np.array_equal(a.spins(), b.spins()) and np.array_equal(a.energies(), b.energies())
+        assert np.array_equal(a.slot_map(), b.slot_map()) and a.counters() == b.counters()
+        assert all(np.array_equal(x, y) for x, y in zip(a.stats(), b.stats()))
+        ea, sa, _ = a.best()
+        eb, sb, _ = b.best()
+        assert ea == eb and np.array_equal(sa, sb)
+        b.close()
+    assert len(seen) == 3
+    a.close()

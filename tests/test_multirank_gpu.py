@@ -1,0 +1,128 @@
+"""The N > 1 path on real engines: `python bench.py --gpus N` starts its own ranks (no torchrun),
+and a 2-rank run over torch.distributed reproduces the 1-rank run bit for bit.  On a 1-GPU box
+the two ranks share cuda:0 and talk over gloo (the rehearsal mode of bench.py); with >= 2 GPUs
+the same check runs one rank per GPU over RCCL (backend "nccl")."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SPINS, R_GLOBAL, ROUNDS, SEED = 600, 12, 6, 4242
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_without_gpu_fails_loudly_in_every_rank():
+    """CPU-side check of the launcher: without a GPU every rank refuses (no CPU fallback) and the
+    parent reports the failed ranks with a non-zero exit code."""
+    if torch.cuda.device_count() > 0:
+        pytest.skip("checks the no-GPU failure mode")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "ranks failed" in p.stderr and "no HIP device visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: two ranks, one JSON line."""
+    two_gpus = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+           "--spins", "2000", "--replicas", "64", "--no-autotune", "--no-variants"]
+    if not two_gpus:
+        cmd += ["--backend", "gloo", "--share-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["backend"] == ("nccl" if two_gpus else "gloo")
+    assert d["config"]["replicas_total"] == 128 and d["config"]["replicas_per_gpu"] == 64
+    assert d["value"] == pytest.approx(128 * 2000 * 12 / (d["ms_per_step"] * 12 * 1e-3))
+    assert d["exchange"]["rounds_timed"] >= 1 and d["exchange"]["allgather_ms_per_round"] > 0
+
+
+def _rank_main(rank, world, port, backend, share, n_ladders, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import spin_glass_anneal_rl_amd as sg
+    dev_index = 0 if share else rank
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(5)
+    J = np.triu(rng.randint(0, 2, (N_SPINS, N_SPINS)) * 2 - 1, 1).astype(np.float32)
+    J, h = J + J.T, rng.randint(-1, 2, N_SPINS).astype(np.float32)
+    L = R_GLOBAL // n_ladders
+    ladder = np.asarray([6.0 * (0.3 / 6.0) ** (i / (L - 1)) for i in range(L)] * n_ladders)
+    eng = sg.AnnealEngine(dev_index)
+    eng.set_dense(J, h)
+    comm = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    pt = sg.ShardedTempering(eng, R_GLOBAL // world, rank, world, SEED, ladder, n_ladders,
+                             dist if world > 1 else None, comm)
+    swaps = []
+    for _ in range(ROUNDS):
+        pt.sweep(2)
+        swaps.append(pt.exchange())
+    e, s, idx = pt.global_best()
+    np.savez(out_path, swaps=np.asarray(swaps), energies=pt.gather_energies().cpu().numpy(),
+             best_e=e, best_s=s, best_idx=idx, spins=eng.spins(), temps=eng.temperatures(),
+             slot_map=eng.slot_map())
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_ranks(world, backend, share, n_ladders, tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    paths = [str(tmp_path / f"w{world}_r{r}.npz") for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, backend, share, n_ladders, paths[r]))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    return [dict(np.load(p)) for p in paths]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+@pytest.mark.parametrize("n_ladders", [1, 3])
+def test_two_ranks_on_real_engines_equal_one_rank(backend, n_ladders, tmp_path):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has one (the 8-GPU driver run covers it)")
+    share = backend == "gloo"
+    single = _run_ranks(1, backend, True, n_ladders, tmp_path)[0]
+    assert single["swaps"].sum() > 0
+    got = _run_ranks(2, backend, share, n_ladders, tmp_path)
+    half = R_GLOBAL // 2
+    for rank, o in enumerate(got):
+        sl = slice(rank * half, (rank + 1) * half)
+        assert np.array_equal(o["swaps"], single["swaps"])
+        assert np.array_equal(o["energies"], single["energies"])
+        assert np.array_equal(o["slot_map"], single["slot_map"])
+        assert np.array_equal(o["spins"], single["spins"][sl])
+        assert np.array_equal(o["temps"], single["temps"][sl])
+        assert o["best_e"] == single["best_e"] and o["best_idx"] == single["best_idx"]
+        assert np.array_equal(o["best_s"], single["best_s"])
