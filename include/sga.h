@@ -162,6 +162,15 @@ int sga_recompute_energies(sga_engine *e);
 int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *start,
                  const double *u, int *n_accepted);
 
+/* Exchange attempts over an ordered list of slot pairs: the CPU branch of the reference's
+ * exchange_method="all_pairs" (annealing/parallel_tempering.py:222-232 -- for i < j, gated by
+ * `np.random.rand() < 0.1`, _attempt_single_exchange(i, j), :234-258; statistics under
+ * min(i, j)).  Each attempt sees the swaps before it.  pairs: host [count][2] int32 global
+ * slot indices in attempt order (the gate is the caller's: it only selects the list);
+ * u: [count] doubles or NULL (Philox, domain 1); energies_global as in sga_exchange. */
+int sga_exchange_pairs(sga_engine *e, const double *energies_global, const int32_t *pairs,
+                       const double *u, int count, int *n_accepted);
+
 /* Stateless operator form of CUDAKernelManager.parallel_tempering_exchange_optimized
  * (annealing/cuda_kernels.py:326-369, fallback :415-443): sequential adjacent pairs, fp32,
  * p = exp((1/T[i+1] - 1/T[i]) * (E[i] - E[i+1])), accepted pairs swap spin rows and energies

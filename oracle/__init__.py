@@ -56,6 +56,8 @@ def lib():
         L.sgo_pt_exchange_round.argtypes = [C.c_int, p, p, p, C.c_int, p, C.c_uint64, C.c_uint32,
                                             C.c_uint32, p, p]
         L.sgo_pt_exchange_round.restype = C.c_int
+        L.sgo_pt_exchange_pairs.argtypes = [C.c_int, p, p, p, p, p, C.c_int, C.c_uint64, C.c_uint32, p, p]
+        L.sgo_pt_exchange_pairs.restype = C.c_int
         L.sgo_pt_exchange_operator.argtypes = [C.c_int, C.c_int, p, p, p, p]
         L.sgo_pt_exchange_operator.restype = C.c_int
         L.sgo_init_spins.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, p]
@@ -209,6 +211,20 @@ def pt_exchange_round(slot_temps, rep_energy, slot_to_rep, start=-1, u=None, see
     return int(lib().sgo_pt_exchange_round(len(t), _ptr(t), _ptr(e), _ptr(slot_to_rep), int(start),
                                            _ptr(uu), int(seed), int(round_), int(ladder), _ptr(attempts),
                                            _ptr(accepts)))
+
+
+def pt_exchange_pairs(slot_temps, rep_energy, slot_to_rep, pairs, u=None, seed=0, round_=0,
+                      attempts=None, accepts=None):
+    """In place on slot_to_rep (int32), attempts/accepts (int64); pairs [count, 2] slot indices."""
+    t, e = _c(slot_temps, np.float64), _c(rep_energy, np.float64)
+    assert slot_to_rep.dtype == np.int32 and slot_to_rep.flags.c_contiguous
+    pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    uu = _c(u, np.float64)
+    rc = int(lib().sgo_pt_exchange_pairs(len(t), _ptr(t), _ptr(e), _ptr(slot_to_rep), _ptr(pr), _ptr(uu),
+                                         len(pr), int(seed), int(round_), _ptr(attempts), _ptr(accepts)))
+    if rc < 0:
+        raise RuntimeError("sgo_pt_exchange_pairs: slot index out of range")
+    return rc
 
 
 def pt_exchange_operator(spins, energies, temps, u):

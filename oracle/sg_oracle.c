@@ -451,6 +451,41 @@ int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_ene
     return n_acc;
 }
 
+int sgo_pt_exchange_pairs(int R, const double *slot_temps, const double *rep_energy,
+                          int32_t *slot_to_rep, const int32_t *pairs, const double *u, int count,
+                          uint64_t seed, uint32_t round, int64_t *attempts, int64_t *accepts) {
+    /* ParallelTempering._all_pairs_exchange, CPU branch (parallel_tempering.py:222-232): the
+     * caller has applied the `rand() < 0.1` gate; each listed pair runs
+     * _attempt_single_exchange (:234-258) and sees the swaps before it. */
+    int n_acc = 0;
+    for (int k = 0; k < count; ++k) {
+        int i = pairs[2 * k], j = pairs[2 * k + 1];
+        if (i < 0 || j < 0 || i >= R || j >= R) return -1;
+        double beta_i = 1.0 / slot_temps[i], beta_j = 1.0 / slot_temps[j];
+        double Ei = rep_energy[slot_to_rep[i]], Ej = rep_energy[slot_to_rep[j]];
+        double x = (beta_j - beta_i) * (Ej - Ei);
+        double prob = (x >= 0.0) ? 1.0 : sgo_exp(x);
+        double uu;
+        if (u) {
+            uu = u[k];
+        } else {
+            uint32_t o[4];
+            stream_block(seed, 0x40000000u | (uint32_t)k, round, 0, 1, o);
+            uu = ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) * 0x1.0p-53;
+        }
+        int lo = i < j ? i : j; /* pair_idx = min(i, j), :249 */
+        if (attempts) attempts[lo] += 1;
+        if (uu < prob) {
+            int32_t tmp = slot_to_rep[i];
+            slot_to_rep[i] = slot_to_rep[j];
+            slot_to_rep[j] = tmp;
+            if (accepts) accepts[lo] += 1;
+            ++n_acc;
+        }
+    }
+    return n_acc;
+}
+
 int sgo_pt_exchange_operator(int R, int n, int8_t *spins, float *energies, const float *temps,
                              const float *u) {
     /* CUDAKernelManager._parallel_tempering_fallback, cuda_kernels.py:415-443 */

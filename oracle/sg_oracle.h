@@ -92,6 +92,12 @@ int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_ene
                           int32_t *slot_to_rep, int start, const double *u, uint64_t seed,
                           uint32_t round, uint32_t ladder, int64_t *attempts, int64_t *accepts);
 
+/* ordered list of slot pairs, each seeing the swaps before it (exchange_method="all_pairs",
+ * parallel_tempering.py:222-258); u NULL = Philox domain 1, block 0x40000000 | k */
+int sgo_pt_exchange_pairs(int R, const double *slot_temps, const double *rep_energy,
+                          int32_t *slot_to_rep, const int32_t *pairs, const double *u, int count,
+                          uint64_t seed, uint32_t round, int64_t *attempts, int64_t *accepts);
+
 /* CUDAKernelManager._parallel_tempering_fallback, cuda_kernels.py:415-443: sequential
  * adjacent pairs, fp32, p = exp((b2-b1)*(E1-E2)), swaps spin rows and energies. */
 int sgo_pt_exchange_operator(int R, int n, int8_t *spins, float *energies, const float *temps,

@@ -40,6 +40,7 @@ SYMBOLS = [
     ("sga_set_update_rule", _i, [_p, _i]),
     ("sga_recompute_energies", _i, [_p]),
     ("sga_exchange", _i, [_p, _p, _p, _p, C.POINTER(_i)]),
+    ("sga_exchange_pairs", _i, [_p, _p, _p, _p, _i, C.POINTER(_i)]),
     ("sga_op_pt_exchange", _i, [_i, _p, _p, _p, _p, _u64, _u32, _i, _i, C.POINTER(_i)]),
     ("sga_get_energies", _i, [_p, _p]),
     ("sga_get_temperatures", _i, [_p, _p]),

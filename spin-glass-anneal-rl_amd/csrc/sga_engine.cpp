@@ -135,8 +135,11 @@ struct sga_engine {
     long long ld = 0;   // spins per replica (whole chunks)
     long long ldj = 0;  // row stride of J_packed: n rounded up to 128 bytes
     int waves = 0, cpw = 0;
-    int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while nnz < 2^31
-    long long *rowptr64 = nullptr;                  // always (energy / single-site kernels, big form)
+    int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while the layout has < 2^31 entries
+    long long *rowptr64 = nullptr;                  // always (energy / single-site kernels)
+    int32_t *rowslot = nullptr;  // slotted layout: row extents in 64-entry slots (wide sweep forms)
+    bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
+    long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
     bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
     int big_form = 0;  // 0 int8 spins | 1 bits, one replica per workgroup, 64-bit extents | 2 bits, narrow
     float *val = nullptr;   // colidx / val: only while the structure is being checked
@@ -149,6 +152,7 @@ struct sga_engine {
     int rule = SGA_RULE_METROPOLIS;
     bool consistent_dE = true;  // J symmetric with zero diagonal: dE of the rule == energy change
     int table_m = 0;  // integer problems: largest possible |dE| / 2 (0 = not integer / too big)
+    int csr_acc = sga::CSR_ACC_F64_CANON;  // CSR: how the sweep kernels form a row sum (set time)
 
     // replicas
     int R = 0, Rg = 0, replica0 = 0;
@@ -186,6 +190,8 @@ struct sga_engine {
         use_t2 = false;
         dev_free(rowptr);
         dev_free(rowptr64);
+        dev_free(rowslot);
+        slotted = false;
         dev_free(colidx);
         dev_free(val);
         dev_free(cv);
@@ -653,10 +659,74 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     return rc;
 }
 
+// Row extents of the layout the kernels read: dst[i] = prefix sum of the rows' lengths, each rounded
+// up to whole 64-entry slots when `slotted`.  n <= ~1.3e6 rows: done on the host at set time.
+static int build_layout(sga_engine *e, const std::vector<long long> &src, bool slotted) {
+    const int n = e->n;
+    std::vector<long long> dst((size_t)n + 1);
+    std::vector<int32_t> slots(slotted ? (size_t)n + 1 : 0), narrow;
+    long long at = 0;
+    for (int i = 0; i < n; ++i) {
+        dst[(size_t)i] = at;
+        if (slotted) slots[(size_t)i] = (int32_t)(at >> 6);
+        const long long len = src[(size_t)i + 1] - src[(size_t)i];
+        at += slotted ? (len + 63) / 64 * 64 : len;
+    }
+    dst[(size_t)n] = at;
+    if (slotted) {
+        if ((at >> 6) >= (long long)INT32_MAX) return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large");
+        slots[(size_t)n] = (int32_t)(at >> 6);
+    }
+    dev_free(e->rowptr);
+    dev_free(e->rowslot);
+    const size_t np1 = (size_t)n + 1;
+    HIPCHK(hipMemcpyAsync(e->rowptr64, dst.data(), sizeof(long long) * np1, hipMemcpyHostToDevice, e->stream));
+    if (at < (long long)INT32_MAX) {
+        narrow.assign(dst.begin(), dst.end());
+        HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * np1));
+        HIPCHK(hipMemcpyAsync(e->rowptr, narrow.data(), sizeof(int32_t) * np1, hipMemcpyHostToDevice, e->stream));
+    }
+    if (slotted) {
+        HIPCHK(hipMalloc(&e->rowslot, sizeof(int32_t) * np1));
+        HIPCHK(hipMemcpyAsync(e->rowslot, slots.data(), sizeof(int32_t) * np1, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));  // the host vectors go out of scope
+    e->slotted = slotted;
+    e->layout_entries = at;
+    return SGA_OK;
+}
+
+// The wide sweep forms (a row dealt to several waves) address rows by 64-entry slots: re-pad an
+// unpadded layout on demand (short-row problems run wide only when tuning asks for it).
+static int ensure_slotted(sga_engine *e) {
+    if (!e->csr || e->slotted) return SGA_OK;
+    const size_t np1 = (size_t)e->n + 1;
+    std::vector<long long> src(np1);
+    HIPCHK(hipMemcpy(src.data(), e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToHost));
+    long long *old_ptr = nullptr;
+    HIPCHK(hipMalloc(&old_ptr, sizeof(long long) * np1));
+    hipError_t he = hipMemcpy(old_ptr, e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToDevice);
+    int2 *old_cv = e->cv;
+    int rc = he == hipSuccess ? build_layout(e, src, true) : fail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    if (rc == SGA_OK) {
+        e->cv = nullptr;
+        he = hipMalloc(&e->cv, sizeof(int2) * ((size_t)e->layout_entries + 64));
+        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * 64, e->stream);
+        if (he == hipSuccess)
+            he = sga::launch_pack_cv_rows(old_ptr, e->rowptr64, nullptr, nullptr, old_cv, e->cv, e->n, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) rc = fail(he == hipErrorOutOfMemory ? SGA_ERR_MEMORY : SGA_ERR_DEVICE, hipGetErrorString(he));
+        dev_free(old_cv);
+    }
+    dev_free(old_ptr);
+    return rc;
+}
+
 // CSR problem from 32- or 64-bit row extents (host or device pointers).  The structure is
 // checked on the device -- a bad extent or column would fault in the sweep kernels -- and the
 // same pass classifies the problem: integer valued (accept table, fp32-exact row sums),
-// symmetric with zero diagonal (dE of the rule == energy change).
+// symmetric with zero diagonal (dE of the rule == energy change).  Device arrays are read where
+// they lie, host arrays are staged; only the interleaved layout stays resident.
 static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, const int32_t *colidx,
                           const float *val, const float *h, int n, int64_t nnz) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
@@ -671,25 +741,32 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     e->n_models = 1;
     e->nnz = nnz;
     const size_t np1 = (size_t)n + 1;
-    const bool narrow_ok = nnz < (int64_t)INT32_MAX;
+    if (!wide_extents && nnz >= (int64_t)INT32_MAX) {
+        e->free_problem();
+        return fail(SGA_ERR_INVALID, "nnz >= 2^31 needs 64-bit row extents (sga_set_csr64)");
+    }
     HIPCHK(hipMalloc(&e->rowptr64, sizeof(long long) * np1));
-    if (narrow_ok) HIPCHK(hipMalloc(&e->rowptr, sizeof(int32_t) * np1));
     if (wide_extents) {
         HIPCHK(hipMemcpyAsync(e->rowptr64, rowptr, sizeof(long long) * np1, hipMemcpyDefault, e->stream));
     } else {
-        if (!narrow_ok) {
-            e->free_problem();
-            return fail(SGA_ERR_INVALID, "nnz >= 2^31 needs 64-bit row extents (sga_set_csr64)");
-        }
-        HIPCHK(hipMemcpyAsync(e->rowptr, rowptr, sizeof(int32_t) * np1, hipMemcpyDefault, e->stream));
-        HIPCHK(sga::launch_widen_rowptr(e->rowptr, e->rowptr64, (long long)np1, e->stream));
+        HIPCHK(e->scratch[1].reserve(sizeof(int32_t) * np1));
+        int32_t *tmp = static_cast<int32_t *>(e->scratch[1].ptr);
+        HIPCHK(hipMemcpyAsync(tmp, rowptr, sizeof(int32_t) * np1, hipMemcpyDefault, e->stream));
+        HIPCHK(sga::launch_widen_rowptr(tmp, e->rowptr64, (long long)np1, e->stream));
     }
     const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
-    HIPCHK(hipMalloc(&e->colidx, sizeof(int32_t) * nz));
-    HIPCHK(hipMalloc(&e->val, sizeof(float) * nz));
-    if (nnz > 0) {
-        HIPCHK(hipMemcpyAsync(e->colidx, colidx, sizeof(int32_t) * nz, hipMemcpyDefault, e->stream));
-        HIPCHK(hipMemcpyAsync(e->val, val, sizeof(float) * nz, hipMemcpyDefault, e->stream));
+    // the caller's arrays: borrowed when they are device memory, staged otherwise (freed below)
+    const int32_t *ci = colidx;
+    const float *vv = val;
+    if (nnz > 0 && !is_device_ptr(colidx)) {
+        HIPCHK(hipMalloc(&e->colidx, sizeof(int32_t) * nz));
+        HIPCHK(hipMemcpyAsync(e->colidx, colidx, sizeof(int32_t) * nz, hipMemcpyHostToDevice, e->stream));
+        ci = e->colidx;
+    }
+    if (nnz > 0 && !is_device_ptr(val)) {
+        HIPCHK(hipMalloc(&e->val, sizeof(float) * nz));
+        HIPCHK(hipMemcpyAsync(e->val, val, sizeof(float) * nz, hipMemcpyHostToDevice, e->stream));
+        vv = e->val;
     }
     HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)n));
     HIPCHK(hipMemcpyAsync(e->h, h, sizeof(float) * (size_t)n, hipMemcpyDefault, e->stream));
@@ -712,9 +789,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
     if (flags[sga::CSR_BAD_ROWPTR])
         return bail(SGA_ERR_INVALID, "CSR rowptr is not monotone or does not span [0, nnz]");
-    if (wide_extents && narrow_ok)
-        HIPCHK(sga::launch_narrow_rowptr(e->rowptr64, e->rowptr, (long long)np1, e->stream));
-    he = sga::launch_csr_scan(e->rowptr64, e->colidx, e->val, e->h, n, d_flags, e->stream);
+    he = sga::launch_csr_scan(e->rowptr64, ci, vv, e->h, n, d_flags, e->stream);
     if (he == hipSuccess) he = read_flags();
     if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
     if (flags[sga::CSR_BAD_COLUMN]) return bail(SGA_ERR_INVALID, "CSR column index out of range");
@@ -724,7 +799,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     const bool sorted = !flags[sga::CSR_UNSORTED];
     const double avg_deg = (double)nnz / n;
     if (sorted || (double)nnz * avg_deg <= 4.0e10) {
-        he = sga::launch_csr_symmetry(e->rowptr64, e->colidx, e->val, n, sorted, d_flags, e->stream);
+        he = sga::launch_csr_symmetry(e->rowptr64, ci, vv, n, sorted, d_flags, e->stream);
         if (he == hipSuccess) he = read_flags();
         if (he != hipSuccess) return bail(SGA_ERR_DEVICE, hipGetErrorString(he));
     } else {
@@ -737,17 +812,51 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     e->table_m = 0;
     if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f)
         e->table_m = (int)std::min(m, 2048.0f);
-    HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, e->colidx, e->val, n, e->diag, e->stream));
-    // the kernels read interleaved entries; the separate arrays are done with
-    // (+1 zeroed entry: a lane of the wide forms that falls past its row's end re-reads the row's
-    // first entry, which for an empty last row is the slot behind the array)
-    HIPCHK(hipMalloc(&e->cv, sizeof(int2) * (nz + 1)));
-    HIPCHK(hipMemsetAsync(e->cv + std::max<int64_t>(nnz, 0), 0, sizeof(int2), e->stream));
-    HIPCHK(sga::launch_pack_cv(e->colidx, e->val, e->cv, nnz, e->stream));
+    HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, ci, vv, n, e->diag, e->stream));
+    std::vector<long long> src(np1);
+    HIPCHK(hipMemcpyAsync(src.data(), e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    dev_free(e->colidx);
+    {
+        // How exact is a row sum?  Integer J with sum |J| < 2^24: fp32 accumulation is exact.  Else,
+        // if every J's set bits lie within 53 binary places of each other once the carries of
+        // the longest row are counted, the fp64 sum of the (exact) fp32 products is exact in any
+        // order.  Only couplings of a wider dynamic range need the canonical summation order.
+        long long max_len = 0;
+        for (int i = 0; i < n; ++i) max_len = std::max(max_len, src[(size_t)i + 1] - src[(size_t)i]);
+        int carry = 0;
+        while ((1ll << carry) < std::max<long long>(max_len, 1)) ++carry;
+        const int e_hi = flags[sga::CSR_EXP_HI] - 1024, e_lo = 1024 - flags[sga::CSR_EXP_LO];
+        const bool any = flags[sga::CSR_EXP_HI] != 0;
+        const bool j_int = (flags[sga::CSR_NOT_INTEGRAL] & 1) == 0;
+        if (j_int && m < 16777216.0f)
+            e->csr_acc = e->table_m > 0 ? sga::CSR_ACC_F32_TABLE : sga::CSR_ACC_F32;
+        else if (!any || (e_hi - e_lo + 1 + carry) <= 52)
+            e->csr_acc = sga::CSR_ACC_F64;
+        else
+            e->csr_acc = sga::CSR_ACC_F64_CANON;
+        if (const char *force = std::getenv("SGA_FORCE_CSR_ACC"))  // parity tests: the slower forms
+            e->csr_acc = std::max(e->csr_acc, std::min(3, std::atoi(force)));
+    }
+    // The layout the kernels read: (column, value) interleaved, one 8-byte load per entry.  Long
+    // rows (mean degree >= 192: the problems that run the wide forms) are padded to whole 64-entry
+    // slots; +64 zeroed entries behind the array (an empty last row's slot 0).
+    long long *src_ptr = nullptr;  // the caller's extents, on the device, while rows are packed
+    HIPCHK(hipMalloc(&src_ptr, sizeof(long long) * np1));
+    he = hipMemcpyAsync(src_ptr, e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToDevice, e->stream);
+    int rc = he == hipSuccess ? build_layout(e, src, avg_deg >= 192.0 && std::getenv("SGA_NO_CSR_SLOTS") == nullptr)
+                              : fail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    if (rc == SGA_OK) {
+        he = hipMalloc(&e->cv, sizeof(int2) * ((size_t)e->layout_entries + 64));
+        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * 64, e->stream);
+        if (he == hipSuccess) he = sga::launch_pack_cv_rows(src_ptr, e->rowptr64, ci, vv, nullptr, e->cv, n, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) rc = fail(he == hipErrorOutOfMemory ? SGA_ERR_MEMORY : SGA_ERR_DEVICE, hipGetErrorString(he));
+    }
+    dev_free(src_ptr);
+    dev_free(e->colidx);  // staging copies of host arrays (null when the caller's were device memory)
     dev_free(e->val);
-    return SGA_OK;
+    if (rc != SGA_OK) e->free_problem();
+    return rc;
 }
 
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
@@ -844,12 +953,17 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
         }
         // real-valued rows are summed in the canonical order of sweep_csr.hip, whose wide builds
         // exist for 1, 2, 4 and 8 waves per replica
-        if (e->table_m == 0 || !e->consistent_dE) {
+        if (e->csr_acc == sga::CSR_ACC_F64_CANON) {
             int p2 = 1;
             while (p2 < e->waves) p2 *= 2;
             e->waves = std::min(p2, 8);
         }
         e->cpw = 0;
+        // one replica per workgroup (row dealt to its waves): rows are addressed by 64-entry slots
+        if (e->waves > 1 || e->big_form == 1) {
+            int rc = ensure_slotted(e);
+            if (rc != SGA_OK) return rc;
+        }
     }
     const size_t sb = (size_t)R_local * e->sstride;
     HIPCHK(hipMalloc(&e->spins, sb));
@@ -1000,6 +1114,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.J = e->J_packed;
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
+        a.rowslot = e->rowslot;
+        a.csr_acc = e->csr_acc;  // (the table form needs its table: set below once table_m is final)
         a.big = e->big_form;
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
@@ -1032,6 +1148,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.arith = arith;
         a.rule = e->rule;
         a.table_m = exact_mode ? 0 : e->table_m;
+        if (a.csr_acc == sga::CSR_ACC_F32_TABLE && a.table_m == 0) a.csr_acc = sga::CSR_ACC_F32;
         a.no_best = exact_mode ? 1 : 0;
         a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
         a.model_stride_j = (long long)e->n * e->ldj;
@@ -1243,6 +1360,56 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
     } else if (d_e.staged || d_u.staged || d_start.staged) {
         HIPCHK(hipStreamSynchronize(st));  // the host buffers may be reused by the caller
     }
+    return SGA_OK;
+}
+
+int sga_exchange_pairs(sga_engine *e, const double *energies_global, const int32_t *pairs,
+                       const double *u, int count, int *n_accepted) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder (call sga_set_ladder)");
+    if (!energies_global && e->R != e->Rg)
+        return fail(SGA_ERR_INVALID, "sharded replicas need the all-gathered energies");
+    if (count < 0 || (count > 0 && !pairs)) return fail(SGA_ERR_INVALID, "bad pair list");
+    if (is_device_ptr(pairs)) return fail(SGA_ERR_INVALID, "pairs must be a host buffer");
+    for (int k = 0; k < 2 * count; ++k)
+        if (pairs[k] < 0 || pairs[k] >= e->Rg) return fail(SGA_ERR_INVALID, "slot index out of range");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    DevIn<double> d_e, d_u;
+    DevIn<int32_t> d_pairs;
+    int rc;
+    if (energies_global) {
+        rc = d_e.init(e->scratch[6], energies_global, (size_t)e->Rg, st);
+        if (rc != SGA_OK) return rc;
+    }
+    rc = d_pairs.init(e->scratch[7], pairs, (size_t)2 * count, st);
+    if (rc != SGA_OK) return rc;
+    if (u) {
+        rc = d_u.init(e->scratch[8], u, (size_t)count, st);
+        if (rc != SGA_OK) return rc;
+    }
+    sga::ExchangeArgs a{};
+    a.energies = energies_global ? d_e.ptr : e->energy;
+    a.slot_temps = e->slot_temps;
+    a.slot_to_rep = e->slot_to_rep;
+    a.rep_temp = e->rep_temp;
+    a.attempts = e->ex_attempts;
+    a.accepts = e->ex_accepts;
+    a.u = d_u.ptr;
+    a.n_accepted = e->d_count;
+    a.R_global = e->Rg;
+    a.R_local = e->R;
+    a.replica0 = e->replica0;
+    a.n_ladders = e->n_ladders;
+    a.seed_lo = (uint32_t)e->seed;
+    a.seed_hi = (uint32_t)(e->seed >> 32);
+    a.round = e->rounds;
+    HIPCHK(sga::launch_exchange_pairs(a, d_pairs.ptr, count, st));
+    e->rounds += 1;
+    int cnt = 0;  // (the pair list was staged from the host: synchronise in any case)
+    HIPCHK(hipMemcpyAsync(&cnt, e->d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_accepted) *n_accepted = cnt;
     return SGA_OK;
 }
 
@@ -1599,7 +1766,13 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->n, e->nnz, e->R, e->waves,
                       e->big_form == 2 ? sga::csr_bits_waves_per_block(e->sstride, e->table_m)
                                        : ((e->waves > 1 || e->big) ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m)),
-                      e->sstride, e->table_m > 0 ? "integer-fast" : "general", e->table_m,
+                      e->sstride,
+                      (e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0) ? "integer-fast"
+                      : e->csr_acc == sga::CSR_ACC_F32_TABLE ? "general acc=f32-exact"
+                      : e->csr_acc == sga::CSR_ACC_F32     ? "general acc=f32-exact"
+                      : e->csr_acc == sga::CSR_ACC_F64     ? "general acc=f64-exact"
+                                                           : "general acc=f64-canonical",
+                      e->table_m,
                       e->big ? "lds-bits" : "lds-int8");
     else
         std::snprintf(tmp, sizeof(tmp),
@@ -1615,6 +1788,9 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,
                                                   e->use_t2 ? e->waves_t2 : e->waves, e->R)
                           : 1);
+    if (e->csr && e->slotted)
+        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp), " rows=64-entry-slots(+%.1f%%)",
+                      e->nnz > 0 ? 100.0 * (double)(e->layout_entries - e->nnz) / (double)e->nnz : 0.0);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

@@ -19,8 +19,10 @@ constexpr int CSR_WAVES_PER_BLOCK = 4;
 struct SweepArgs {
     // couplings
     const void *J;           // dense: [n][ld] of float | int8, zero padded rows
-    const int32_t *rowptr;   // CSR, nnz < 2^31 (null otherwise)
+    const int32_t *rowptr;   // CSR, layout entries < 2^31 (null otherwise)
     const long long *rowptr64;  // CSR, always present
+    const int32_t *rowslot;  // CSR, slotted layout (rows padded to whole 64-entry slots): row extents
+                             // in slots; the wide sweep forms address rows by it (null otherwise)
     const int2 *cv;          // CSR entries, (column, value bits) interleaved: one 8-byte load each
     const float *h;          // [n]
     const float *diag;       // [n] J_ii (ARITH_F32 only)
@@ -57,6 +59,7 @@ struct SweepArgs {
     int big;      // CSR: spins held as bits in LDS; 1 = one replica per workgroup with 64-bit row
                   // extents (n > ~160k, nnz >= 2^31, long rows), 2 = narrow form, several replicas per
                   // workgroup (short rows)
+    int csr_acc;         // CSR: one of CSR_ACC_* (how a row sum is formed)
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
@@ -114,6 +117,8 @@ size_t csr_lds_bytes(int sstride, int table_m, bool bits);  // LDS of one replic
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
+// ordered list of slot pairs [count][2], one serial chain (exchange_method="all_pairs")
+hipError_t launch_exchange_pairs(const ExchangeArgs &a, const int32_t *pairs, int count, hipStream_t st);
 hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,
                              uint32_t seed_hi, uint32_t replica0, hipStream_t st);
 // J repack: fp32 [n][ldJ] -> float | int8 [n][ld] zero padded (ld = the packed row stride), plus diag[n]
@@ -133,6 +138,9 @@ hipError_t launch_gather_diag_csr(const long long *rowptr, const int32_t *colidx
 // (half the memory instructions, one page instead of two per row)
 hipError_t launch_pack_cv(const int32_t *colidx, const float *val, int2 *cv, long long nnz,
                           hipStream_t st);
+// row-wise packing into a (possibly padded) layout; cv_src != null: re-pad an interleaved layout
+hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_ptr, const int32_t *colidx,
+                               const float *val, const int2 *cv_src, int2 *cv, int n, hipStream_t st);
 // CSR row extents between their 32- and 64-bit forms ([n + 1] entries)
 hipError_t launch_widen_rowptr(const int32_t *src, long long *dst, long long count, hipStream_t st);
 hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long count, hipStream_t st);
@@ -141,8 +149,16 @@ hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long co
 //  [2] some J or h not an integer                     [3] rows not strictly sorted by column
 //  [4] non-zero diagonal entry                        [5] J[i][j] != J[j][i]
 //  [6] bits of max_i(sum_j |J_ij| + |h_i|) as float
+//  [7] 1024 + highest binary exponent of a non-zero J   [8] 1024 - exponent of the lowest set bit
+//  ([2]: bit 0 = some J, bit 1 = some h not an integer)
 enum { CSR_BAD_ROWPTR = 0, CSR_BAD_COLUMN, CSR_NOT_INTEGRAL, CSR_UNSORTED, CSR_DIAGONAL,
-       CSR_ASYMMETRIC, CSR_ROW_ABS_MAX, CSR_FLAG_COUNT = 8 };
+       CSR_ASYMMETRIC, CSR_ROW_ABS_MAX, CSR_EXP_HI, CSR_EXP_LO, CSR_FLAG_COUNT = 10 };
+// how the CSR sweep kernels form a row sum
+enum { CSR_ACC_F32_TABLE = 0,   // integer J and h, few distinct uphill moves: fp32 (exact) + accept table
+       CSR_ACC_F32 = 1,         // integer J with row sums below 2^24: fp32 accumulation is exact
+       CSR_ACC_F64 = 2,         // the fp64 sum of the row's fp32 values is exact (binary exponents of
+                                // all J within 53 bits of each other incl. the row length): any order
+       CSR_ACC_F64_CANON = 3 }; // anything else: fp64 in the canonical order (sweep_csr.hip)
 hipError_t launch_csr_check_rowptr(const long long *rowptr, int n, long long nnz, int *flags,
                                    hipStream_t st);
 hipError_t launch_csr_scan(const long long *rowptr, const int32_t *colidx, const float *val,

@@ -210,6 +210,46 @@ hipError_t launch_pack_cv(const int32_t *colidx, const float *val, int2 *cv, lon
     return hipGetLastError();
 }
 
+// Row-wise packing into a layout whose rows may be PADDED (dst extents >= src extents): long rows
+// are padded to whole 64-entry slots (512 B) so that the wide sweep forms address a row by
+// wave-uniform slot numbers -- scalar address arithmetic, no per-lane bounds tests.  Pad entries
+// carry value 0 and the row's first column (an in-range gather).  One workgroup per row.
+// SRC_CV: the source is already interleaved (re-padding an unpadded layout on demand).
+template <bool SRC_CV>
+__global__ void __launch_bounds__(256) pack_cv_rows_kernel(const long long *__restrict__ src_ptr,
+                                                           const long long *__restrict__ dst_ptr,
+                                                           const int32_t *__restrict__ colidx,
+                                                           const float *__restrict__ val,
+                                                           const int2 *__restrict__ cv_src,
+                                                           int2 *__restrict__ cv, int n) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long sb = src_ptr[i], len = src_ptr[i + 1] - sb;
+        const long long db = dst_ptr[i], plen = dst_ptr[i + 1] - db;
+        int pad_col = 0;
+        if (len > 0) pad_col = SRC_CV ? cv_src[sb].x : colidx[sb];
+        for (long long j = threadIdx.x; j < plen; j += blockDim.x) {
+            int2 e = make_int2(pad_col, 0);
+            if (j < len) {
+                if constexpr (SRC_CV) e = cv_src[sb + j];
+                else e = make_int2(colidx[sb + j], __float_as_int(val[sb + j]));
+            }
+            cv[db + j] = e;
+        }
+    }
+}
+hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_ptr, const int32_t *colidx,
+                               const float *val, const int2 *cv_src, int2 *cv, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int blocks = std::min(n, 65536);
+    if (cv_src)
+        hipLaunchKernelGGL(pack_cv_rows_kernel<true>, dim3(blocks), dim3(256), 0, st, src_ptr, dst_ptr,
+                           colidx, val, cv_src, cv, n);
+    else
+        hipLaunchKernelGGL(pack_cv_rows_kernel<false>, dim3(blocks), dim3(256), 0, st, src_ptr, dst_ptr,
+                           colidx, val, cv_src, cv, n);
+    return hipGetLastError();
+}
+
 __global__ void widen_rowptr_kernel(const int32_t *src, long long *dst, long long count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i];
@@ -252,6 +292,7 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
     int bad_col = 0, non_int = 0, unsorted = 0, diag = 0;
+    int exp_hi = 0, exp_lo = 0;  // 1024 + highest exponent | 1024 - lowest set bit's exponent (0: no value yet)
     float row_max = 0.0f;
     for (int i = wave; i < n; i += n_waves) {
         const long long beg = rowptr[i], end = rowptr[i + 1];
@@ -260,19 +301,30 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
             const int c = colidx[j];
             const float v = val[j];
             if (c < 0 || c >= n) bad_col = 1;
-            if (v != rintf(v)) non_int = 1;
+            if (v != rintf(v)) non_int |= 1;
+            if (v != 0.0f) {  // binary exponents of the value's highest and lowest set bits
+                const unsigned int bits = __float_as_uint(v);
+                const int ef = (int)((bits >> 23) & 255u);
+                const unsigned int mant = (bits & 0x7FFFFFu) | (ef ? 0x800000u : 0u);
+                const int e_hi = ef ? ef - 127 : -127;
+                const int e_lo = (ef ? ef - 127 : -126) - 23 + __builtin_ctz(mant ? mant : 1u);
+                exp_hi = max(exp_hi, e_hi + 1024);
+                exp_lo = max(exp_lo, 1024 - e_lo);
+            }
             if (c == i && v != 0.0f) diag = 1;
             if (j > beg && colidx[j - 1] >= c) unsorted = 1;
             acc += (double)fabsf(v);
         }
         const float hi = h[i];
-        if (hi != rintf(hi)) non_int = 1;
+        if (hi != rintf(hi)) non_int |= 2;
         // an upper bound is all the table needs; fp32 rounds it up or down by < 1 ulp
         const float tot = (float)(wave_sum(acc) + (double)fabsf(hi));
         row_max = fmaxf(row_max, tot);
     }
     if (bad_col) flags[CSR_BAD_COLUMN] = 1;
-    if (non_int) flags[CSR_NOT_INTEGRAL] = 1;
+    if (non_int) atomicOr(&flags[CSR_NOT_INTEGRAL], non_int);  // bit 0: some J, bit 1: some h
+    if (exp_hi) atomicMax(&flags[CSR_EXP_HI], exp_hi);
+    if (exp_lo) atomicMax(&flags[CSR_EXP_LO], exp_lo);
     if (unsorted) flags[CSR_UNSORTED] = 1;
     if (diag) flags[CSR_DIAGONAL] = 1;
     if (lane == 0) atomicMax(&flags[CSR_ROW_ABS_MAX], __float_as_int(row_max));  // >= 0: bits order
@@ -703,6 +755,51 @@ hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st) {
     if (total <= 0) return hipSuccess;
     const int blocks = (total + 255) / 256;
     hipLaunchKernelGGL(exchange_neighbor_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// Exchange attempts over an explicit, ordered list of slot pairs -- the reference's
+// exchange_method="all_pairs" (annealing/parallel_tempering.py:222-232: for i < j, gated by
+// rand() < 0.1, _attempt_single_exchange(i, j)): every attempt sees the swaps before it, so the
+// list is one serial chain (thread 0); the local temperatures are rewritten by the workgroup.
+__global__ void __launch_bounds__(256) exchange_pairs_kernel(const ExchangeArgs a, const int32_t *pairs,
+                                                             int count) {
+    if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int k = 0; k < count; ++k) {
+            const int i = pairs[2 * k], j = pairs[2 * k + 1];
+            // _attempt_single_exchange, parallel_tempering.py:234-258
+            const double beta_i = 1.0 / a.slot_temps[i], beta_j = 1.0 / a.slot_temps[j];
+            const int ri = a.slot_to_rep[i], rj = a.slot_to_rep[j];
+            const double x = (beta_j - beta_i) * (a.energies[rj] - a.energies[ri]);
+            const double prob = (x >= 0.0) ? 1.0 : exp_det(x);
+            double uu;
+            if (a.u) {
+                uu = a.u[k];
+            } else {
+                const u32x4 w = philox4x32_10(0x40000000u | (uint32_t)k, a.round, 0u, DOMAIN_EXCHANGE,
+                                              a.seed_lo, a.seed_hi);
+                uu = words_to_u53(w.x, w.y);
+            }
+            const int lo = i < j ? i : j;  // pair_idx = min(i, j), parallel_tempering.py:249
+            a.attempts[lo] += 1;
+            if (uu < prob) {
+                a.slot_to_rep[i] = rj;
+                a.slot_to_rep[j] = ri;
+                a.accepts[lo] += 1;
+                ++cnt;
+            }
+        }
+        *a.n_accepted = cnt;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < a.R_global; s += blockDim.x) {
+        const int l = a.slot_to_rep[s] - a.replica0;
+        if (l >= 0 && l < a.R_local) a.rep_temp[l] = a.slot_temps[s];
+    }
+}
+hipError_t launch_exchange_pairs(const ExchangeArgs &a, const int32_t *pairs, int count, hipStream_t st) {
+    hipLaunchKernelGGL(exchange_pairs_kernel, dim3(1), dim3(256), 0, st, a, pairs, count);
     return hipGetLastError();
 }
 

@@ -48,18 +48,25 @@ constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (1
 // NW = 1, 2, 4 or 8 real waves reproduces that exactly with 8 / NW accumulators per lane (NW is a
 // template parameter of the wide real-valued builds, so every accumulator index is a constant);
 // the CPU checker forms the same sum.
-template <bool FAST, bool LEAN, bool WIDE, bool BIG, int NW = 0>
-__global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CSR_WAVES_PER_BLOCK))
+// ACC = how a row sum is formed (CSR_ACC_*, chosen at set time): fp32 where that is exact
+// (integer J), with the accept table if h is integer too and the moves are few; fp64 in any order
+// where THAT is exact (all J within 53 binary places of each other, row length included -- e.g. the
+// TSP distances); the canonical fp64 order otherwise.
+template <int ACC, bool LEAN, bool WIDE, bool BIG, int NW = 0>
+__global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
     sweep_csr_kernel(const SweepArgs a) {
-    static_assert(FAST || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
-                  "real-valued wide builds are made per wave count");
-    // bit spins also come in the narrow form (several replicas per workgroup, 32-bit extents):
-    // short rows on 40k < n <= 1.3M spins, where the int8 spins leave one or two replicas per
-    // workgroup
-    using rp_t = typename std::conditional<BIG && WIDE, long long, int>::type;
-    const rp_t *rowptr = nullptr;
-    if constexpr (BIG && WIDE) rowptr = a.rowptr64;
-    else rowptr = a.rowptr;
+    constexpr bool FAST = ACC == CSR_ACC_F32_TABLE || ACC == CSR_ACC_F32;  // fp32 accumulation
+    constexpr bool TABLE = ACC == CSR_ACC_F32_TABLE;
+    constexpr bool CANON = ACC == CSR_ACC_F64_CANON;
+    static_assert(!CANON || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
+                  "canonical-order wide builds are made per wave count");
+    // Row extents: the narrow forms (one wave per replica) index entries (a.rowptr, 32 bit); the
+    // wide forms address a row by its 64-entry SLOTS (a.rowslot: rows are padded to whole slots,
+    // pad entries carry the value 0), so a slot number is wave-uniform: the address arithmetic is
+    // scalar and no lane tests a bound.  32-bit slot numbers cover nnz >= 2^31 (config 5 at 1000
+    // cities: 63 M slots).
+    using rp_t = int;
+    const rp_t *rowptr = WIDE ? a.rowslot : a.rowptr;
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;  // (a run-time rule costs C3 12 %: issue bound)
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,26 +136,24 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
     struct Head {
         int col[HEAD];
         float val[HEAD];
-        int len;                  // wide forms: the row's entry count (wave-uniform)
+        int len;                  // wide forms: the row's slot count (wave-uniform)
         const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer)
     };
-    // wave-uniform value -> SGPRs
-    auto uniform = [&](rp_t v) -> rp_t {
-        if constexpr (sizeof(rp_t) == 8) {
-            const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)v);
-            const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)v >> 32));
-            return (rp_t)(((unsigned long long)hi << 32) | lo);
-        } else {
-            return (rp_t)__builtin_amdgcn_readfirstlane((int)v);
-        }
-    };
-    // entry `idx` of a row (wide forms): uniform row pointer + 32-bit byte offset = the scalar-base
-    // load form; past the row's end the lane re-reads entry 0 and the caller zeroes its value
-    auto row_entry = [&](const int2 *row, int idx, int len) -> int2 {
-        unsigned int off = (unsigned int)(idx < len ? idx : 0) * 8u;
+    // wave-uniform value -> SGPR
+    auto uniform = [&](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+    // this lane's entry of slot `slot` (wave-uniform) of the row starting at `row` (wave-uniform):
+    // scalar base + one constant 32-bit lane offset = the scalar-base load form
+    const unsigned int lane8 = (unsigned int)lane * 8u;
+    auto slot_entry = [&](const int2 *row, int slot) -> int2 {
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(row) +
+                                 ((unsigned long long)(unsigned int)slot << 9);
+        // the lane offset stays a 32-bit value opaque to the optimiser (a hoisted 64-bit
+        // zero extension of it loses the base + zext(VGPR) address form)
+        unsigned int off = lane8;
         asm volatile("" : "+v"(off));
-        return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
+        return *reinterpret_cast<const int2 *>(p + off);
     };
+    const int nwc = (WIDE && NW > 0) ? NW : nw;  // waves of this replica (a constant in the real-valued wide builds)
     auto load_extent = [&](int site) {
         Extent o;
         o.beg = rowptr[site];
@@ -162,17 +167,18 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
         o.len = 0;
         o.row = nullptr;
         if constexpr (WIDE) {
-            // 8 entries per lane: per-entry 64-bit index arithmetic and predication were a third
-            // of the kernel's VALU work at degree 4000 (PMC: 27 VALU per entry); the extent arrived
-            // updates ago, so pin it to SGPRs and address entries by a 32-bit index from the row
-            const rp_t beg = uniform(x.beg);
-            o.len = (int)(uniform(x.end) - beg);
-            o.row = a.cv + beg;
+            // HEAD slots per wave: slot w + nw q of the row, q = 0..HEAD-1.  The extent arrived
+            // updates ago: pin it to SGPRs.  A slot past the row's end re-reads slot 0 (no extra
+            // traffic) and its values are zeroed by a wave-uniform select when used.
+            const int beg = uniform(x.beg);
+            o.len = uniform(x.end) - beg;
+            o.row = a.cv + ((long long)beg << 6);
 #pragma unroll
             for (int q = 0; q < HEAD; ++q) {
-                const int2 ent = row_entry(o.row, first_lane + stride_lanes * q, o.len);
+                const int sq = w + nwc * q;
+                const int2 ent = slot_entry(o.row, sq < o.len ? sq : 0);
                 o.col[q] = ent.x;
-                o.val[q] = __int_as_float(ent.y);  // zeroed past the end when used
+                o.val[q] = __int_as_float(ent.y);
             }
             return o;
         }
@@ -190,7 +196,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
     // value q of the requested head; the wide forms zero it past the row's end here, not right
     // behind the load (a select there would put the wait directly behind the load)
     auto head_val = [&](const Head &hd, int q) -> float {
-        if constexpr (WIDE) return (first_lane + stride_lanes * q) < hd.len ? hd.val[q] : 0.0f;
+        if constexpr (WIDE) return (w + nwc * q) < hd.len ? hd.val[q] : 0.0f;  // wave-uniform test
         else return hd.val[q];
     };
 
@@ -207,15 +213,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
             // longer rows: issue eight entry wave-loads before the first gather so the round trips
             // overlap instead of serialising (degree ~600 at C4)
             if constexpr (WIDE) {
-                for (int i0 = stride_lanes * HEAD; i0 < hd.len; i0 += stride_lanes * TAIL_UNROLL) {
+                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
                     float v[TAIL_UNROLL];
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const int idx = i0 + first_lane + stride_lanes * q;
-                        const int2 ent = row_entry(hd.row, idx, hd.len);
+                        const int sq = s0 + w + nwc * q;
+                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
                         c[q] = ent.x;
-                        v[q] = idx < hd.len ? __int_as_float(ent.y) : 0.0f;
+                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
                     }
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) acc += term(v[q], c[q]);
@@ -247,6 +253,53 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
                 dot = t;
                 pp ^= 1;
             }
+        } else if constexpr (!CANON) {
+            // the fp64 sum of this row's values is exact (set-time scan): any order, one tree
+            double acc = (double)term(head_val(hd, 0), hd.col[0]);
+#pragma unroll
+            for (int q = 1; q < HEAD; ++q) acc += (double)term(head_val(hd, q), hd.col[q]);
+            if constexpr (WIDE) {
+                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const int sq = s0 + w + nwc * q;
+                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
+                        c[q] = ent.x;
+                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                }
+            } else {
+                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
+                     j0 += stride_lanes * TAIL_UNROLL) {
+                    int c[TAIL_UNROLL];
+                    float v[TAIL_UNROLL];
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const rp_t j = j0 + stride_lanes * q;
+                        const bool in = j < x.end;
+                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                        c[q] = ent.x;
+                        v[q] = __int_as_float(ent.y);
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                }
+            }
+            double tot = wave_sum(acc);
+            if constexpr (WIDE) {
+                double *slot = part + pp * CSR_MAX_WIDE;
+                if (lane == 0) slot[w] = tot;
+                __syncthreads();
+                double t = slot[0];
+                for (int i = 1; i < nw; ++i) t += slot[i];
+                tot = t;
+                pp ^= 1;
+            }
+            dot = (float)tot;
         } else {  // fp64 sum in the canonical order, rounded to fp32 once (core/ising_model.py:183)
             constexpr int NV = WIDE ? 8 / (NW > 0 ? NW : 8) : 8;  // virtual waves per real wave
             double acc[NV];
@@ -258,15 +311,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
                     if (q < NV) acc[q] = t;
                     else acc[q % NV] += t;
                 }
-                for (int i0 = stride_lanes * HEAD; i0 < hd.len; i0 += stride_lanes * TAIL_UNROLL) {
+                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
                     float v[TAIL_UNROLL];
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const int idx = i0 + first_lane + stride_lanes * q;
-                        const int2 ent = row_entry(hd.row, idx, hd.len);
+                        const int sq = s0 + w + nwc * q;
+                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
                         c[q] = ent.x;
-                        v[q] = idx < hd.len ? __int_as_float(ent.y) : 0.0f;
+                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
                     }
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NV] += (double)term(v[q], c[q]);
@@ -276,8 +329,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int v = w + (NW > 0 ? NW : 8) * j;
-                    double sv = 0.0;
-                    if (hd.len > 64 * v) sv = wave_sum(acc[j]);  // wave-uniform test
+                    const double sv = wave_sum(acc[j]);  // (+0 when the row has no slot v)
                     if (lane == 0) slot[v] = sv;
                 }
                 __syncthreads();
@@ -314,10 +366,11 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
                     if (len > 64 * j) t += wave_sum(acc[j]);  // wave-uniform test
                 dot = (float)t;
             }
+        
         }
         double dE;
         bool flip;
-        if (FAST && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
+        if (TABLE && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
             // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2k exactly
             const float fk = (float)si * (dot + x.h);
             dE = (double)(2.0f * fk);
@@ -352,7 +405,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? (NW > 0 ? NW : CSR_MAX_WIDE) : CS
 
     auto sweep_start = [&](int k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-        if constexpr (FAST) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
+        if constexpr (TABLE) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
             if constexpr (WIDE) __syncthreads();  // nobody still reads last sweep's table
             for (int q = first_lane; q <= a.table_m; q += stride_lanes)
                 ptab[q] = expf_det((float)(-(double)(2 * q) / T));
@@ -488,23 +541,35 @@ int csr_bits_waves_per_block(int sstride, int table_m) {  // narrow bit-spin for
 
 template <bool WIDE, bool BIG>
 static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
-    const bool fast = a.table_m > 0, lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
+    const bool lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
     const int slots = WIDE ? 1 : waves;
     const size_t lds = csr_lds_per_replica(a.sstride, a.table_m, BIG) * slots +
                        2 * CSR_MAX_WIDE * sizeof(double);
+    // the accept table is a specialisation of the production (LEAN) builds
+    int acc = a.csr_acc;
+    if (acc == CSR_ACC_F32_TABLE && (!lean || a.table_m <= 0)) acc = CSR_ACC_F32;
     void (*kern)(const SweepArgs) = nullptr;
-    if (fast) {
-        kern = lean ? sweep_csr_kernel<true, true, WIDE, BIG> : sweep_csr_kernel<true, false, WIDE, BIG>;
-    } else if constexpr (!WIDE) {
-        kern = lean ? sweep_csr_kernel<false, true, false, BIG> : sweep_csr_kernel<false, false, false, BIG>;
-    } else {  // real-valued wide builds: one per wave count (canonical summation order)
-        switch (waves) {
-            case 1: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 1> : sweep_csr_kernel<false, false, true, BIG, 1>; break;
-            case 2: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 2> : sweep_csr_kernel<false, false, true, BIG, 2>; break;
-            case 4: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 4> : sweep_csr_kernel<false, false, true, BIG, 4>; break;
-            case 8: kern = lean ? sweep_csr_kernel<false, true, true, BIG, 8> : sweep_csr_kernel<false, false, true, BIG, 8>; break;
-            default: return hipErrorInvalidValue;  // the engine rounds the wave count up to a power of two
-        }
+    switch (acc) {
+        case CSR_ACC_F32_TABLE: kern = sweep_csr_kernel<CSR_ACC_F32_TABLE, true, WIDE, BIG>; break;
+        case CSR_ACC_F32:
+            kern = lean ? sweep_csr_kernel<CSR_ACC_F32, true, WIDE, BIG> : sweep_csr_kernel<CSR_ACC_F32, false, WIDE, BIG>;
+            break;
+        case CSR_ACC_F64:
+            kern = lean ? sweep_csr_kernel<CSR_ACC_F64, true, WIDE, BIG> : sweep_csr_kernel<CSR_ACC_F64, false, WIDE, BIG>;
+            break;
+        default:
+            if constexpr (!WIDE) {
+                kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, false, BIG>
+                            : sweep_csr_kernel<CSR_ACC_F64_CANON, false, false, BIG>;
+            } else {  // one build per wave count
+                switch (waves) {
+                    case 1: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 1> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 1>; break;
+                    case 2: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 2> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 2>; break;
+                    case 4: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 4> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 4>; break;
+                    case 8: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 8> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 8>; break;
+                    default: return hipErrorInvalidValue;  // the engine rounds the wave count up to a power of two
+                }
+            }
     }
     {
         hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
@@ -520,24 +585,23 @@ static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
 // always one replica per workgroup (1..CSR_MAX_WIDE waves).
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st) {
     if (a.big) {
-        if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !a.rowptr64 ||
-            !csr_big_fits(a.sstride, a.table_m))
+        if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !csr_big_fits(a.sstride, a.table_m))
             return hipErrorInvalidValue;
         if (waves_per_replica == 1 && a.rowptr && a.big == 2) {  // several replicas per workgroup
             const int wpb = csr_bits_waves_per_block(a.sstride, a.table_m);
             if (wpb < 1) return hipErrorInvalidValue;
             return launch_csr<false, true>(a, wpb, st);
         }
+        if (!a.rowslot) return hipErrorInvalidValue;  // wide forms read the slotted layout
         return launch_csr<true, true>(a, waves_per_replica, st);
     }
-    if (!a.rowptr) return hipErrorInvalidValue;
     if (waves_per_replica > 1) {
-        if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1)
+        if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1 || !a.rowslot)
             return hipErrorInvalidValue;
         return launch_csr<true, false>(a, waves_per_replica, st);
     }
     const int wpb = csr_waves_per_block(a.sstride, a.table_m);
-    if (wpb < 1) return hipErrorInvalidValue;
+    if (wpb < 1 || !a.rowptr) return hipErrorInvalidValue;
     return launch_csr<false, false>(a, wpb, st);
 }
 

@@ -290,6 +290,19 @@ class AnnealEngine:
         N.check(self._lib.sga_exchange(self._h, ep, stp, up, C.byref(out)), "sga_exchange")
         return int(out.value)
 
+    def exchange_pairs(self, pairs, u=None, energies_global=None) -> int:
+        """Exchange attempts over an ordered list of slot pairs [(i, j), ...], each seeing the
+        swaps before it (the reference's exchange_method="all_pairs").  Returns the accepted count."""
+        pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        ep, k1 = _buf(energies_global, np.float64, "float64")
+        up, k2 = _buf(u, np.float64, "float64")
+        if k2 is not None and (k2.numel() if _is_tensor(k2) else k2.size) != len(pr):
+            raise AnnealingError("u must have one entry per pair")
+        out = C.c_int(0)
+        N.check(self._lib.sga_exchange_pairs(self._h, ep, pr.ctypes.data_as(C.c_void_p), up, len(pr),
+                                             C.byref(out)), "sga_exchange_pairs")
+        return int(out.value)
+
     # ------------------------------------------------------------------ state access
     def energies(self) -> np.ndarray:
         out = np.zeros(self.R, np.float64)

@@ -66,8 +66,13 @@ class ParallelTempering:
         recorded from the reference, replacing every Philox draw."""
         rule = rule_code(update_rule)
         cfg = self.config
-        if cfg.exchange_method != "nearest_neighbor":
-            raise AnnealingError("only exchange_method='nearest_neighbor' runs on the HIP engine")
+        if cfg.exchange_method not in ("nearest_neighbor", "all_pairs"):
+            raise ValueError(f"Unknown exchange method: {cfg.exchange_method}")  # reference :212
+        all_pairs = cfg.exchange_method == "all_pairs"
+        # all_pairs: the gate `np.random.rand() < 0.1` of the reference (:222-232) only selects which
+        # pairs are attempted; it is drawn on the host (seeded), the attempts run on the engine
+        gate_rng = np.random.RandomState(fresh_seed(cfg.random_seed) & 0x7FFFFFFF)
+        pair_list = [(i, j) for i in range(cfg.n_replicas - 1) for j in range(i + 1, cfg.n_replicas)]
         t_start = time.time()
         R, n = cfg.n_replicas, model.n_spins
         temps = np.asarray(self.temperatures, np.float64)
@@ -103,7 +108,23 @@ class ParallelTempering:
                 acc_slot += (acc_now - acc_prev)[slot_to_rep]
                 att_slot += count * n
                 acc_prev = acc_now
-                if stop % cfg.exchange_interval == 0 and stop > 0:  # reference :113
+                if stop % cfg.exchange_interval == 0 and stop > 0 and all_pairs:
+                    if _replay is None:
+                        gates = gate_rng.rand(len(pair_list)) < 0.1
+                        eng.exchange_pairs([p for p, g in zip(pair_list, gates) if g])
+                    else:  # the recorded stream: a gate draw per pair, an exchange draw behind an open gate
+                        stream, chosen, uu = _replay["np_rand_all"], [], []
+                        for p in pair_list:
+                            g = stream[ucur]
+                            ucur += 1
+                            if g < 0.1:
+                                chosen.append(p)
+                                uu.append(stream[ucur])
+                                ucur += 1
+                        eng.exchange_pairs(chosen, u=np.asarray(uu, np.float64))
+                    rnd += 1
+                    slot_to_rep = eng.slot_map()
+                elif stop % cfg.exchange_interval == 0 and stop > 0:  # reference :113
                     if _replay is None:
                         eng.exchange()
                     else:

@@ -67,26 +67,21 @@ class AnnealingResult:
         data["best_configuration"] = self.best_configuration.cpu().numpy()
         np.savez_compressed(filepath, **data)
 
+    # how each saved entry comes back from the npz (the reference's reader, result.py:167-188):
+    # 0-d arrays to python scalars, histories to lists; a falsy convergence_sweep / random_seed
+    # (None is stored as an object array, and 0 reads as None too) means "not set"
+    _opt_int = staticmethod(lambda a: int(a) if a else None)
+    _READ = {"best_energy": float, "total_time": float, "n_sweeps": int, "final_temperature": float,
+             "final_acceptance_rate": float, "energy_std": float, "algorithm": str, "device": str,
+             "energy_history": np.ndarray.tolist, "temperature_history": np.ndarray.tolist,
+             "acceptance_rate_history": np.ndarray.tolist}
+
     @classmethod
     def load(cls, filepath: str) -> "AnnealingResult":
-        z = np.load(filepath, allow_pickle=True)
-
-        return cls(
-            best_configuration=torch.from_numpy(z["best_configuration"]),
-            best_energy=float(z["best_energy"]),
-            energy_history=z["energy_history"].tolist(),
-            temperature_history=z["temperature_history"].tolist(),
-            acceptance_rate_history=z["acceptance_rate_history"].tolist(),
-            total_time=float(z["total_time"]),
-            n_sweeps=int(z["n_sweeps"]),
-            convergence_sweep=int(z["convergence_sweep"]) if z["convergence_sweep"] else None,
-            final_temperature=float(z["final_temperature"]),
-            final_acceptance_rate=float(z["final_acceptance_rate"]),
-            energy_std=float(z["energy_std"]),
-            algorithm=str(z["algorithm"]),
-            device=str(z["device"]),
-            random_seed=int(z["random_seed"]) if z["random_seed"] else None,
-        )
+        with np.load(filepath, allow_pickle=True) as z:
+            fields = {k: cls._READ.get(k, cls._opt_int)(z[k]) for k in cls._SAVED}
+            fields["best_configuration"] = torch.from_numpy(z["best_configuration"])
+        return cls(**fields)
 
     def __repr__(self) -> str:
         return (f"AnnealingResult(best_energy={self.best_energy:.6f}, n_sweeps={self.n_sweeps}, "

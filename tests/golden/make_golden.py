@@ -233,9 +233,23 @@ def case_pt(name, J, h, cfg_kwargs, out):
     st = rec.stream()
     R, n = cfg.n_replicas, J.shape[0]
     assert len(st["site"]) == cfg.n_sweeps * R * n
-    # np.random log: one randint per exchange round, one rand per attempted pair
+    # np.random log, nearest neighbour: one randint per exchange round, one rand per attempted
+    # pair.  all_pairs (parallel_tempering.py:222-232): per pair (i < j) one gate draw
+    # (`rand() < 0.1`) and, behind an open gate, the exchange's own draw -- the whole stream is
+    # kept (np_rand_all) and exch_u are the exchange draws in attempt order.
     starts = np.asarray([v for k, v in rec.np_log if k == "randint"], np.int32)
-    us = np.asarray([v for k, v in rec.np_log if k == "rand"], np.float64)
+    all_rand = np.asarray([v for k, v in rec.np_log if k == "rand"], np.float64)
+    if cfg.exchange_method == "all_pairs":
+        us, k = [], 0
+        while k < len(all_rand):
+            if all_rand[k] < 0.1:
+                us.append(all_rand[k + 1])
+                k += 2
+            else:
+                k += 1
+        us = np.asarray(us, np.float64)
+    else:
+        us = all_rand
     assert len(us) == len(exch_log)
     ex = np.asarray(exch_log, np.float64).reshape(-1, 5)
     np.savez_compressed(
@@ -251,12 +265,49 @@ def case_pt(name, J, h, cfg_kwargs, out):
         exch_start=starts, exch_i=ex[:, 0].astype(np.int32), exch_j=ex[:, 1].astype(np.int32),
         exch_Ei=ex[:, 2], exch_Ej=ex[:, 3], exch_accepted=ex[:, 4].astype(np.bool_), exch_u=us,
         exchange_attempts=pt.exchange_attempts, exchange_accepts=pt.exchange_accepts,
+        exchange_method=cfg.exchange_method, np_rand_all=all_rand,
         energy_histories=np.asarray(pt.energy_histories, np.float64),
         best_energy=np.float64(res.best_energy), best_configuration=i8(res.best_configuration),
         acceptance_rates=np.asarray(res.acceptance_rate_history, np.float64),
         s_final=np.stack([i8(r.spins) for r in pt.replicas]))
     print(f"{name}: best={res.best_energy} accepts={pt.exchange_accepts.tolist()} "
           f"attempts={pt.exchange_attempts.tolist()} hist0={pt.energy_histories[0][:4]}")
+
+
+def case_wire_formats(out):
+    """Files WRITTEN BY THE REFERENCE: AnnealingResult.save (annealing/result.py:147-165) and
+    IsingModel.to_dict (core/ising_model.py:213-229), so that the build's readers are pinned to
+    the reference's on-disk format (and its writers to what the reference reads back)."""
+    import json
+    J = pm1_couplings(12, 21)
+    g = torch.Generator().manual_seed(22)
+    h = torch.randint(-2, 3, (12,), generator=g).float()
+    m = dense_model(J, h)
+    ann = GPUAnnealer(GPUAnnealerConfig(n_sweeps=40, initial_temp=3.0, final_temp=0.2, record_interval=4,
+                                        random_seed=5))
+    res = ann.anneal(m)
+    path = os.path.join(out, "wire_result_reference.npz")
+    res.save(path)                       # the reference's own writer
+    back = type(res).load(path)          # and its own reader, as a sanity check of the file
+    assert back.best_energy == res.best_energy
+    d = m.to_dict()                      # {"config": {...}, "spins", "couplings", "external_fields"}
+    assert sorted(d) == ["config", "couplings", "external_fields", "spins"]
+    np.savez_compressed(os.path.join(out, "wire_model_reference.npz"), spins=d["spins"],
+                        couplings=d["couplings"], external_fields=d["external_fields"],
+                        config_json=json.dumps(d["config"], sort_keys=True))
+    # expected values, for the readers' checks
+    np.savez_compressed(os.path.join(out, "wire_expected.npz"), J=J.numpy(), h=h.numpy(),
+                        spins=i8(m.spins), best_energy=np.float64(res.best_energy),
+                        best_configuration=i8(res.best_configuration),
+                        energy_history=np.asarray(res.energy_history, np.float64),
+                        temperature_history=np.asarray(res.temperature_history, np.float64),
+                        acceptance_rate_history=np.asarray(res.acceptance_rate_history, np.float64),
+                        n_sweeps=np.int32(res.n_sweeps), total_time=np.float64(res.total_time),
+                        final_temperature=np.float64(res.final_temperature),
+                        final_acceptance_rate=np.float64(res.final_acceptance_rate),
+                        energy_std=np.float64(res.energy_std), random_seed=np.int64(res.random_seed),
+                        convergence_sweep=np.int64(-1 if res.convergence_sweep is None else res.convergence_sweep))
+    print("wire formats:", sorted(d.keys()), "->", path)
 
 
 def case_operator(name, J, h, T, seed, out):
@@ -454,6 +505,13 @@ def main():
                 dict(n_replicas=4, n_sweeps=120, temp_min=0.5, temp_max=5.0,
                      temp_distribution="linear", exchange_interval=3, record_interval=4,
                      random_seed=7), a.out)
+    if want("pt_allpairs_n16_r5"):
+        case_pt("pt_allpairs_n16_r5", pm1_couplings(16, 2), z(16),
+                dict(n_replicas=5, n_sweeps=90, temp_min=0.5, temp_max=5.0,
+                     exchange_interval=3, record_interval=4, exchange_method="all_pairs",
+                     random_seed=11), a.out)
+    if want("wire"):
+        case_wire_formats(a.out)
     if want("operator_n48"):
         g = torch.Generator().manual_seed(13)
         h = torch.randint(-1, 2, (48,), generator=g).float()

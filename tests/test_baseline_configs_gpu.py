@@ -306,6 +306,63 @@ def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big, monkey
             assert np.array_equal(f, [oracle.local_field(prob, s[0], i) for i in (0, 5, n - 1)])
 
 
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("kind", ["integer", "half_integer_h", "fixed_point", "gaussian"])
+def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
+    """How a CSR row sum is formed is chosen at set time from what is exact: fp32 (+ accept table)
+    for integer problems, fp32 without the table when only h is fractional (BASELINE configs[3]),
+    fp64 in any order when the values' binary exponents span few enough places (TSP distances),
+    the canonical fp64 order otherwise.  Each form, and each slower form forced onto the same
+    problem, gives the oracle's chain bit for bit at 1 to 8 waves per replica."""
+    if big:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    n, R, ns, seed = 1100, 4, 2, 99
+    rng = np.random.RandomState(4)
+    mask = np.triu(rng.rand(n, n) < 0.45, 1)
+    if kind in ("integer", "half_integer_h"):
+        vals = rng.randint(-3, 4, (n, n)).astype(np.float64)
+    elif kind == "fixed_point":
+        vals = np.rint(rng.rand(n, n) * 141.0 * 1024.0) / 1024.0 / 4.0   # distances / 4 on a 2^-12 grid
+    else:
+        vals = rng.randn(n, n)
+    J = (mask * vals).astype(np.float32)
+    J = J + J.T
+    h = rng.randint(-2, 3, n).astype(np.float32) + (0.5 if kind == "half_integer_h" else 0.0)
+    if kind in ("fixed_point", "gaussian"):
+        h = rng.randn(n).astype(np.float32)
+    expect = {"integer": "path=integer-fast", "half_integer_h": "acc=f32-exact",
+              "fixed_point": "acc=f64-exact", "gaussian": "acc=f64-canonical"}[kind]
+    csr = csr_of(J)
+    prob = oracle.Problem(csr=csr, h=h)
+    temps = ladder(R, 40.0, 2.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
+    first = {"integer": 0, "half_integer_h": 1, "fixed_point": 2, "gaussian": 3}[kind]
+    for force in range(first, 4):
+        if force > first:
+            monkeypatch.setenv("SGA_FORCE_CSR_ACC", str(force))
+        for waves in (1, 2, 3, 8):
+            with sg.AnnealEngine(0) as e:
+                e.set_tuning(waves_per_replica=waves)
+                e.set_csr(*csr, h)
+                e.init_replicas(R, seed=seed)
+                d = e.describe()
+                if force == first:
+                    assert expect in d, d
+                if force == 3:
+                    assert "acc=f64-canonical" in d and f"waves_per_replica={4 if waves == 3 else waves} " in d, d
+                e.set_temperatures(temps)
+                e.sweep(ns)                                       # production variant
+                assert np.array_equal(e.spins(), s), d
+                assert np.array_equal(e.stats()[0], ref["n_accepted"]), d
+                e.init_replicas(R, seed=seed)
+                e.set_temperatures(temps)
+                out = e.sweep(ns, trace=True)                     # general (traced) variant
+                assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
+                assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
+    monkeypatch.delenv("SGA_FORCE_CSR_ACC", raising=False)
+
+
 def test_single_site_operators_use_the_canonical_order_dense(sg):
     n = 3000
     rng = np.random.RandomState(12)
@@ -320,9 +377,11 @@ def test_single_site_operators_use_the_canonical_order_dense(sg):
         e.init_replicas(2, seed=5)
         assert np.array_equal(e.local_fields(1, sites), [oracle.local_field(prob, s[1], i) for i in sites])
         for site, u in ((7, 0.3), (2999, 0.9), (7, 0.01)):
+            proposed = 2.0 * float(s[1][site]) * oracle.local_field(prob, s[1], site)
             acc, dE = e.update(1, site, 1.7, u)
             ra, rd = oracle.metropolis_update(prob, s[1], site, 1.7, u)
-            assert (acc, dE) == (ra, rd)
+            # (the engine reports the proposed dE, the oracle 0 for a rejected move)
+            assert acc == ra and dE == proposed and (not ra or rd == proposed)
         assert np.array_equal(e.spins(1), s[1])
 
 

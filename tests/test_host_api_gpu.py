@@ -183,6 +183,68 @@ def test_parallel_tempering_reproduces_reference_run(sg, name):
     assert res.n_sweeps == ns and res.algorithm == "parallel_tempering"
 
 
+def test_parallel_tempering_all_pairs_reproduces_reference_run(sg):
+    """exchange_method="all_pairs" (parallel_tempering.py:222-232): the reference's gate and exchange
+    draws are replayed from the recorded np.random stream; attempts run as one ordered pair list
+    on the engine (sga_exchange_pairs)."""
+    g = load_golden("pt_allpairs_n16_r5")
+    assert str(g["exchange_method"]) == "all_pairs"
+    n, R, ns = g["J"].shape[0], int(g["n_replicas"]), int(g["n_sweeps"])
+    cfg = sg.ParallelTemperingConfig(
+        n_replicas=R, n_sweeps=ns, temp_min=float(g["temp_min"]), temp_max=float(g["temp_max"]),
+        temp_distribution=str(g["temp_distribution"]), exchange_method="all_pairs",
+        exchange_interval=int(g["exchange_interval"]), record_interval=int(g["record_interval"]),
+        random_seed=int(g["random_seed"]))
+    pt = sg.ParallelTempering(cfg)
+    replay = dict(s0=g["s0"], site=g["site"].astype(np.int32).reshape(ns, R, n),
+                  u=np.nan_to_num(g["u"], nan=2.0).astype(np.float32).reshape(ns, R, n),
+                  np_rand_all=g["np_rand_all"])
+    res = pt.run(model_from(sg, g["J"], g["h"]), _replay=replay)
+    assert g["exchange_attempts"].sum() > 0 and g["exchange_accepts"].sum() > 0
+    assert res.best_energy == float(g["best_energy"])
+    assert np.array_equal(res.best_configuration.numpy().astype(np.int8), g["best_configuration"])
+    assert np.array_equal(np.asarray(pt.energy_histories), g["energy_histories"])
+    assert np.array_equal(pt.exchange_attempts, g["exchange_attempts"])
+    assert np.array_equal(pt.exchange_accepts, g["exchange_accepts"])
+    assert np.array_equal(pt.final_spins, g["s_final"])
+    # production mode (Philox uniforms, seeded host gate): runs, is reproducible, conserves the ladder
+    runs = [sg.ParallelTempering(cfg).run(model_from(sg, g["J"], g["h"])) for _ in range(2)]
+    assert runs[0].best_energy == runs[1].best_energy and runs[0].energy_history == runs[1].energy_history
+    with pytest.raises(ValueError):
+        bad = sg.ParallelTemperingConfig(n_replicas=R, n_sweeps=5, exchange_method="ring")
+        sg.ParallelTempering(bad).run(model_from(sg, g["J"], g["h"]))
+
+
+def test_exchange_pairs_equals_oracle(sg):
+    rng = np.random.RandomState(3)
+    R, n = 9, 40
+    J = np.triu(rng.randint(-1, 2, (n, n)), 1).astype(np.float32)
+    J = J + J.T
+    temps = np.geomspace(8.0, 0.3, R)
+    pairs = [(i, j) for i in range(R - 1) for j in range(i + 1, R) if rng.rand() < 0.4]
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, np.zeros(n, np.float32))
+        e.init_replicas(R, seed=5)
+        e.set_ladder(temps)
+        slot = np.arange(R, dtype=np.int32)
+        att, acc = np.zeros(R, np.int64), np.zeros(R, np.int64)
+        for rnd in range(3):
+            e.sweep(2)
+            en = e.energies()
+            u = rng.rand(len(pairs)) if rnd == 1 else None     # recorded uniforms | Philox
+            want = oracle.pt_exchange_pairs(temps, en, slot, pairs, u=u, seed=5, round_=rnd,
+                                            attempts=att, accepts=acc)
+            assert e.exchange_pairs(pairs, u=u) == want
+            assert np.array_equal(e.slot_map(), slot)
+            rep_T = np.empty(R)
+            rep_T[slot] = temps
+            assert np.array_equal(e.temperatures(), rep_T)
+        a2, c2 = e.exchange_stats()
+        assert np.array_equal(a2, att) and np.array_equal(c2, acc) and acc.sum() > 0
+        with pytest.raises(sg.AnnealingError):
+            e.exchange_pairs([(0, R)])
+
+
 def test_parallel_tempering_philox_run_equals_oracle_driver(sg):
     g = load_golden("pt_c1_n64_r8")
     R, ns = 8, 200

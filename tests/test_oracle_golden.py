@@ -215,6 +215,55 @@ def test_pt_replay_matches_reference(name):
     assert np.array_equal(spins[slot_to_rep], g["s_final"])
 
 
+def test_pt_all_pairs_replay_matches_reference():
+    """exchange_method="all_pairs" (parallel_tempering.py:222-232): per pair i < j a gate draw
+    (`rand() < 0.1`) and, behind an open gate, _attempt_single_exchange(i, j)."""
+    g = load_golden("pt_allpairs_n16_r5")
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    n, R, ns = prob.n, int(g["n_replicas"]), int(g["n_sweeps"])
+    temps = g["temperatures"]
+    site = g["site"].astype(np.int32).reshape(ns, R, n)
+    u = np.nan_to_num(g["u"], nan=2.0).reshape(ns, R, n)
+    spins = g["s0"].copy()
+    slot_to_rep = np.arange(R, dtype=np.int32)
+    energy = oracle.energy(prob, spins)
+    attempts, accepts = np.zeros(R - 1, np.int64), np.zeros(R - 1, np.int64)
+    ei, ri = int(g["exchange_interval"]), int(g["record_interval"])
+    hist = [[] for _ in range(R)]
+    stream, cur, n_att = g["np_rand_all"], 0, 0
+    for k in range(ns):
+        inv = np.argsort(slot_to_rep)
+        out = oracle.sweeps(prob, spins, temps[inv], 1, site_mode=oracle.SITE_REPLAY,
+                            replay_site=site[k][inv], replay_u=u[k][inv], energy=energy,
+                            recompute_energy=True)
+        energy = out["energy"]
+        if k % ei == 0 and k > 0:
+            pairs, uu = [], []
+            for i in range(R - 1):
+                for j in range(i + 1, R):
+                    gate = stream[cur]
+                    cur += 1
+                    if gate < 0.1:
+                        pairs.append((i, j))
+                        uu.append(stream[cur])
+                        cur += 1
+            before = accepts.sum()
+            got = oracle.pt_exchange_pairs(temps, energy, slot_to_rep, pairs, u=np.asarray(uu),
+                                           attempts=attempts, accepts=accepts)
+            assert [tuple(p) for p in pairs] == list(zip(g["exch_i"][n_att:n_att + len(pairs)],
+                                                          g["exch_j"][n_att:n_att + len(pairs)]))
+            assert got == accepts.sum() - before == g["exch_accepted"][n_att:n_att + len(pairs)].sum()
+            n_att += len(pairs)
+        if k % ri == 0:
+            for i in range(R):
+                hist[i].append(energy[slot_to_rep[i]])
+    assert cur == len(stream) and n_att == len(g["exch_u"]) > 0
+    assert np.array_equal(attempts, g["exchange_attempts"].astype(np.int64))
+    assert np.array_equal(accepts, g["exchange_accepts"].astype(np.int64))
+    assert np.array_equal(np.asarray(hist), g["energy_histories"])
+    assert np.array_equal(spins[slot_to_rep], g["s_final"])
+
+
 # ----------------------------------------------------------------------------- operator API
 def test_operator_fallback_semantics():
     g = load_golden("operator_n48")
