@@ -221,6 +221,9 @@ def main():
                     help="c5 only: TSP size (spins = cities^2; above 400 the spins are held as bits "
                          "in LDS; 1000 = BASELINE configs[4] at full size, 32 GB of CSR, use with "
                          "--replicas 256 = one GPU's share of the 2048)")
+    ap.add_argument("--implicit", action="store_true",
+                    help="c5 only: run the TSP-structured couplings without storing them (sga_set_tsp): a "
+                         "different byte model (two distance rows per attempt), reported beside the CSR figure")
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU (0 = workload default)")
     ap.add_argument("--storage", default="f32", choices=["f32", "i8", "t2"])
     ap.add_argument("--exchange-interval", type=int, default=10)
@@ -283,7 +286,7 @@ def main():
             xy = rs.rand(a.cities, 2) * 100.0
             dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
             bld = None
-            tsp = enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
+            tsp = None if a.implicit else enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
             n_ladders, t_hot, t_cold = 32, 200.0, 2.0
             label = f"C5: {a.cities}-city TSP QUBO ({a.cities ** 2} spins)"
         n = bld.n if bld is not None else a.cities ** 2
@@ -303,6 +306,10 @@ def main():
         csr = bld.to_csr()
         h = torch.from_numpy(bld.fields()).to(dev)
         eng.set_csr(*csr, h)
+    elif a.implicit:  # the couplings are never stored: distances + penalty weights + fields
+        d32, w_city, w_pos, h_np, _ = enc.tsp_structure(dmat, 200.0, 200.0)
+        h = torch.from_numpy(h_np).to(dev)
+        eng.set_tsp(torch.from_numpy(d32).to(dev), w_city, w_pos, h)
     else:  # rows written on the device (int64 extents); host copy only while it is small
         h = tsp[3]
         eng.set_csr(tsp[0], tsp[1], tsp[2], h)
@@ -316,7 +323,8 @@ def main():
     ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
                           slot_temps=ladder, n_ladders=n_ladders, dist=dist, device=comm_dev)
-    autotuned = (not a.no_autotune) and csr is None and a.waves == 0
+    implicit = a.workload == "c5" and a.implicit
+    autotuned = (not a.no_autotune) and csr is None and a.waves == 0 and not implicit
     if autotuned:
         eng.autotune()  # keeps its winner; sweeps per launch stay as set above
     geometry = eng.describe()
@@ -342,11 +350,12 @@ def main():
     if os.environ.get("SGA_BENCH_NOPROBE") is None:
         copy_gbs = measured_copy_bandwidth(dev)
         read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
-    # Let the device settle after the set-up's allocations and frees: short-kernel workloads showed
-    # one 45-75 ms device-side gap within the first steps of about one fresh process in three; with
-    # this pause 22 of 22 runs were clean (profiles/r01_experiments.md).  Untimed set-up.
     torch.cuda.synchronize()
-    time.sleep(float(os.environ.get("SGA_BENCH_SETTLE", "0.3")))
+    # (round 1 paused 0.3 s here to step around a rare 45-75 ms device-side gap on the short-kernel
+    # workloads; the A/B of profiles/r02_experiments.md shows the set-up's frees are not its cause.
+    # The pause is gone: wall_ms_total vs kernel_ms_total below makes any such gap visible.)
+    if os.environ.get("SGA_BENCH_SETTLE"):
+        time.sleep(float(os.environ["SGA_BENCH_SETTLE"]))
     for _ in range(a.warmup):
         step()
     if a.exchange_interval > 0:
@@ -384,7 +393,9 @@ def main():
     elem = {"f32": 4, "i8": 1, "t2": 0.25}[a.storage]
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
-    if csr is None:
+    if implicit:
+        bytes_per_attempt = 8.0 * a.cities + 8.0     # two fp32 distance rows + the field (its own byte model)
+    elif csr is None:
         bytes_per_attempt = float(n * elem)          # one coupling row
     else:
         bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
@@ -400,7 +411,10 @@ def main():
         pmc_tag = "c4_csr"
     elif a.workload == "c5" and (a.cities, R) in ((100, 2048), (1000, 256)):
         pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
-    traffic, traffic_src = pmc_traffic(pmc_tag, "sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
+    kernel_name = "sweep_tsp_kernel" if implicit else ("sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
+    if implicit:
+        pmc_tag = f"c5_{a.cities}_implicit"
+    traffic, traffic_src = pmc_traffic(pmc_tag, kernel_name)
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -414,21 +428,23 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if (a.storage == "f32" or csr is not None) else ("i8" if a.storage == "i8" else "b2"),
+        "dtype": "f32" if (a.storage == "f32" or csr is not None or implicit) else ("i8" if a.storage == "i8" else "b2"),
         "data": "synthetic",
         "ranks_seen": dist.get_world_size() if dist is not None else 1,
         "backend": (dist.get_backend() if dist is not None else None),
         "exchange": {"rounds_timed": pt.gather_calls, "allgather_ms_per_round":
                      (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
                      "bytes_per_rank": 8 * R},
-        "config": {"workload": (f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
+        "config": {"workload": ((label + ", couplings implicit (TSP structure: 2 distance rows per attempt)")
+                                if implicit else f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
                                 (label or f"C3: {n}-spin CSR +-1 Ising") +
                                 f", CSR mean degree {len(csr[1]) / n:.1f}") +
                                f", {R} replicas/GPU, {n_ladders} geometric ladder(s) T {t_hot:g}->"
                                f"{t_cold:g}, random-site Metropolis sweeps, exchange every "
                                f"{a.exchange_interval}",
                    "spins": n, "replicas_per_gpu": R, "replicas_total": Rg,
-                   "coupling_storage": a.storage if csr is None else "csr", "geometry": geometry,
+                   "coupling_storage": "implicit-tsp" if implicit else (a.storage if csr is None else "csr"),
+                   "geometry": geometry,
                    "geometry_autotuned": autotuned,
                    "best_energy_rank0": best_e},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -440,10 +456,17 @@ def main():
                                      "WRITE_SIZE, separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": per_launch_attempts * bytes_per_attempt,
-                     "kernel": "sweep_dense_kernel" if csr is None else "sweep_csr_kernel",
+                     "kernel": kernel_name,
                      "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
+    if implicit:
+        out["roofline"]["bound"] = "hbm"
+        out["roofline"]["note"] = (
+            "different byte model from the graded CSR figure: the couplings are never stored; an attempt reads "
+            f"two {4 * a.cities}-byte rows of the scaled distance table ({8 * a.cities ** 2 / 1e6:.0f} MB, cache "
+            "resident), so the kernel is bound by the per-update chain (reduction, barrier, decision), not by HBM; "
+            "the same chain as the CSR form, bit for bit")
     if csr is not None:
         nbytes = float(len(csr[1])) * 8.0
         out["roofline"]["note"] = (
@@ -518,8 +541,8 @@ def main():
             "value": float(R) * nb * 2 / dtb, "unit_value": "attempts/s", "geometry": eng.describe(),
             "kernel": "sweep_dense_kernel"}
         eng.set_dense(J, h, storage=a.storage)  # back to the headline instance (cpu_baseline replays on it)
-    if csr is not None and csr[0] is None:
-        a.no_cpu_baseline = True  # no host copy of an instance this large
+    if (csr is not None and csr[0] is None) or implicit:
+        a.no_cpu_baseline = True  # no host copy of an instance this large / the CPU port runs on CSR
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(None if J is None else J.cpu().numpy(), n, 42, csr=csr,
                                            h=None if csr is None else h.cpu().numpy(), eng=eng)

@@ -108,6 +108,22 @@ int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, con
 int sga_set_csr64(sga_engine *e, const int64_t *rowptr, const int32_t *colidx, const float *val,
                   const float *h, int n, int64_t nnz);
 
+/* TSP-structured couplings that are never stored (BASELINE configs[4], examples/tsp_example.py
+ * at 1000 cities: 10^6 spins whose CSR is 32 GB).  The problem is the one problems/routing.py:250-328
+ * compiles, spin (c, p) = city c at tour position p, index c * n_cities + p, in the convention of
+ * the build's encoders.tsp_csr:
+ *     J[(c,p),(c,p')] = -city_visit/2     J[(c,p),(c',p)] = -position_fill/2
+ *     J[(c,p),(c',p-1)] = -dist[c'][c]/4  J[(c,p),(c',p+1)] = -dist[c][c']/4   (c' != c, p mod n)
+ * dist: fp32 [n_cities][ld] (host or device; its diagonal is ignored), h: [n_cities^2] fields.
+ * The sweep reads two 4 n_cities-byte distance rows per update instead of a 32 n_cities-byte
+ * coupling row.  Row sums are exact (checked here) and rounded once to fp32, as in the stored
+ * forms, so the chain equals sga_set_csr's on the same couplings bit for bit; sga_describe says
+ * "acc=f64" without "-exact" in the one case where that cannot be guaranteed (distances spanning
+ * more than ~40 binary orders of magnitude).  Single-site flip / update are not available on this
+ * form (SGA_ERR_UNSUPPORTED); local fields are. */
+int sga_set_tsp(sga_engine *e, const float *dist, int64_t ld, int n_cities, float city_visit,
+                float position_fill, const float *h);
+
 /* ---- replicas ------------------------------------------------------------------------- */
 /* R_local replicas live on this engine; they are replicas [replica0, replica0+R_local) of a
  * global set of R_global (R_global == R_local, replica0 == 0 on one GPU).  s0 == NULL draws

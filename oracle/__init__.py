@@ -56,6 +56,8 @@ def lib():
         L.sgo_pt_exchange_round.argtypes = [C.c_int, p, p, p, C.c_int, p, C.c_uint64, C.c_uint32,
                                             C.c_uint32, p, p]
         L.sgo_pt_exchange_round.restype = C.c_int
+        L.sgo_tsp_to_csr.argtypes = [C.c_int, p, C.c_float, C.c_float, p, p, p]
+        L.sgo_tsp_to_csr.restype = C.c_int
         L.sgo_pt_exchange_pairs.argtypes = [C.c_int, p, p, p, p, p, C.c_int, C.c_uint64, C.c_uint32, p, p]
         L.sgo_pt_exchange_pairs.restype = C.c_int
         L.sgo_pt_exchange_operator.argtypes = [C.c_int, C.c_int, p, p, p, p]
@@ -211,6 +213,18 @@ def pt_exchange_round(slot_temps, rep_energy, slot_to_rep, start=-1, u=None, see
     return int(lib().sgo_pt_exchange_round(len(t), _ptr(t), _ptr(e), _ptr(slot_to_rep), int(start),
                                            _ptr(uu), int(seed), int(round_), int(ladder), _ptr(attempts),
                                            _ptr(accepts)))
+
+
+def tsp_to_csr(dist, city_visit, position_fill):
+    """(rowptr int64, colidx int32, val float32) of the TSP-structured couplings, written out."""
+    d = np.ascontiguousarray(dist, np.float32)
+    n = d.shape[0]
+    nnz = 4 * (n - 1) * n * n
+    rowptr, col, val = np.zeros(n * n + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz, np.float32)
+    if lib().sgo_tsp_to_csr(n, _ptr(d), float(city_visit), float(position_fill), _ptr(rowptr), _ptr(col),
+                            _ptr(val)) != 0:
+        raise RuntimeError("sgo_tsp_to_csr: bad arguments")
+    return rowptr, col, val
 
 
 def pt_exchange_pairs(slot_temps, rep_energy, slot_to_rep, pairs, u=None, seed=0, round_=0,

@@ -413,6 +413,52 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
 }
 
 /* ------------------------------------------------------------------------------------
+ * TSP-structured couplings written out as CSR (problems/routing.py:250-328 in the convention of
+ * the build's encoders.tsp_csr): spin (c, p) = c * n + p has the 4 (n - 1) neighbours
+ *   (c, p')      p' != p            -A/2     one position per city
+ *   (c', p)      c' != c            -B/2     one city per position
+ *   (c', p - 1)  c' != c      -d[c'][c]/4    c' precedes c in the tour
+ *   (c', p + 1)  c' != c      -d[c][c']/4    c' follows c
+ * columns ascending within a row.  The checker for the engine's implicit form (sga_set_tsp): the
+ * CSR functions above run on what this writes.
+ * ---------------------------------------------------------------------------------- */
+int sgo_tsp_to_csr(int n, const float *d, float A, float B, int64_t *rowptr, int32_t *colidx, float *val) {
+    if (n < 3 || !d || !rowptr || !colidx || !val) return -1;
+    const int deg = 4 * (n - 1);
+    for (int c = 0; c < n; ++c)
+        for (int p = 0; p < n; ++p) {
+            const int64_t row = (int64_t)c * n + p;
+            int64_t at = row * deg;
+            rowptr[row] = at;
+            int trip[3] = {(p + n - 1) % n, p, (p + 1) % n}, kind[3] = {0, 1, 2};
+            for (int i = 0; i < 3; ++i) /* sort the three positions, carrying what each one is */
+                for (int j = i + 1; j < 3; ++j)
+                    if (trip[j] < trip[i]) {
+                        int t = trip[i]; trip[i] = trip[j]; trip[j] = t;
+                        t = kind[i]; kind[i] = kind[j]; kind[j] = t;
+                    }
+            for (int c2 = 0; c2 < n; ++c2) {
+                if (c2 == c) {
+                    for (int p2 = 0; p2 < n; ++p2)
+                        if (p2 != p) {
+                            colidx[at] = c * n + p2;
+                            val[at++] = -(A / 2.0f);
+                        }
+                } else {
+                    for (int i = 0; i < 3; ++i) {
+                        colidx[at] = c2 * n + trip[i];
+                        val[at++] = kind[i] == 1 ? -(B / 2.0f)
+                                  : kind[i] == 0 ? -(d[(int64_t)c2 * n + c] / 4.0f)
+                                                 : -(d[(int64_t)c * n + c2] / 4.0f);
+                    }
+                }
+            }
+        }
+    rowptr[(int64_t)n * n] = (int64_t)n * n * deg;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * replica exchange
  * ---------------------------------------------------------------------------------- */
 int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_energy,

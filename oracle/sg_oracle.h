@@ -92,6 +92,10 @@ int sgo_pt_exchange_round(int R, const double *slot_temps, const double *rep_ene
                           int32_t *slot_to_rep, int start, const double *u, uint64_t seed,
                           uint32_t round, uint32_t ladder, int64_t *attempts, int64_t *accepts);
 
+/* TSP-structured couplings written out as CSR (the engine's sga_set_tsp never stores them):
+ * rowptr [n*n + 1] int64, colidx / val [4 (n-1) n^2], columns ascending within a row. */
+int sgo_tsp_to_csr(int n, const float *d, float A, float B, int64_t *rowptr, int32_t *colidx, float *val);
+
 /* ordered list of slot pairs, each seeing the swaps before it (exchange_method="all_pairs",
  * parallel_tempering.py:222-258); u NULL = Philox domain 1, block 0x40000000 | k */
 int sgo_pt_exchange_pairs(int R, const double *slot_temps, const double *rep_energy,

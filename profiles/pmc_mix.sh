@@ -18,3 +18,4 @@ for d in (1, 2):
         for (k, c), v in sorted(acc.items()):
             print(k, c, "per launch %.4g" % (sum(v) / len(v)), "launches", len(v))
 PY
+rm -rf gpurun_out/mix_${tag}_1 gpurun_out/mix_${tag}_2  # raw counter CSVs: tens of MB

@@ -30,6 +30,7 @@ SYMBOLS = [
     ("sga_set_dense_batch", _i, [_p, _p, _i64, _p, _i, _i, _i]),
     ("sga_set_csr", _i, [_p, _p, _p, _p, _p, _i, _i64]),
     ("sga_set_csr64", _i, [_p, _p, _p, _p, _p, _i, _i64]),
+    ("sga_set_tsp", _i, [_p, _p, _i64, _i, C.c_float, C.c_float, _p]),
     ("sga_init_replicas", _i, [_p, _i, _i, _i, _u64, _p]),
     ("sga_set_temperatures", _i, [_p, _p]),
     ("sga_set_ladder", _i, [_p, _p, _i]),

@@ -146,6 +146,11 @@ struct sga_engine {
     int2 *cv = nullptr;     // [nnz] interleaved (column, value bits): what the kernels read
     long long nnz = 0;
     float *h = nullptr, *diag = nullptr;
+    // TSP-structured couplings, never stored (sga_set_tsp): scaled distance tables + penalties
+    bool tsp = false, tsp_exact = true;
+    float *nd4 = nullptr, *nd4t = nullptr;
+    sga::TspArgs tsp_args{};
+    int tsp_waves = 0, tsp_passes = 0;
     double *epart = nullptr;  // per-slice energy sums (few replicas)
     size_t epart_bytes = 0;
     int tune_waves = 0, tune_spl = 0;
@@ -197,6 +202,9 @@ struct sga_engine {
         dev_free(cv);
         dev_free(h);
         dev_free(diag);
+        dev_free(nd4);
+        dev_free(nd4t);
+        tsp = false;
         dev_free(epart);
         epart_bytes = 0;
         n = 0;
@@ -294,8 +302,9 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
         }
         a.partial = e->epart;
     }
-    HIPCHK(e->csr ? sga::launch_energy_csr(a, e->stream)
-                  : sga::launch_energy_dense(a, e->want_i8, e->stream));
+    HIPCHK(e->tsp ? sga::launch_energy_tsp(a, e->tsp_args, e->stream)
+           : e->csr ? sga::launch_energy_csr(a, e->stream)
+                    : sga::launch_energy_dense(a, e->want_i8, e->stream));
     HIPCHK(sga::launch_energy_finish(a.partial, a.slices, a.energy, count, e->stream));
     return SGA_OK;
 }
@@ -304,7 +313,7 @@ int recompute_energy_range(sga_engine *e, int r0, int count) {
 // matrices are laid out by n alone (pack_dense, at set time), so a change of geometry never
 // touches them.
 int ensure_packed(sga_engine *e) {
-    if (e->csr) return SGA_OK;
+    if (e->csr || e->tsp) return SGA_OK;
     if (!e->J_packed) return fail(SGA_ERR_INVALID, "no couplings set");
     int W, CPW;
     long long ld;
@@ -448,7 +457,7 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas (call sga_init_replicas)");
     if (best_ms_per_sweep) *best_ms_per_sweep = 0.0;
-    if (e->csr) return SGA_OK;  // CSR forms are chosen from LDS residency (sga_init_replicas)
+    if (e->csr || e->tsp) return SGA_OK;  // CSR forms are chosen from LDS residency (sga_init_replicas)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int n = e->n, R = e->R;
@@ -869,6 +878,99 @@ int sga_set_csr64(sga_engine *e, const int64_t *rowptr, const int32_t *colidx, c
     return set_csr_common(e, rowptr, true, colidx, val, h, n, nnz);
 }
 
+int sga_set_tsp(sga_engine *e, const float *dist, int64_t ld, int n_cities, float city_visit,
+                float position_fill, const float *h) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (!dist || !h || n_cities < 3 || ld < n_cities) return fail(SGA_ERR_INVALID, "bad TSP problem arguments");
+    if (n_cities > 2048) return fail(SGA_ERR_UNSUPPORTED, "more than 2048 cities");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->free_replicas();
+    e->free_problem();
+    const int n = n_cities;
+    const long long N = (long long)n * n;
+    const int waves = (n + 255) / 256, npad = 256 * waves;
+    if (sga::tsp_lds_bytes(n, npad) > 160 * 1024 - 256)
+        return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (too many cities)");
+    // the distances on the host (4 MB at 1000 cities): classification of the arithmetic
+    std::vector<float> dh((size_t)N), hh((size_t)N);
+    HIPCHK(hipMemcpy2D(dh.data(), sizeof(float) * (size_t)n, dist, sizeof(float) * (size_t)ld,
+                       sizeof(float) * (size_t)n, (size_t)n, hipMemcpyDefault));
+    HIPCHK(hipMemcpy(hh.data(), h, sizeof(float) * (size_t)N, hipMemcpyDefault));
+    const float a2 = -(city_visit / 2.0f), b2 = -(position_fill / 2.0f);
+    bool integral = a2 == std::rint(a2) && b2 == std::rint(b2);
+    int e_hi = -10000, e_lo = 10000;
+    auto span = [&](float v) {  // binary exponents of the highest and the lowest set bit
+        if (v == 0.0f || !std::isfinite(v)) return;
+        int ex;
+        const float m = std::frexp(std::fabs(v), &ex);  // v = m 2^ex, m in [0.5, 1)
+        uint32_t mant = (uint32_t)std::ldexp(m, 24);    // 24-bit integer mantissa
+        int low = 0;
+        while (!(mant & 1u)) {
+            mant >>= 1;
+            ++low;
+        }
+        e_hi = std::max(e_hi, ex - 1);
+        e_lo = std::min(e_lo, ex - 24 + low);
+    };
+    span(a2);
+    span(b2);
+    double worst_row = 0.0;
+    for (int c = 0; c < n; ++c) {
+        double row = 0.0;
+        for (int q = 0; q < n; ++q) {
+            if (q == c) continue;
+            const float v1 = dh[(size_t)c * n + q] / 4.0f, v2 = dh[(size_t)q * n + c] / 4.0f;
+            if (!std::isfinite(v1)) return fail(SGA_ERR_INVALID, "distance matrix holds a non-finite value");
+            integral = integral && v1 == std::rint(v1);
+            span(v1);
+            row += std::fabs((double)v1) + std::fabs((double)v2);
+        }
+        worst_row = std::max(worst_row, row);
+    }
+    for (long long i = 0; i < N && integral; ++i) integral = hh[(size_t)i] == std::rint(hh[(size_t)i]);
+    worst_row += (double)(n - 1) * (std::fabs((double)a2) + std::fabs((double)b2));
+    int carry = 0;
+    while ((1ll << carry) < 4ll * n) ++carry;
+    const bool exact32 = integral && worst_row < 16777216.0;
+    e->tsp_exact = exact32 || e_hi < e_lo || (e_hi - e_lo + 1 + carry) <= 52;
+    // site / n by multiply-shift, verified for every site
+    const unsigned int magic = (unsigned int)((0x100000000ull + (unsigned long long)n - 1) / (unsigned long long)n);
+    for (long long sidx = 0; sidx < N; ++sidx)
+        if ((long long)(((unsigned long long)sidx * magic) >> 32) != sidx / n)
+            return fail(SGA_ERR_UNSUPPORTED, "internal: site decomposition does not hold for this size");
+    // tables on the device
+    const float *src = dist;
+    long long ld_src = ld;
+    struct Staged {
+        float *p = nullptr;
+        ~Staged() { dev_free(p); }
+    } staged;
+    if (!is_device_ptr(dist)) {
+        HIPCHK(hipMalloc(&staged.p, sizeof(float) * (size_t)N));
+        HIPCHK(hipMemcpyAsync(staged.p, dh.data(), sizeof(float) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+        src = staged.p;
+        ld_src = n;
+    }
+    HIPCHK(hipMalloc(&e->nd4, sizeof(float) * (size_t)n * npad));
+    HIPCHK(hipMalloc(&e->nd4t, sizeof(float) * (size_t)n * npad));
+    HIPCHK(sga::launch_tsp_tables(src, ld_src, n, npad, e->nd4, e->nd4t, e->stream));
+    HIPCHK(hipMalloc(&e->h, sizeof(float) * (size_t)N));
+    HIPCHK(hipMemcpyAsync(e->h, hh.data(), sizeof(float) * (size_t)N, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->tsp = true;
+    e->csr = false;
+    e->n = (int)N;
+    e->n_models = 1;
+    e->nnz = 4ll * (n - 1) * N;
+    e->consistent_dE = true;  // symmetric with a zero diagonal by construction
+    e->table_m = 0;
+    e->tsp_waves = waves;
+    e->tsp_passes = 1;
+    e->tsp_args = sga::TspArgs{e->nd4, e->nd4t, n, npad, magic, (unsigned int)(4 * npad), a2, b2, exact32 ? 0 : 1};
+    return SGA_OK;
+}
+
 int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
                       const int8_t *s0) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
@@ -887,7 +989,11 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
     e->sweeps_done = 0;
     e->rounds = 0;
     e->attempted = 0;
-    if (!e->csr) {
+    if (e->tsp) {
+        e->sstride = (e->n + 15) / 16 * 16;
+        e->waves = e->tsp_waves;
+        e->cpw = 0;
+    } else if (!e->csr) {
         int rc = ensure_packed(e);  // geometry depends on the replica count
         if (rc != SGA_OK) return rc;
         e->sstride = (int)e->ld;
@@ -1056,7 +1162,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     HIPCHK(hipSetDevice(e->device));
     int rc = ensure_packed(e);
     if (rc != SGA_OK) return rc;
-    if (!e->csr && e->sstride != (int)e->ld)
+    if (!e->csr && !e->tsp && e->sstride != (int)e->ld)
         return fail(SGA_ERR_INVALID, "tuning changed after sga_init_replicas; re-initialise");
 
     const int n = e->n, R = e->R;
@@ -1095,7 +1201,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // sweeps per launch: aim for ~50 ms of estimated work per launch
     int spl = e->tune_spl;
     if (spl <= 0) {
-        const double row_bytes = e->csr ? 264.0 : (double)e->ldj * (e->want_i8 ? 1 : 4);
+        const double row_bytes = e->tsp ? 8.0 * e->tsp_args.npad
+                                 : e->csr ? 264.0 : (double)e->ldj * (e->want_i8 ? 1 : 4);
         const double per_update = std::max(row_bytes * R / 4.0e12, 1.0e-6);
         const double per_sweep = per_update * n;
         spl = (int)std::min<double>(n_sweeps, std::max(1.0, std::floor(0.05 / per_sweep)));
@@ -1167,7 +1274,10 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         const bool lean = !force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
                           e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
         hipError_t le;
-        if (e->csr) {
+        if (e->tsp) {
+            a.table_m = 0;
+            le = sga::launch_sweep_tsp(a, e->tsp_args, e->tsp_waves, e->tsp_passes, st);
+        } else if (e->csr) {
             le = sga::launch_sweep_csr(a, e->waves, st);
         } else if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
             a.J = e->J_bits;
@@ -1240,6 +1350,19 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         std::memcpy(hs.data(), sites, sizeof(int32_t) * hs.size());
     for (int32_t v : hs)
         if (v < 0 || v >= e->n) return fail(SGA_ERR_INVALID, "site index out of range");
+    if (e->tsp) {  // structured couplings: local fields only (flip / update go through sweeps)
+        if (op != 0)
+            return fail(SGA_ERR_UNSUPPORTED, "single-site flip / update are not implemented for sga_set_tsp problems");
+        HIPCHK(e->point_sites.reserve(sizeof(int32_t) * hs.size()));
+        HIPCHK(e->point_out.reserve(sizeof(double) * (size_t)out_count));
+        HIPCHK(hipMemcpyAsync(e->point_sites.ptr, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(sga::launch_fields_tsp(e->tsp_args, e->spins + (long long)r * e->sstride, e->h,
+                                      static_cast<const int32_t *>(e->point_sites.ptr), count,
+                                      static_cast<double *>(e->point_out.ptr), st));
+        HIPCHK(hipMemcpyAsync(out_host, e->point_out.ptr, sizeof(double) * (size_t)out_count, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SGA_OK;
+    }
     // staging in grow-only scratch slots (no allocation / free per call)
     HIPCHK(e->point_sites.reserve(sizeof(int32_t) * hs.size()));
     HIPCHK(e->point_out.reserve(sizeof(double) * (size_t)std::max(out_count, 2)));
@@ -1759,7 +1882,14 @@ int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, in
 int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (!e || !buf || buflen <= 0) return fail(SGA_ERR_INVALID, "bad arguments");
     char tmp[512];
-    if (e->csr)
+    if (e->tsp)
+        std::snprintf(tmp, sizeof(tmp),
+                      "tsp n_cities=%d n=%d R=%d waves_per_replica=%d passes=%d couplings=implicit "
+                      "(2 x %d-byte distance rows per update) acc=%s lds_bytes=%zu",
+                      e->tsp_args.n_cities, e->n, e->R, e->tsp_waves, e->tsp_passes, 4 * e->tsp_args.n_cities,
+                      !e->tsp_args.f64 ? "f32-exact" : (e->tsp_exact ? "f64-exact" : "f64"),
+                      sga::tsp_lds_bytes(e->tsp_args.n_cities, e->tsp_args.npad));
+    else if (e->csr)
         std::snprintf(tmp, sizeof(tmp),
                       "csr n=%d nnz=%lld R=%d waves_per_replica=%d replicas_per_block=%d sstride=%d "
                       "path=%s table_m=%d spins=%s",

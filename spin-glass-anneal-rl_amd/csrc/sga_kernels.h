@@ -65,6 +65,18 @@ struct SweepArgs {
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
+// TSP-structured couplings that are never stored (sweep_tsp.hip): scaled distance tables + penalties
+struct TspArgs {
+    const float *nd4;    // [n_cities][npad]: -d[c][c']/4, zero diagonal, zero padded
+    const float *nd4t;   // [n_cities][npad]: -d[c'][c]/4 as row c
+    int n_cities, npad;  // npad = 256 * waves * passes >= n_cities (LDS column stride in bits, too)
+    unsigned int div_magic;  // site / n_cities == (site * div_magic) >> 32 for every site (host verified)
+    unsigned int row_bytes;  // 4 * npad
+    float a2, b2;        // -A/2 (one position per city), -B/2 (one city per position)
+    int f64;             // 0: integer instance, fp32 accumulation is exact; 1: fp64 accumulation
+};
+size_t tsp_lds_bytes(int n_cities, int npad);
+
 struct EnergyArgs {
     int reps_per_model, replica_base;  // many-model batches, as in SweepArgs
     long long model_stride_j;
@@ -110,6 +122,12 @@ hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStre
 hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned int *planes,
                                long long row_bits, float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
+hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st);
+hipError_t launch_energy_tsp(const EnergyArgs &a, const TspArgs &t, hipStream_t st);
+hipError_t launch_fields_tsp(const TspArgs &t, const int8_t *spins, const float *h, const int32_t *sites,
+                             int count, double *out, hipStream_t st);
+hipError_t launch_tsp_tables(const float *d, long long ldd, int n, int npad, float *nd4, float *nd4t,
+                             hipStream_t st);
 int csr_waves_per_block(int sstride, int table_m);  // replicas per workgroup that fit LDS (0: none)
 bool csr_big_fits(int sstride, int table_m);         // spins as bits: one replica per workgroup
 int csr_bits_waves_per_block(int sstride, int table_m);  // spins as bits, narrow form: replicas per workgroup

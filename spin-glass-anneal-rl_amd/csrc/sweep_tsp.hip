@@ -1,0 +1,364 @@
+// sweep_tsp.hip -- single-spin sweeps on TSP-structured couplings that are never stored
+// (BASELINE configs[4]: examples/tsp_example.py at 1000 cities = 10^6 spins; as CSR the couplings
+// are 32 GB and every update streams a 32 KB row from HBM).
+//
+// The Ising problem is the one problems/routing.py:250-328 compiles (spin (c, p) = city c at tour
+// position p, index c * n + p), in the convention of encoders.tsp_csr:
+//     J[(c,p),(c,p')] = -A/2  (p' != p)          one position per city
+//     J[(c,p),(c',p)] = -B/2  (c' != c)          one city per position
+//     J[(c,p),(c',p-1)] = -d[c'][c]/4,  J[(c,p),(c',p+1)] = -d[c][c']/4   (c' != c, positions mod n)
+// so row (c,p) . s = -A/2 (S_city[c] - s) - B/2 (S_pos[p] - s)
+//                    + sum_c' ( -d[c'][c]/4 s(c',p-1) - d[c][c']/4 s(c',p+1) ),
+// with S_city / S_pos the spin sums of a city's row / a position's column.  Per replica the kernel
+// keeps the spins as bits in LDS, POSITION-major (a position's column of n cities is contiguous:
+// 32 words at n = 1000), and the 2n sums as integers; an update reads two 4-KB rows of the scaled
+// distance table (4 MB at n = 1000: cache resident) instead of a 32-KB coupling row from HBM.
+//
+// Arithmetic: every product is exact in fp32 (a distance times +-1, a penalty times an integer
+// below 2^11).  The engine checks at set time that the fp64 sum of a row is exact as well (all
+// values within 53 binary places of each other, carries included -- true for distances of any
+// realistic range); then row . s rounded to fp32 is THE correctly rounded value, which is also what
+// the CSR kernels and the oracle produce: the chains are bit-identical to the stored-coupling forms.
+// (Integer instances accumulate in fp32.)  One workgroup per replica, W waves; lane l of wave w
+// holds cities 4 (l + 64 (w + W k)) ... + 3 of pass k.
+#include "sweep_common.h"
+
+namespace sga {
+
+constexpr int TSP_MAX_WAVES = 8;
+
+// spins of the replica: int8 city-major in HBM -> bits position-major in LDS, plus the 2n sums
+__device__ inline void tsp_load_spins(const int8_t *src, unsigned int *bits, int *sums, int n, int cw,
+                                      int first, int step) {
+    for (int i = first; i < n * cw; i += step) bits[i] = 0u;
+    for (int i = first; i < 2 * n; i += step) sums[i] = 0;
+    __syncthreads();
+    const int N = n * n;
+    for (int idx = first; idx < N; idx += step) {
+        const int c = idx / n, p = idx - c * n;
+        const int s = src[idx];
+        if (s < 0) atomicOr(&bits[p * cw + (c >> 5)], 1u << (c & 31));
+        atomicAdd(&sums[c], s);       // S_city[c]
+        atomicAdd(&sums[n + p], s);   // S_pos[p]
+    }
+    __syncthreads();
+}
+
+__device__ inline void tsp_store_spins(const unsigned int *bits, int8_t *dst, int n, int cw, int sstride,
+                                       int first, int step) {
+    const int N = n * n;
+    for (int idx = first; idx < sstride; idx += step) {
+        int8_t v = 0;
+        if (idx < N) {
+            const int c = idx / n, p = idx - c * n;
+            v = ((bits[p * cw + (c >> 5)] >> (c & 31)) & 1u) ? (int8_t)-1 : (int8_t)1;
+        }
+        dst[idx] = v;
+    }
+}
+
+// this lane's four cities of pass k against the columns `pm` (previous position) and `pn` (next)
+template <typename acc_t>
+__device__ __forceinline__ void tsp_accumulate(acc_t &acc, const float4 &xprev, const float4 &xnext,
+                                               const unsigned int *bits, int cw, int pm, int pn, int city0) {
+    const unsigned int wp = bits[pm * cw + (city0 >> 5)] >> (city0 & 31);
+    const unsigned int wn = bits[pn * cw + (city0 >> 5)] >> (city0 & 31);
+    auto signed_val = [](float v, unsigned int word, int q) -> float {
+        return __int_as_float(__float_as_int(v) ^ (int)(((word >> q) & 1u) << 31));
+    };
+    acc += (acc_t)signed_val(xprev.x, wp, 0);
+    acc += (acc_t)signed_val(xprev.y, wp, 1);
+    acc += (acc_t)signed_val(xprev.z, wp, 2);
+    acc += (acc_t)signed_val(xprev.w, wp, 3);
+    acc += (acc_t)signed_val(xnext.x, wn, 0);
+    acc += (acc_t)signed_val(xnext.y, wn, 1);
+    acc += (acc_t)signed_val(xnext.z, wn, 2);
+    acc += (acc_t)signed_val(xnext.w, wn, 3);
+}
+
+// NP = passes per wave over a distance row (256 cities per wave and pass); F64 = fp64 accumulation
+template <int NP, bool F64, bool LEAN>
+__global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_kernel(const SweepArgs a, const TspArgs t) {
+    using acc_t = typename std::conditional<F64, double, float>::type;
+    const int rule = a.rule;
+    const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = t.n_cities, cw = t.npad >> 5;
+    unsigned int *bits = reinterpret_cast<unsigned int *>(smem);      // [n positions][cw words]
+    int *sums = reinterpret_cast<int *>(smem + 4ll * n * cw);         // S_city[n], S_pos[n]
+    double *part = reinterpret_cast<double *>(smem + ((4ll * n * cw + 8ll * n + 7) & ~7ll));  // [2][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = (int)(blockDim.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    tsp_load_spins(a.spins + (long long)r * a.sstride, bits, sums, n, cw, tid, (int)blockDim.x);
+
+    double E = a.energy[r], bestE = a.best_energy[r], T = 1.0;
+    unsigned long long nacc = 0;
+    int pp = 0;
+    const unsigned int lane16 = (unsigned int)(lane + 64 * w) * 16u;  // byte offset of this lane's float4 in pass 0
+    const unsigned int pass_bytes = (unsigned int)(64 * W) * 16u;
+
+    struct Slot {
+        float4 prev[NP], next[NP];
+        int site, c, p;
+        float u, h;
+    };
+    auto request = [&](Slot &sl) {
+        // c = site / n by the multiply-shift the host verified for every site
+        sl.c = (int)(((unsigned long long)(unsigned int)sl.site * t.div_magic) >> 32);
+        sl.p = sl.site - sl.c * n;
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(t.nd4t) + (unsigned long long)sl.c * t.row_bytes;
+        const unsigned char *rn = reinterpret_cast<const unsigned char *>(t.nd4) + (unsigned long long)sl.c * t.row_bytes;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            unsigned int off = lane16 + (unsigned int)k * pass_bytes;
+            asm volatile("" : "+v"(off));
+            sl.prev[k] = *reinterpret_cast<const float4 *>(rp + off);
+            sl.next[k] = *reinterpret_cast<const float4 *>(rn + off);
+        }
+        sl.h = a.h[sl.site];
+    };
+
+    PairSource<LEAN> rng;
+    UpdatePair pairP{0, 0, 2.0f, 2.0f};
+    int kP = 0, tP = 0;  // producer cursor
+    const int N = a.n;
+    auto produce = [&](Slot &sl) {
+        const bool second = tP & 1;
+        if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
+        const int sA = pairP.sA, sB = pairP.sB;
+        const float uA = pairP.uA, uB = pairP.uB;
+        sl.site = second ? sB : sA;
+        sl.u = second ? uB : uA;
+        request(sl);
+        if (++tP == N) {
+            tP = 0;
+            ++kP;
+        }
+    };
+
+    auto step = [&](const Slot &sl, long long upd) {
+        const int c = sl.c, p = sl.p;
+        const int pm = p == 0 ? n - 1 : p - 1, pn = p == n - 1 ? 0 : p + 1;
+        acc_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            tsp_accumulate(acc, sl.prev[k], sl.next[k], bits, cw, pm, pn, 4 * (lane + 64 * (w + W * k)));
+        acc_t dist = wave_sum(acc);
+        // what the flip needs, read before any wave can have applied THIS update's flip
+        const int si = ((bits[p * cw + (c >> 5)] >> (c & 31)) & 1u) ? -1 : 1;
+        const int sc = sums[c], sp = sums[n + p];
+        if (W > 1) {
+            acc_t *slot = reinterpret_cast<acc_t *>(part + pp * TSP_MAX_WAVES);
+            if (lane == 0) slot[w] = dist;
+            __syncthreads();
+            acc_t s = slot[0];
+            for (int i = 1; i < W; ++i) s += slot[i];
+            dist = s;
+            pp ^= 1;
+        }
+        // exact products, exact sum (set-time check), one rounding to fp32 (core/ising_model.py:183)
+        const double row = (double)t.a2 * (double)(sc - si) + (double)t.b2 * (double)(sp - si) + (double)dist;
+        const float dot = (float)row;
+        double dE;
+        const bool flip = metropolis_accept(rule, arith, dot, si, sl.h, 0.0f, T, sl.u, dE);
+        if (flip) {
+            E += dE;
+            ++nacc;
+            if (lane == 0) {  // the same absolute values from every wave: idempotent
+                if (si > 0) atomicOr(&bits[p * cw + (c >> 5)], 1u << (c & 31));
+                else atomicAnd(&bits[p * cw + (c >> 5)], ~(1u << (c & 31)));
+                sums[c] = sc - 2 * si;
+                sums[n + p] = sp - 2 * si;
+            }
+        }
+        if constexpr (!LEAN) {
+            if (tid == 0) {
+                if (a.accept_trace) a.accept_trace[(long long)r * a.replay_stride + upd] = flip ? 1 : 0;
+                if (a.dE_trace)
+                    a.dE_trace[(long long)r * a.replay_stride + upd] =
+                        flip ? (rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
+            }
+        }
+    };
+
+    Slot ring[2];
+    produce(ring[0]);
+    const long long total = (long long)a.n_sweeps * N;
+    int k = 0, tt = 0;
+    for (long long g0 = 0; g0 < total; g0 += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (g0 + j >= total) break;  // workgroup-uniform
+            if (tt == 0) T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+            produce(ring[j ^ 1]);  // the row of update g + 1, in flight while update g is reduced
+            step(ring[j], g0 + j);
+            if (++tt == N) {
+                if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+                if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
+                    bestE = E;
+                    __syncthreads();  // every wave has applied the last flip
+                    tsp_store_spins(bits, a.best_spins + (long long)r * a.sstride, n, cw, a.sstride, tid,
+                                    (int)blockDim.x);
+                    __syncthreads();
+                }
+                tt = 0;
+                ++k;
+            }
+        }
+    }
+    __syncthreads();
+    tsp_store_spins(bits, a.spins + (long long)r * a.sstride, n, cw, a.sstride, tid, (int)blockDim.x);
+    if (tid == 0) {
+        a.energy[r] = E;
+        a.best_energy[r] = bestE;
+        a.n_accepted[r] += nacc;
+    }
+}
+
+size_t tsp_lds_bytes(int n_cities, int npad) {
+    return (size_t)(((4ll * n_cities * (npad >> 5) + 8ll * n_cities + 7) & ~7ll) + 2 * TSP_MAX_WAVES * sizeof(double));
+}
+
+template <int NP>
+static hipError_t launch_tsp_np(const SweepArgs &a, const TspArgs &t, int waves, hipStream_t st) {
+    const bool lean = sweep_args_are_lean(a);
+    void (*kern)(const SweepArgs, const TspArgs) =
+        t.f64 ? (lean ? sweep_tsp_kernel<NP, true, true> : sweep_tsp_kernel<NP, true, false>)
+              : (lean ? sweep_tsp_kernel<NP, false, true> : sweep_tsp_kernel<NP, false, false>);
+    const size_t lds = tsp_lds_bytes(t.n_cities, t.npad);
+    hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st) {
+    if (waves < 1 || waves > TSP_MAX_WAVES || 256 * waves * passes != t.npad) return hipErrorInvalidValue;
+    switch (passes) {
+        case 1: return launch_tsp_np<1>(a, t, waves, st);
+        case 2: return launch_tsp_np<2>(a, t, waves, st);
+        case 4: return launch_tsp_np<4>(a, t, waves, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Full energy on the same structure: -1/2 fp32(sum_i mv_i s_i) - fp32(h . s) with mv_i the fp32
+// row sum (core/ising_model.py:149-174).  Grid (replica, slice of cities); 4 waves, one row each.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) energy_tsp_kernel(const EnergyArgs a, const TspArgs t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = t.n_cities, cw = t.npad >> 5;
+    unsigned int *bits = reinterpret_cast<unsigned int *>(smem);
+    int *sums = reinterpret_cast<int *>(smem + 4ll * n * cw);
+    double *red = reinterpret_cast<double *>(smem + ((4ll * n * cw + 8ll * n + 7) & ~7ll));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    tsp_load_spins(a.spins + (long long)r * a.sstride, bits, sums, n, cw, tid, (int)blockDim.x);
+    const int per = (n + a.slices - 1) / a.slices;
+    const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
+    double e_acc = 0.0, h_acc = 0.0;
+    for (int c = c0; c < c1; ++c) {
+        const float *rp = t.nd4t + (long long)c * (t.row_bytes >> 2);
+        const float *rn = t.nd4 + (long long)c * (t.row_bytes >> 2);
+        for (int p = w; p < n; p += 4) {
+            const int pm = p == 0 ? n - 1 : p - 1, pn = p == n - 1 ? 0 : p + 1;
+            double acc = 0.0;
+            for (int city0 = 4 * lane; city0 < t.npad; city0 += 256)
+                tsp_accumulate(acc, *reinterpret_cast<const float4 *>(rp + city0),
+                               *reinterpret_cast<const float4 *>(rn + city0), bits, cw, pm, pn, city0);
+            const double dist = wave_sum(acc);
+            const int si = ((bits[p * cw + (c >> 5)] >> (c & 31)) & 1u) ? -1 : 1;
+            const double row = (double)t.a2 * (double)(sums[c] - si) + (double)t.b2 * (double)(sums[n + p] - si) + dist;
+            const float mv = (float)row;
+            e_acc += (double)mv * (double)si;
+            h_acc += (double)a.h[c * n + p] * (double)si;
+        }
+    }
+    if (lane == 0) {
+        red[w] = e_acc;
+        red[4 + w] = h_acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double e = (red[0] + red[1]) + (red[2] + red[3]);
+        const double hs = (red[4] + red[5]) + (red[6] + red[7]);
+        if (a.slices <= 1) {
+            a.energy[r] = -0.5 * (double)(float)e + (-(double)(float)hs);
+        } else {
+            double *o = a.partial + ((long long)r * a.slices + blockIdx.y) * 2;
+            o[0] = e;
+            o[1] = hs;
+        }
+    }
+}
+
+hipError_t launch_energy_tsp(const EnergyArgs &a, const TspArgs &t, hipStream_t st) {
+    const size_t lds = tsp_lds_bytes(t.n_cities, t.npad);
+    hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(energy_tsp_kernel), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(energy_tsp_kernel, dim3(a.R, a.slices), dim3(256), lds, st, a, t);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Local fields of single sites (IsingModel.get_local_field, core/ising_model.py:176-185) on the
+// structure, spins read from HBM: one wave per requested site.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) fields_tsp_kernel(const TspArgs t, const int8_t *spins, const float *h,
+                                                        const int32_t *sites, double *out) {
+    const int n = t.n_cities, lane = threadIdx.x;
+    const int site = sites[blockIdx.x];
+    const int c = site / n, p = site - c * n;
+    const int pm = p == 0 ? n - 1 : p - 1, pn = p == n - 1 ? 0 : p + 1;
+    const float *rp = t.nd4t + (long long)c * (t.row_bytes >> 2);
+    const float *rn = t.nd4 + (long long)c * (t.row_bytes >> 2);
+    double acc = 0.0;
+    int sc = 0, sp = 0;
+    for (int q = lane; q < n; q += 64) {
+        acc += (double)(rp[q] * (float)spins[q * n + pm]);
+        acc += (double)(rn[q] * (float)spins[q * n + pn]);
+        sc += spins[c * n + q];
+        sp += spins[q * n + p];
+    }
+    const double dist = wave_sum(acc);
+    sc = wave_sum(sc);
+    sp = wave_sum(sp);
+    const int si = spins[site];
+    const double row = (double)t.a2 * (double)(sc - si) + (double)t.b2 * (double)(sp - si) + dist;
+    if (lane == 0) out[blockIdx.x] = (double)(float)row + (double)h[site];
+}
+
+hipError_t launch_fields_tsp(const TspArgs &t, const int8_t *spins, const float *h, const int32_t *sites,
+                             int count, double *out, hipStream_t st) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fields_tsp_kernel, dim3(count), dim3(64), 0, st, t, spins, h, sites, out);
+    return hipGetLastError();
+}
+
+// scaled distance tables: nd4[c][c'] = -d[c][c']/4 and its transpose, rows zero padded to npad,
+// diagonal forced to zero (a city is no neighbour of itself)
+__global__ void tsp_tables_kernel(const float *d, long long ldd, int n, int npad, float *nd4, float *nd4t) {
+    const long long total = (long long)n * npad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / npad), q = (int)(i - (long long)c * npad);
+        float a = 0.0f, b = 0.0f;
+        if (q < n && q != c) {
+            a = -d[(long long)c * ldd + q] / 4.0f;   // exact scaling
+            b = -d[(long long)q * ldd + c] / 4.0f;
+        }
+        nd4[i] = a;
+        nd4t[i] = b;
+    }
+}
+hipError_t launch_tsp_tables(const float *d, long long ldd, int n, int npad, float *nd4, float *nd4t,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(tsp_tables_kernel, dim3(1024), dim3(256), 0, st, d, ldd, n, npad, nd4, nd4t);
+    return hipGetLastError();
+}
+
+}  // namespace sga

@@ -271,6 +271,31 @@ def tsp_csr(distance_matrix, city_visit: float = 100.0, position_fill: float = 1
     return rowptr, colidx, val, h, constant
 
 
+def tsp_structure(distance_matrix, city_visit: float = 100.0, position_fill: float = 100.0,
+                  auto_scale: bool = True):
+    """What `AnnealEngine.set_tsp` needs to run the couplings of `tsp_csr` WITHOUT storing them:
+    (dist float32 [n, n], city_visit, position_fill, h float32 [n^2], constant) -- the penalty
+    weights after the routing.py:237-241 scaling, the fields and the constant exactly as
+    `tsp_csr` computes them (same float64 expressions, rounded to float32 once)."""
+    d = np.asarray(distance_matrix, np.float64)
+    n = d.shape[0]
+    if d.shape != (n, n) or n < 3:
+        raise ValueError("distance_matrix must be square with at least 3 cities")
+    if auto_scale and n > 50:  # routing.py:237-241
+        f = np.sqrt(n / 50.0)
+        city_visit, position_fill = city_visit * f, position_fill * f
+    off = d.copy()
+    np.fill_diagonal(off, 0.0)
+    tour_h = -(off.sum(1) + off.sum(0)) / 4.0
+    card = 2.0 * (city_visit / 4.0 + position_fill / 4.0) * (2.0 - n)
+    h = np.ascontiguousarray(np.broadcast_to((tour_h[:, None] + card), (n, n)).reshape(n * n).astype(np.float32))
+    constant = float(off.sum()) * n / 4.0 + \
+        n * (city_visit / 4.0 + position_fill / 4.0) * (n + (2.0 - n) ** 2)
+    # the couplings tsp_csr stores are float32(-w / 2) and float32(-d / 4): scaling by a power of two
+    # commutes with the rounding, so float32 weights / distances reproduce them exactly
+    return d.astype(np.float32), float(np.float32(city_visit)), float(np.float32(position_fill)), h, constant
+
+
 def scheduling_ising(durations: Sequence[float], n_agents: int, time_horizon: float,
                      time_discretization: int, due_dates: Optional[Sequence[float]] = None,
                      priorities: Optional[Sequence[float]] = None, objective: str = "makespan",

@@ -190,6 +190,31 @@ class AnnealEngine:
         N.check(fn(self._h, rp, ci, vp, hp, int(n), int(nnz)), name)
         self.n, self.R = n, 0
 
+    def set_tsp(self, dist, city_visit: float, position_fill: float, h):
+        """TSP-structured couplings, never stored (see sga_set_tsp): dist [n, n] float32 (numpy or
+        torch), the two penalty weights as the encoder scaled them, and the fields h [n * n]
+        (`encoders.tsp_structure` returns all four)."""
+        if _is_tensor(dist):
+            dt = dist.detach().float()
+            if dt.dim() != 2 or dt.shape[0] != dt.shape[1]:
+                raise AnnealingError("the distance matrix must be square")
+            if dt.stride(1) != 1:
+                dt = dt.contiguous()
+            _producer_done(dt)
+            n, ld, dp, keep = dt.shape[0], dt.stride(0), C.c_void_p(dt.data_ptr()), dt
+        else:
+            da = np.ascontiguousarray(dist, dtype=np.float32)
+            if da.ndim != 2 or da.shape[0] != da.shape[1]:
+                raise AnnealingError("the distance matrix must be square")
+            n, ld, dp, keep = da.shape[0], da.shape[1], da.ctypes.data_as(C.c_void_p), da
+        hp, hk = _buf(h, np.float32, "float32")
+        if (hk.numel() if _is_tensor(hk) else hk.size) != n * n:
+            raise AnnealingError("the fields must have n_cities^2 entries")
+        N.check(self._lib.sga_set_tsp(self._h, dp, int(ld), int(n), float(city_visit), float(position_fill),
+                                      hp), "sga_set_tsp")
+        del keep
+        self.n, self.R, self.n_models = n * n, 0, 1
+
     # ------------------------------------------------------------------ replicas
     def init_replicas(self, R: int, seed: int = 0, s0=None, R_global: Optional[int] = None,
                       replica0: int = 0):

@@ -105,15 +105,18 @@ def test_c4_scheduling_instance_at_1024_replicas_per_gpu(sg):
 
 
 # ----------------------------------------------------------------------------- configs[4]
-def _tsp(n_cities, seed, integer, device="cuda:0"):
-    from spin_glass_anneal_rl_amd import encoders as enc
+def _tsp_distances(n_cities, seed, integer):
     rs = np.random.RandomState(seed)
     xy = rs.rand(n_cities, 2) * 100.0
     d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
-    if integer:  # distances in multiples of 4, integer penalties: every J and h is an integer
-        d = np.rint(d / 4.0) * 4.0
-        return enc.tsp_csr(d, city_visit=200.0, position_fill=200.0, auto_scale=False, device=device)
-    return enc.tsp_csr(d, city_visit=200.0, position_fill=200.0, device=device)
+    # integer: distances in multiples of 4 (and integer penalties: every J and h is an integer)
+    return np.rint(d / 4.0) * 4.0 if integer else d
+
+
+def _tsp(n_cities, seed, integer, device="cuda:0"):
+    from spin_glass_anneal_rl_amd import encoders as enc
+    return enc.tsp_csr(_tsp_distances(n_cities, seed, integer), city_visit=200.0, position_fill=200.0,
+                       auto_scale=not integer, device=device)
 
 
 @pytest.mark.parametrize("integer", [True, False])
@@ -152,6 +155,115 @@ def test_c5_tsp_1000_cities_full_size(sg, integer):
         slots = e.slot_map()
         assert sorted(slots) == list(range(R))
         assert np.array_equal(slots // (R // n_ladders), np.arange(R) // (R // n_ladders))
+        spins_csr = e.spins()
+    # the same problem with the couplings never stored (sga_set_tsp): identical chain
+    from spin_glass_anneal_rl_amd import encoders as enc
+    d32, A, B, h2, _ = enc.tsp_structure(_tsp_distances(1000, 5, integer), 200.0, 200.0,
+                                         auto_scale=not integer)
+    assert np.array_equal(h2, h.cpu().numpy())
+    with sg.AnnealEngine(0) as e:
+        e.set_tsp(d32, A, B, h2)
+        e.init_replicas(R, seed=seed)
+        d = e.describe()
+        assert "couplings=implicit" in d and ("acc=f32-exact" if integer else "acc=f64-exact") in d, d
+        e.set_ladder(temps, n_ladders)
+        assert np.allclose(e.energies(), e0, rtol=1e-6, atol=0)
+        e.sweep(1)
+        assert np.array_equal(e.spins(), spins_csr)
+        assert np.array_equal(e.stats()[0], acc)
+        assert np.allclose(e.energies(), tracked, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n_cities", [3, 5, 40, 130, 300, 600])
+def test_tsp_implicit_form_equals_stored_couplings_and_oracle(sg, n_cities, integer):
+    """sga_set_tsp against sga_set_csr on the couplings encoders.tsp_csr writes, and both against
+    the oracle running on the CSR its own restatement writes (oracle.tsp_to_csr): energies,
+    local fields, every decision and dE of two sweeps, asymmetric distances included."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    if n_cities == 600 and integer:
+        pytest.skip("the 600-city case (3 waves per replica) runs once, on real distances")
+    dist = _tsp_distances(n_cities, 100 + n_cities, integer)
+    if n_cities == 40:
+        dist = dist + (np.rint(np.random.RandomState(1).rand(n_cities, n_cities) * 5) * 4 if integer
+                       else np.random.RandomState(1).rand(n_cities, n_cities))   # asymmetric
+    d32, A, B, h, _ = enc.tsp_structure(dist, 200.0, 120.0, auto_scale=not integer)
+    n, R, ns, seed = n_cities ** 2, 3, (2 if n_cities <= 130 else 1), 31 + n_cities
+    csr = oracle.tsp_to_csr(d32, A, B)
+    rowptr, col, val, h_enc, _ = enc.tsp_csr(dist, 200.0, 120.0, auto_scale=not integer)
+    assert np.array_equal(rowptr.numpy(), csr[0]) and np.array_equal(col.numpy(), csr[1])
+    assert np.array_equal(val.numpy(), csr[2]) and np.array_equal(h_enc.numpy(), h)
+    temps = ladder(R, 150.0, 3.0)
+    prob = oracle.Problem(csr=(csr[0].astype(np.int32), csr[1], csr[2]), h=h)
+    s = oracle.init_spins(n, R, seed)
+    s0 = s.copy()
+    e_ref = np.asarray([oracle.energy(prob, s[r]) for r in range(R)])
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, energy=e_ref.copy(), trace=True, n_threads=R)
+    sites = [0, 1, n_cities, n // 2, n - 1]
+    for form in ("implicit", "csr"):
+        with sg.AnnealEngine(0) as e:
+            if form == "implicit":
+                e.set_tsp(d32, A, B, h)
+            else:
+                e.set_csr(csr[0], csr[1], csr[2], h)
+            e.init_replicas(R, seed=seed)
+            d = e.describe()
+            if form == "implicit":
+                assert f"tsp n_cities={n_cities} " in d and ("acc=f32-exact" if integer else "acc=f64-exact") in d, d
+            if integer:
+                assert np.array_equal(e.energies(), e_ref), d
+            else:
+                assert np.allclose(e.energies(), e_ref, rtol=1e-6, atol=1e-6), d
+            assert np.array_equal(e.local_fields(1, sites), [oracle.local_field(prob, s0[1], i) for i in sites]), d
+            e.set_temperatures(temps)
+            e.sweep(ns)                                   # production variant
+            assert np.array_equal(e.spins(), s), d
+            assert np.array_equal(e.stats()[0], ref["n_accepted"]), d
+            be, bs, br = e.best()
+            assert np.array_equal(bs, ref["best_spins"][br]), d
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            out = e.sweep(ns, trace=True)                 # general (traced) variant
+            assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
+            assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
+            if form == "implicit":
+                with pytest.raises(sg.AnnealingError):
+                    e.flip(0, 1)
+
+
+def test_tsp_implicit_form_checkpoint_ladders_and_errors(sg):
+    from spin_glass_anneal_rl_amd import encoders as enc
+    d32, A, B, h, _ = enc.tsp_structure(_tsp_distances(30, 3, False), 200.0, 200.0)
+    R, n_ladders = 12, 3
+    temps = np.tile(ladder(R // n_ladders, 100.0, 2.0), n_ladders)
+
+    def fresh():
+        e = sg.AnnealEngine(0)
+        e.set_tsp(d32, A, B, h)
+        e.init_replicas(R, seed=4)
+        e.set_ladder(temps, n_ladders)
+        return e
+
+    a = fresh()
+    for _ in range(3):
+        a.sweep(2)
+        a.exchange(count=False)
+    blob = a.export_state()
+    a.sweep(3)
+    b = fresh()
+    b.import_state(blob)
+    b.sweep(3)
+    assert np.array_equal(a.spins(), b.spins()) and np.array_equal(a.energies(), b.energies())
+    tracked = a.energies()
+    a.recompute_energies()
+    assert np.allclose(a.energies(), tracked, rtol=1e-6, atol=1e-6)
+    a.close()
+    b.close()
+    with sg.AnnealEngine(0) as e:
+        with pytest.raises(sg.AnnealingError):
+            e.set_tsp(np.zeros((2, 2), np.float32), 1.0, 1.0, np.zeros(4, np.float32))
+        with pytest.raises(sg.AnnealingError):
+            e.set_tsp(np.zeros((5, 5), np.float32), 1.0, 1.0, np.zeros(7, np.float32))
 
 
 def test_c5_tsp_500_cities_against_the_oracle(sg):

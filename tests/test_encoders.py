@@ -117,3 +117,22 @@ def test_large_instance_assembly_is_fast_and_consistent():
     assert set(np.unique(val)) <= {-50.0, -25.0}               # -lambda/2 per shared group
     m = b.to_model()
     assert m.couplings.is_sparse and m.n_spins == 10000
+
+
+def test_tsp_structure_and_the_oracles_writer_reproduce_tsp_csr():
+    """The implicit TSP form (sga_set_tsp) takes (distances, weights, h) from `tsp_structure`; the
+    oracle restates the couplings as CSR (oracle.tsp_to_csr).  Both equal what `tsp_csr` stores,
+    entry for entry -- asymmetric distances and the routing.py:237-241 weight scaling included."""
+    import oracle
+    from spin_glass_anneal_rl_amd import encoders as enc
+    for n in (3, 4, 7, 60):
+        rs = np.random.RandomState(n)
+        xy = rs.rand(n, 2) * 100
+        d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+        if n == 7:
+            d = d + rs.rand(n, n)
+        rowptr, col, val, h, const = enc.tsp_csr(d, 200.0, 150.0)
+        d32, A, B, h2, const2 = enc.tsp_structure(d, 200.0, 150.0)
+        r2, c2, v2 = oracle.tsp_to_csr(d32, A, B)
+        assert np.array_equal(rowptr.numpy(), r2) and np.array_equal(col.numpy(), c2)
+        assert np.array_equal(val.numpy(), v2) and np.array_equal(h.numpy(), h2) and const == const2
