@@ -473,6 +473,10 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
         dev_free(ben);
         dev_free(acc);
     };
+    struct Guard {  // every exit path, the HIPCHK returns included, releases the saved state
+        decltype(release) &fn;
+        ~Guard() { fn(); }
+    } guard{release};
     hipError_t he = hipMalloc(&spins_c, cb);
     if (he == hipSuccess) he = hipMalloc(&best_c, cb);
     if (he == hipSuccess) he = hipMalloc(&en, sizeof(double) * R);
@@ -502,8 +506,12 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
             dev_free(e->spins);
             dev_free(e->best_spins);
             e->sstride = (int)e->ld;
-            HIPCHK(hipMalloc(&e->spins, (size_t)R * e->sstride));
-            HIPCHK(hipMalloc(&e->best_spins, (size_t)R * e->sstride));
+            hipError_t me = hipMalloc(&e->spins, (size_t)R * e->sstride);
+            if (me == hipSuccess) me = hipMalloc(&e->best_spins, (size_t)R * e->sstride);
+            if (me != hipSuccess) {  // no half-allocated replica set: the engine is back to "no replicas"
+                e->free_replicas();
+                return fail(SGA_ERR_MEMORY, std::string("autotune layout: ") + hipGetErrorString(me));
+            }
         }
         HIPCHK(sga::launch_pad_spins(spins_c, n, e->spins, e->sstride, R, e->stream));
         HIPCHK(sga::launch_pad_spins(best_c, n, e->best_spins, e->sstride, R, e->stream));
@@ -557,9 +565,8 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     // leave with the winner (or the caller's setting if something failed) and the saved state
     e->timing = was_timing;
     e->tune_spl = user_spl;
-    const int final_rc = layout(rc == SGA_OK && best_w >= 0 ? best_w : user_waves);
+    const int final_rc = e->R > 0 ? layout(rc == SGA_OK && best_w >= 0 ? best_w : user_waves) : SGA_ERR_MEMORY;
     HIPCHK(hipStreamSynchronize(e->stream));
-    release();
     if (rc != SGA_OK) return rc;
     if (final_rc != SGA_OK) return final_rc;
     if (best_ms_per_sweep) *best_ms_per_sweep = best;
@@ -1057,9 +1064,9 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             const int wpr = e->tune_waves > 0 ? e->tune_waves : ((long_rows && R_local <= 1024) ? 2 : 1);
             e->waves = std::min(wpr, 8);
         }
-        // real-valued rows are summed in the canonical order of sweep_csr.hip, whose wide builds
-        // exist for 1, 2, 4 and 8 waves per replica
-        if (e->csr_acc == sga::CSR_ACC_F64_CANON) {
+        // the wide builds exist for 1, 2, 4 and 8 waves per replica (slot arithmetic on constants; the
+        // canonical summation order of real-valued rows is defined on that grid)
+        {
             int p2 = 1;
             while (p2 < e->waves) p2 *= 2;
             e->waves = std::min(p2, 8);
@@ -1295,6 +1302,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             (void)hipEventRecord(ev1, st);
             e->events.emplace_back(ev0, ev1);
         }
+        if (le != hipSuccess) (void)hipStreamSynchronize(st);  // staged inputs / scratch slots are reusable again
         HIPCHK(le);
         if (exact_mode) {
             int rc2 = recompute_energy_range(e, 0, R);

@@ -60,6 +60,8 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     constexpr bool CANON = ACC == CSR_ACC_F64_CANON;
     static_assert(!CANON || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
                   "canonical-order wide builds are made per wave count");
+    // (the production wide builds are made per wave count as well: with the slot arithmetic and
+    // the cross-wave sum on constants the 1000-city instance runs 12 % faster)
     // Row extents: the narrow forms (one wave per replica) index entries (a.rowptr, 32 bit); the
     // wide forms address a row by its 64-entry SLOTS (a.rowslot: rows are padded to whole slots,
     // pad entries carry the value 0), so a slot number is wave-uniform: the address arithmetic is
@@ -193,26 +195,31 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         return o;
     };
 
-    // value q of the requested head; the wide forms zero it past the row's end here, not right
-    // behind the load (a select there would put the wait directly behind the load)
-    auto head_val = [&](const Head &hd, int q) -> float {
-        if constexpr (WIDE) return (w + nwc * q) < hd.len ? hd.val[q] : 0.0f;  // wave-uniform test
-        else return hd.val[q];
-    };
-
     double T = 1.0;
     auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
         // read s_i before any wave can have applied THIS update's flip (WIDE: before the barrier)
         const int si = spin_i(site);
         // J[site,:].s over the stored entries; products val * (+-1) are exact
         float dot;
-        if constexpr (FAST) {
-            float acc = term(head_val(hd, 0), hd.col[0]);
+        {
+            // one code path for the four row-sum forms: fp32 | fp64 accumulators, one per virtual wave
+            // of the canonical order (a single one in the exact forms, where the order is free)
+            using acc_t = typename std::conditional<FAST, float, double>::type;
+            constexpr int NVA = !CANON ? 1 : (WIDE ? 8 / (NW > 0 ? NW : 8) : 8);
+            acc_t acc[NVA];
 #pragma unroll
-            for (int q = 1; q < HEAD; ++q) acc += term(head_val(hd, q), hd.col[q]);
-            // longer rows: issue eight entry wave-loads before the first gather so the round trips
-            // overlap instead of serialising (degree ~600 at C4)
+            for (int j = 0; j < NVA; ++j) acc[j] = 0;
             if constexpr (WIDE) {
+                // Every head slot is computed; the values of a slot past the row's end are zeroed by a
+                // wave-uniform select.  Measured against one wave-uniform branch per slot and against a
+                // straight-line block per valid-slot count (same box, profiles/r02_experiments.md): the
+                // branch-free form wins on both graded instances -- C4 49.3 vs 57.8 / 55.4 ms per sweep,
+                // C5 at 1000 cities 1478 vs 1699 / 1597 ms -- because the LDS gathers of all eight
+                // slots stay in flight together.  Virtual wave of slot q: (w + nw q) % 8 -> q % NVA.
+#pragma unroll
+                for (int q = 0; q < HEAD; ++q)
+                    acc[q % NVA] += (acc_t)term((w + nwc * q) < hd.len ? hd.val[q] : 0.0f, hd.col[q]);
+                // rows beyond HEAD slots per wave (degree > 4096 at 8 waves): eight more slots per pass
                 for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
                     float v[TAIL_UNROLL];
@@ -224,9 +231,13 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                         v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
                     }
 #pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += term(v[q], c[q]);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NVA] += (acc_t)term(v[q], c[q]);
                 }
             } else {
+                // one wave: entry q' = 0 is the head, the tail batch t holds q' = 1 + 8 t + q, i.e.
+                // virtual wave (1 + q) % 8 of the canonical order
+                static_assert(WIDE || (TAIL_UNROLL == 8 && HEAD == 1), "virtual wave of a tail entry = (1 + q) % 8");
+                acc[0] += (acc_t)term(hd.val[0], hd.col[0]);
                 for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
                      j0 += stride_lanes * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
@@ -240,97 +251,34 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                         v[q] = __int_as_float(ent.y);
                     }
 #pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += term(v[q], c[q]);
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[(1 + q) % NVA] += (acc_t)term(v[q], c[q]);
                 }
             }
-            dot = wave_sum(acc);
-            if constexpr (WIDE) {
-                float *slot = reinterpret_cast<float *>(part) + pp * CSR_MAX_WIDE;
-                if (lane == 0) slot[w] = dot;
-                __syncthreads();
-                float t = slot[0];
-                for (int i = 1; i < nw; ++i) t += slot[i];
-                dot = t;
-                pp ^= 1;
-            }
-        } else if constexpr (!CANON) {
-            // the fp64 sum of this row's values is exact (set-time scan): any order, one tree
-            double acc = (double)term(head_val(hd, 0), hd.col[0]);
+            if constexpr (!CANON) {
+                // exact sums (set-time classification): any order, one wave reduction
+                acc_t tot = wave_sum(acc[0]);
+                if constexpr (WIDE) {
+                    acc_t *slot = reinterpret_cast<acc_t *>(part + pp * CSR_MAX_WIDE);
+                    if (lane == 0) slot[w] = tot;
+                    __syncthreads();
+                    acc_t t = slot[0];
+                    if constexpr (NW > 0) {
 #pragma unroll
-            for (int q = 1; q < HEAD; ++q) acc += (double)term(head_val(hd, q), hd.col[q]);
-            if constexpr (WIDE) {
-                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const int sq = s0 + w + nwc * q;
-                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
-                        c[q] = ent.x;
-                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
+                        for (int i = 1; i < NW; ++i) t += slot[i];
+                    } else {
+                        for (int i = 1; i < nw; ++i) t += slot[i];
                     }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
+                    tot = t;
+                    pp ^= 1;
                 }
-            } else {
-                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                     j0 += stride_lanes * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const rp_t j = j0 + stride_lanes * q;
-                        const bool in = j < x.end;
-                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-                        c[q] = ent.x;
-                        v[q] = __int_as_float(ent.y);
-                    }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc += (double)term(v[q], c[q]);
-                }
-            }
-            double tot = wave_sum(acc);
-            if constexpr (WIDE) {
-                double *slot = part + pp * CSR_MAX_WIDE;
-                if (lane == 0) slot[w] = tot;
-                __syncthreads();
-                double t = slot[0];
-                for (int i = 1; i < nw; ++i) t += slot[i];
-                tot = t;
-                pp ^= 1;
-            }
-            dot = (float)tot;
-        } else {  // fp64 sum in the canonical order, rounded to fp32 once (core/ising_model.py:183)
-            constexpr int NV = WIDE ? 8 / (NW > 0 ? NW : 8) : 8;  // virtual waves per real wave
-            double acc[NV];
-            if constexpr (WIDE) {
-                // this lane's q'-th entry (q' = 8 t + q) lies in virtual wave w + NW * (q % NV)
-#pragma unroll
-                for (int q = 0; q < HEAD; ++q) {
-                    const double t = (double)term(head_val(hd, q), hd.col[q]);
-                    if (q < NV) acc[q] = t;
-                    else acc[q % NV] += t;
-                }
-                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const int sq = s0 + w + nwc * q;
-                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
-                        c[q] = ent.x;
-                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NV] += (double)term(v[q], c[q]);
-                }
-                // one tree per virtual wave that holds entries; all 8 slots are written
+                dot = (float)tot;  // fp64: rounded to fp32 once (core/ising_model.py:183)
+            } else if constexpr (WIDE) {
+                // canonical order: one tree per virtual wave, all 8 slots written, summed in order
                 double *slot = part + pp * CSR_MAX_WIDE;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    const int v = w + (NW > 0 ? NW : 8) * j;
-                    const double sv = wave_sum(acc[j]);  // (+0 when the row has no slot v)
-                    if (lane == 0) slot[v] = sv;
+                for (int j = 0; j < NVA; ++j) {
+                    const double sv = wave_sum(acc[j]);  // (+0 when the row has no slot of that wave)
+                    if (lane == 0) slot[w + (NW > 0 ? NW : 8) * j] = sv;
                 }
                 __syncthreads();
                 double t = slot[0];
@@ -339,34 +287,13 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 pp ^= 1;
                 dot = (float)t;
             } else {
-                // one wave: entry q' = 0 is the head, the tail batch t holds q' = 1 + 8 t + q
-                static_assert(TAIL_UNROLL == 8 && HEAD == 1, "virtual wave of a tail entry = (1 + q) % 8");
-                acc[0] = (double)term(head_val(hd, 0), hd.col[0]);
-#pragma unroll
-                for (int j = 1; j < NV; ++j) acc[j] = 0.0;
-                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                     j0 += stride_lanes * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const rp_t j = j0 + stride_lanes * q;
-                        const bool in = j < x.end;
-                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-                        c[q] = ent.x;
-                        v[q] = __int_as_float(ent.y);
-                    }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[(1 + q) % NV] += (double)term(v[q], c[q]);
-                }
                 const int len = (int)(x.end - x.beg);
                 double t = wave_sum(acc[0]);
 #pragma unroll
-                for (int j = 1; j < NV; ++j)
+                for (int j = 1; j < NVA; ++j)
                     if (len > 64 * j) t += wave_sum(acc[j]);  // wave-uniform test
                 dot = (float)t;
             }
-        
         }
         double dE;
         bool flip;
@@ -549,27 +476,42 @@ static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
     int acc = a.csr_acc;
     if (acc == CSR_ACC_F32_TABLE && (!lean || a.table_m <= 0)) acc = CSR_ACC_F32;
     void (*kern)(const SweepArgs) = nullptr;
-    switch (acc) {
-        case CSR_ACC_F32_TABLE: kern = sweep_csr_kernel<CSR_ACC_F32_TABLE, true, WIDE, BIG>; break;
-        case CSR_ACC_F32:
-            kern = lean ? sweep_csr_kernel<CSR_ACC_F32, true, WIDE, BIG> : sweep_csr_kernel<CSR_ACC_F32, false, WIDE, BIG>;
-            break;
-        case CSR_ACC_F64:
-            kern = lean ? sweep_csr_kernel<CSR_ACC_F64, true, WIDE, BIG> : sweep_csr_kernel<CSR_ACC_F64, false, WIDE, BIG>;
-            break;
-        default:
-            if constexpr (!WIDE) {
+    if constexpr (!WIDE) {
+        switch (acc) {
+            case CSR_ACC_F32_TABLE: kern = sweep_csr_kernel<CSR_ACC_F32_TABLE, true, false, BIG>; break;
+            case CSR_ACC_F32:
+                kern = lean ? sweep_csr_kernel<CSR_ACC_F32, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F32, false, false, BIG>;
+                break;
+            case CSR_ACC_F64:
+                kern = lean ? sweep_csr_kernel<CSR_ACC_F64, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F64, false, false, BIG>;
+                break;
+            default:
                 kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, false, BIG>
                             : sweep_csr_kernel<CSR_ACC_F64_CANON, false, false, BIG>;
-            } else {  // one build per wave count
-                switch (waves) {
-                    case 1: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 1> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 1>; break;
-                    case 2: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 2> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 2>; break;
-                    case 4: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 4> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 4>; break;
-                    case 8: kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, true, BIG, 8> : sweep_csr_kernel<CSR_ACC_F64_CANON, false, true, BIG, 8>; break;
-                    default: return hipErrorInvalidValue;  // the engine rounds the wave count up to a power of two
-                }
-            }
+        }
+    } else {
+        // wide forms: 1, 2, 4 or 8 waves per replica (the engine rounds up); the production builds and
+        // the canonical-order builds are made per wave count, the other traced builds take it at run time
+#define SGA_WIDE_PICK(ACC_, NW_)                                                                      \
+    (lean ? sweep_csr_kernel<ACC_, true, true, BIG, NW_>                                              \
+          : sweep_csr_kernel<ACC_, false, true, BIG, (ACC_ == CSR_ACC_F64_CANON ? NW_ : 0)>)
+#define SGA_WIDE_NW(ACC_)                                                                             \
+    (waves == 1 ? SGA_WIDE_PICK(ACC_, 1) : waves == 2 ? SGA_WIDE_PICK(ACC_, 2)                        \
+     : waves == 4 ? SGA_WIDE_PICK(ACC_, 4) : SGA_WIDE_PICK(ACC_, 8))
+        if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return hipErrorInvalidValue;
+        switch (acc) {
+            case CSR_ACC_F32_TABLE:
+                kern = waves == 1 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 1>
+                     : waves == 2 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 2>
+                     : waves == 4 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 4>
+                                  : sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 8>;
+                break;
+            case CSR_ACC_F32: kern = SGA_WIDE_NW(CSR_ACC_F32); break;
+            case CSR_ACC_F64: kern = SGA_WIDE_NW(CSR_ACC_F64); break;
+            default: kern = SGA_WIDE_NW(CSR_ACC_F64_CANON); break;
+        }
+#undef SGA_WIDE_NW
+#undef SGA_WIDE_PICK
     }
     {
         hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);

@@ -179,7 +179,7 @@ class AnnealEngine:
     def set_csr(self, rowptr, colidx, val, h):
         """CSR couplings (both triangles).  int64 `rowptr` (numpy / torch) is passed through as
         64-bit extents -- required once nnz >= 2^31 -- anything else is taken as int32."""
-        wide = getattr(rowptr, "dtype", None) in (np.dtype(np.int64), torch.int64)
+        wide = getattr(rowptr, "dtype", None) in ((np.dtype(np.int64),) + ((torch.int64,) if torch is not None else ()))
         rp, k1 = _buf(rowptr, np.int64, "int64") if wide else _buf(rowptr, np.int32, "int32")
         ci, k2 = _buf(colidx, np.int32, "int32")
         vp, k3 = _buf(val, np.float32, "float32")
@@ -310,6 +310,7 @@ class AnnealEngine:
         up, k3 = _buf(u, np.float64, "float64")
         if not count:
             N.check(self._lib.sga_exchange(self._h, ep, stp, up, None), "sga_exchange")
+            self._pending = (k1, k2, k3)  # converted device tensors stay alive while the kernel is queued
             return None
         out = C.c_int(0)
         N.check(self._lib.sga_exchange(self._h, ep, stp, up, C.byref(out)), "sga_exchange")
