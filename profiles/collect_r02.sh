@@ -13,7 +13,8 @@ one() {  # tag, bench args...
     find gpurun_out/prof_${tag}_* -name "*_kernel_trace.csv" -delete &&
     python3 profiles/summarize_rocprof.py --stats gpurun_out/prof_${tag}_stats --fetch gpurun_out/prof_${tag}_fetch \
         --write gpurun_out/prof_${tag}_write --tag r02_${tag} --note "bench.py $*" &&
-    cp profiles/r02_${tag}_* gpurun_out/
+    cp profiles/r02_${tag}_* gpurun_out/ &&
+    rm -rf gpurun_out/prof_${tag}_stats gpurun_out/prof_${tag}_fetch gpurun_out/prof_${tag}_write  # raw CSVs: tens of MB
 }
 for t in "$@"; do
   case $t in

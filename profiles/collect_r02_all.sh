@@ -1,0 +1,13 @@
+#!/bin/bash
+# the round's record: bench lines + rocprofv3 passes of every workload (gpurun; see collect_r02.sh)
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+b() { tag=$1; shift; timeout -k 10 300 python bench.py "$@" > gpurun_out/r02_bench_$tag.json 2> gpurun_out/r02_bench_$tag.err; echo "bench $tag rc=$?"; }
+b c2a_f32
+b c3_csr --workload c3
+b c4_csr --workload c4
+b c5_csr --workload c5
+b c5_1000_csr --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1
+b c5_implicit --workload c5 --implicit
+b c5_1000_implicit --workload c5 --implicit --cities 1000 --replicas 256 --steps 2 --warmup 1
+timeout -k 10 900 bash profiles/collect_r02.sh c4 c5_1000 c3 > gpurun_out/r02_collect_all.log 2>&1; echo "collect rc=$?"

@@ -140,6 +140,10 @@ __device__ __forceinline__ bool metropolis_accept(int rule, int arith, float dot
         const double field = (double)dot + (double)h_site;
         dE = 2.0 * (double)si * field;
         if (dE <= 0.0) return true;
+        // -dE/T below -104 rounds to an fp32 argument below expf_det's underflow bound (-103.97):
+        // the probability is exactly 0 and no uniform in [0, 1) is below it -- same decision without
+        // the fp64 divide and the exp (most uphill proposals of a cold replica)
+        if (dE > T * 104.0) return false;
         const float p = expf_det((float)(-dE / T));
         return u < p;
     }

@@ -257,7 +257,11 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             if constexpr (!CANON) {
                 // exact sums (set-time classification): any order, one wave reduction
                 acc_t tot = wave_sum(acc[0]);
+#ifndef SGA_EXPERIMENT_NO_BARRIER   // (timing experiment only: wrong results)
                 if constexpr (WIDE) {
+#else
+                if constexpr (false) {
+#endif
                     acc_t *slot = reinterpret_cast<acc_t *>(part + pp * CSR_MAX_WIDE);
                     if (lane == 0) slot[w] = tot;
                     __syncthreads();
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             dE = (double)(2.0f * fk);
             if (fk <= 0.0f) flip = true;
             else if (fk <= (float)a.table_m) flip = u < ptab[(int)fk];
-            else flip = u < expf_det((float)(-dE / T));  // beyond the table: evaluate
+            else flip = (dE > T * 104.0) ? false : (u < expf_det((float)(-dE / T)));  // beyond the table (p == 0 past -104)
         } else {
             flip = metropolis_accept(rule, arith, dot, si, x.h, x.d, T, u, dE);
         }

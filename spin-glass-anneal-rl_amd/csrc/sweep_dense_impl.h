@@ -335,8 +335,13 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // one Metropolis update at `site` using the row held in `buf`
     auto step = [&](const vec_t(&buf)[NBUF], int site, float u, float h_site, float d_site,
                     long long upd) {
+#ifdef SGA_EXPERIMENT_ACC64_ANYORDER   // timing experiment: the geometry-dependent order of round 1
+        constexpr bool CANON64 = false;
+#else
+        constexpr bool CANON64 = ACC64;
+#endif
         acc_t tot;
-        if constexpr (ACC64) {
+        if constexpr (CANON64) {
             // CANONICAL ORDER for real-valued J: each 256-element chunk c is summed by itself --
             // lane partial ((e0 + e1) + e2) + e3 from +0, adjacent-pairs tree over the 64 lanes
             // (wave_sum) -- and the chunk sums are added in chunk order c = 0, 1, 2, ...  Which
@@ -396,13 +401,13 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
         if (W > 1) {
             acc_t *part = reinterpret_cast<acc_t *>(part_raw + pp * MAX_WAVES * PART_SLOT_BYTES);
             if (lane == 0) {
-                if constexpr (!ACC64)
+                if constexpr (!CANON64)
                     *reinterpret_cast<acc_t *>(reinterpret_cast<unsigned char *>(part) +
                                                w * PART_SLOT_BYTES) = tot;
                 if (w == owner) sislot[pp] = spin_at(site);
             }
             __syncthreads();
-            if constexpr (ACC64) {  // chunk order; chunks past the row's end hold +0
+            if constexpr (CANON64) {  // chunk order; chunks past the row's end hold +0
                 const double *slot = canon + pp * n_chunks_ld;
                 acc_t s = slot[0];
                 for (int c = 1; c < n_chunks_row; ++c) s += slot[c];
@@ -417,7 +422,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
             si = sislot[pp];
             pp ^= 1;
         } else {
-            if constexpr (ACC64 && CPW == 0) {  // one streaming wave: its own LDS writes, in order
+            if constexpr (CANON64 && CPW == 0) {  // one streaming wave: its own LDS writes, in order
                 acc_t s = canon[0];
                 for (int c = 1; c < n_chunks_row; ++c) s += canon[c];
                 tot = s;
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
             dE = (double)(2.0f * fk);
             if (fk <= 0.0f) acc = true;
             else if (fk <= (float)a.table_m) acc = u < ptab[(int)fk];
-            else acc = u < expf_det((float)(-dE / T));
+            else acc = (dE > T * 104.0) ? false : (u < expf_det((float)(-dE / T)));  // beyond the table (p == 0 past -104)
         } else {
             acc = metropolis_accept(rule, arith, dotf, si, h_site, d_site, T, u, dE);
         }
@@ -599,7 +604,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
                     bool acc;
                     if (fk <= 0.0f) acc = true;
                     else if (fk <= (float)a.table_m) acc = cur.u[m] < ptab[(int)fk];
-                    else acc = cur.u[m] < expf_det((float)(-dE / T));
+                    else acc = (dE > T * 104.0) ? false : (cur.u[m] < expf_det((float)(-dE / T)));  // beyond the table (p == 0 past -104)
                     if (acc) {
                         E += dE;
                         ++nacc;

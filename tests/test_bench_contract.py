@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the committed lines of the last GPU runs
-(profiles/r01_bench_*.json): the keys and types the driver and the judge read."""
+(profiles/r0N_bench_*.json): the keys and types the driver and the judge read."""
 import glob
 import json
 import os
@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_bench_*.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -37,3 +37,13 @@ def test_committed_bench_line_follows_the_contract(path):
 
 def test_there_is_a_headline_line():
     assert any(p.endswith("r01_bench_c2a_f32.json") for p in LINES)
+    assert any(p.endswith("r02_bench_c2a_f32.json") for p in LINES)
+
+
+def test_round2_headline_carries_the_beyond_cache_roofline():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_c2a_f32.json")))
+    b = d["roofline_beyond_cache"]
+    assert b["bound"] == "hbm" and b["coupling_bytes"] >= 16 * 256 * 2 ** 20     # 16 x the 256 MB Infinity Cache
+    assert b["frac"] == pytest.approx(b["achieved"] / b["peak"]) and b["frac"] >= 0.6
+    assert abs(b["traffic"] / b["algorithmic_bytes_per_launch"] - 1.0) < 0.05      # PMC bytes within 5 %
+    assert d["kernel_ms_total"] <= d["wall_ms_total"] and d["ranks_seen"] == 1
