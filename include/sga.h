@@ -72,6 +72,7 @@ typedef struct sga_engine sga_engine;
 #define SGA_RULE_METROPOLIS 0 /* spin_dynamics.py:131-152                                      */
 #define SGA_RULE_GLAUBER 1    /* spin_dynamics.py:154-171: s_i = +1 w.p. 1/(1+exp(-2 f/T))     */
 #define SGA_RULE_HEAT_BATH 2  /* spin_dynamics.py:173-191: same with beta = 1/T formed first   */
+#define SGA_RULE_WOLFF 3      /* spin_dynamics.py:193-255: cluster moves (sga_sweep only)         */
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 int sga_create(int device, sga_engine **out);
@@ -164,6 +165,15 @@ int sga_update(sga_engine *e, int r, int site, double T, float u, int arith, int
  * HEAT_BATH always consume the uniform and require SGA_ARITH_F64; the per-update dE record of
  * HEAT_BATH is minus the energy change, as the reference returns it (spin_dynamics.py:188). */
 int sga_set_update_rule(sga_engine *e, int rule);
+/* SGA_RULE_WOLFF (SpinDynamics._wolff_cluster_dense, core/spin_dynamics.py:210-255; for CSR couplings
+ * the same rule over a row's stored entries): a sweep is n cluster moves from drawn start sites,
+ * always accepted, n_accepted grows by the cluster sizes, the per-update dE record is
+ * compute_energy() after minus before, and energies are evaluated from scratch after every sweep
+ * (spin_dynamics.py:87).  Needs SGA_ARITH_F64 and n <= ~31 000 (spins, cluster bitmap and queue in
+ * LDS); not available for sga_update or sga_set_tsp problems.  One uniform per candidate bond:
+ * Philox (domain 3) or, for the parity tests, the recorded stream given here -- u [R_local][capacity]
+ * fp32, consumed in draw order by the following Wolff sweeps (NULL: back to Philox). */
+int sga_set_wolff_replay(sga_engine *e, const float *u, int64_t capacity);
 
 /* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s */
 int sga_recompute_energies(sga_engine *e);

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libsg_oracle.so")
 
 SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
-RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH = 0, 1, 2
+RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH, RULE_WOLFF = 0, 1, 2, 3
 
 
 def build(force=False):

@@ -325,6 +325,52 @@ static inline upd_t metropolis_core(int n, const float *J, int64_t ld, const int
     return o;
 }
 
+/* ------------------------------------------------------------------------------------
+ * Wolff cluster move: SpinDynamics._wolff_cluster_dense, spin_dynamics.py:210-255 (for CSR input the
+ * same rule over the row's stored entries in storage order).  One uniform per candidate bond, taken
+ * from `u` at *cursor (recorded stream) or from the production Philox stream (domain 3).
+ * Returns the cluster size, or -1 when the recorded stream runs out.
+ * ---------------------------------------------------------------------------------- */
+static int wolff_move(int n, const float *J, int64_t ld, const int32_t *rowptr, const int32_t *colidx,
+                      const float *val, int8_t *s, int start, double T, const float *u, int64_t *cursor,
+                      int64_t u_cap, uint64_t seed, uint32_t replica, uint32_t sweep, uint32_t t,
+                      int32_t *queue, uint8_t *in_cluster) {
+    memset(in_cluster, 0, (size_t)n);
+    int head = 0, tail = 1;
+    int64_t drawn = 0;
+    queue[0] = start;
+    in_cluster[start] = 1;
+    while (head < tail) { /* :222  while queue: current_site = queue.pop(0) */
+        int cur = queue[head++];
+        int8_t sc = s[cur];
+        int32_t beg = J ? 0 : rowptr[cur], end = J ? n : rowptr[cur + 1];
+        for (int32_t k = beg; k < end; ++k) { /* :227  for neighbor in range(n_spins) */
+            int j = J ? k : colidx[k];
+            float c = J ? J[(int64_t)cur * ld + j] : val[k];
+            if (j == cur || in_cluster[j]) continue;                    /* :228 */
+            if (!(c < 0.0f && sc == s[j])) continue;                    /* :235 */
+            /* :237  prob_add = 1.0 - torch.exp(torch.tensor(2.0 * coupling / T))  (fp32 tensor) */
+            float p_add = 1.0f - sgo_expf((float)(2.0 * (double)c / T));
+            float uu;
+            if (u) {
+                if (*cursor >= u_cap) return -1;
+                uu = u[(*cursor)++];
+            } else {
+                uint32_t o[4];
+                stream_block(seed, (uint32_t)(drawn >> 2), sweep, replica, 3u | (t << 2), o);
+                uu = word_to_u(o[drawn & 3]);
+            }
+            ++drawn;
+            if (uu < p_add) { /* :239 */
+                in_cluster[j] = 1;
+                queue[tail++] = j;
+            }
+        }
+    }
+    for (int i = 0; i < tail; ++i) s[queue[i]] = (int8_t)-s[queue[i]]; /* :244-245 */
+    return tail;
+}
+
 int sgo_metropolis_update(int n, const float *J, int64_t ld, const int32_t *rowptr,
                           const int32_t *colidx, const float *val, const float *h, int8_t *s,
                           int site, double T, float u, int arith, int rule, double *dE_out) {
@@ -348,7 +394,7 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
     if (n <= 0 || R <= 0 || n_sweeps < 0 || !spins || !energy || !temps || !h) return -1;
     if (!J && !(rowptr && colidx && val)) return -1;
     if (site_mode == SGO_SITE_REPLAY && !replay_site) return -1;
-    if ((site_mode != SGO_SITE_RANDOM) && !replay_u) return -1;
+    if ((site_mode != SGO_SITE_RANDOM) && !replay_u && rule != SGO_RULE_WOLFF) return -1;
     volatile int err = 0;
     (void)n_threads;
 #ifdef _OPENMP
@@ -360,6 +406,13 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
         int64_t acc = 0;
         int64_t per_rep = (int64_t)n_sweeps * n;
         int64_t ucur = 0;
+        int32_t *wq = 0;
+        uint8_t *wc = 0;
+        if (rule == SGO_RULE_WOLFF) {
+            wq = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+            wc = (uint8_t *)malloc((size_t)n);
+            if (!wq || !wc) { err = 3; free(wq); free(wc); continue; }
+        }
         const float *ru = replay_u ? replay_u + (u_compact ? r * u_capacity : r * per_rep) : 0;
         for (int k = 0; k < n_sweeps; ++k) {
             double T = temps[k * t_sweep_stride + r * t_replica_stride];
@@ -380,6 +433,24 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
                     if (!u_compact) u = ru[idx];
                 }
                 if (site < 0 || site >= n) { err = 1; site = 0; }
+                if (rule == SGO_RULE_WOLFF) {
+                    /* always accepted; delta = compute_energy() after - before (:248-249);
+                     * the uniforms: a flat recorded stream per replica (u_compact layout) | Philox */
+                    double e_before = (dE_trace || !recompute_energy)
+                                          ? sgo_energy(n, J, ld, rowptr, colidx, val, h, s) : 0.0;
+                    int size = wolff_move(n, J, ld, rowptr, colidx, val, s, site, T,
+                                          (replay_u && u_compact) ? ru : 0, &ucur, u_capacity, seed,
+                                          replica0 + (uint32_t)r, sweep0 + (uint32_t)k, (uint32_t)t, wq, wc);
+                    if (size < 0) { err = 2; size = 0; }
+                    acc += size;
+                    if (dE_trace || !recompute_energy) {
+                        double d = sgo_energy(n, J, ld, rowptr, colidx, val, h, s) - e_before;
+                        E += d;
+                        if (dE_trace) dE_trace[r * per_rep + idx] = d;
+                    }
+                    if (accept_trace) accept_trace[r * per_rep + idx] = 1;
+                    continue;
+                }
                 upd_t o;
                 if (site_mode != SGO_SITE_RANDOM && u_compact) {
                     /* consume the recorded uniform only where the reference draws one */
@@ -408,6 +479,8 @@ int sgo_sweeps(int n, const float *J, int64_t ld, const int32_t *rowptr, const i
         }
         energy[r] = E;
         if (n_accepted) n_accepted[r] += acc;
+        free(wq);
+        free(wc);
     }
     return err ? -2 : 0;
 }

@@ -34,6 +34,8 @@ extern "C" {
 #define SGO_RULE_METROPOLIS 0 /* spin_dynamics.py:131-152 */
 #define SGO_RULE_GLAUBER 1    /* spin_dynamics.py:154-171 */
 #define SGO_RULE_HEAT_BATH 2  /* spin_dynamics.py:173-191 */
+#define SGO_RULE_WOLFF 3      /* spin_dynamics.py:193-255: cluster moves; uniforms = one flat recorded
+                               * stream per replica (u_compact layout) or Philox domain 3 */
 
 /* Philox4x32-10 (Salmon et al. 2011); pinned by the Random123 known-answer vectors. */
 void sgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

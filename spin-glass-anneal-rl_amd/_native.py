@@ -16,7 +16,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_MEMORY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 J_AUTO, J_F32, J_I8, J_T2 = 0, 1, 2, 3
 SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
-RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH = 0, 1, 2
+RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH, RULE_WOLFF = 0, 1, 2, 3
 
 # every symbol include/sga.h declares: (name, restype, argtypes)
 _p, _i, _i64, _u64, _u32, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_double
@@ -39,6 +39,7 @@ SYMBOLS = [
     ("sga_flip", _i, [_p, _i, _i, C.POINTER(_d)]),
     ("sga_update", _i, [_p, _i, _i, _d, C.c_float, _i, C.POINTER(_i), C.POINTER(_d)]),
     ("sga_set_update_rule", _i, [_p, _i]),
+    ("sga_set_wolff_replay", _i, [_p, _p, _i64]),
     ("sga_recompute_energies", _i, [_p]),
     ("sga_exchange", _i, [_p, _p, _p, _p, C.POINTER(_i)]),
     ("sga_exchange_pairs", _i, [_p, _p, _p, _p, _i, C.POINTER(_i)]),

@@ -175,6 +175,9 @@ struct sga_engine {
     int32_t *slot_to_rep = nullptr;
     long long *ex_attempts = nullptr, *ex_accepts = nullptr;
     int *d_count = nullptr;
+    float *wolff_u = nullptr;        // recorded uniforms of the Wolff rule [R][wolff_cap] (parity tests)
+    long long *wolff_cursor = nullptr;  // [R]
+    long long wolff_cap = 0;
     int *d_flags = nullptr;  // [16] value / structure scan results of the set_* calls (one per engine)
 
     // staging slots: 0 sched, 1 replay sites, 2 replay u, 3 energy trace, 4 accept trace,
@@ -221,6 +224,9 @@ struct sga_engine {
         dev_free(slot_to_rep);
         dev_free(ex_attempts);
         dev_free(ex_accepts);
+        dev_free(wolff_u);
+        dev_free(wolff_cursor);
+        wolff_cap = 0;
         R = Rg = 0;
         n_ladders = 0;
     }
@@ -1219,7 +1225,16 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // it) is not the energy change, so E += dE would drift from compute_energy().  Then every
     // sweep is its own launch, followed by a from-scratch energy evaluation and the best update
     // (exactly the reference's sequence, core/spin_dynamics.py:87, gpu_annealer.py:151-153).
-    const bool exact_mode = !e->consistent_dE;
+    // (the Wolff rule reports compute_energy() after every sweep as well, spin_dynamics.py:87)
+    const bool wolff = e->rule == SGA_RULE_WOLFF;
+    if (wolff) {
+        if (e->tsp) return fail(SGA_ERR_UNSUPPORTED, "the Wolff rule is not implemented for sga_set_tsp problems");
+        if (sga::wolff_lds_bytes(n) > 160 * 1024 - 256)
+            return fail(SGA_ERR_UNSUPPORTED, "the Wolff rule keeps spins, cluster and queue in LDS: n <= ~31 000");
+        if (site_mode == SGA_SITE_SEQUENTIAL && !replay_u)
+            return fail(SGA_ERR_INVALID, "sequential Wolff sweeps need replay_u (unused values are fine)");
+    }
+    const bool exact_mode = !e->consistent_dE || wolff;
     if (exact_mode) spl = 1;
 
     for (int k0 = 0; k0 < n_sweeps; k0 += spl) {
@@ -1281,7 +1296,10 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         const bool lean = !force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
                           e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
         hipError_t le;
-        if (e->tsp) {
+        if (wolff) {
+            const sga::WolffArgs wa{e->wolff_u, e->wolff_cap, e->wolff_cursor};
+            le = sga::launch_sweep_wolff(a, wa, e->csr, e->want_i8, st);
+        } else if (e->tsp) {
             a.table_m = 0;
             le = sga::launch_sweep_tsp(a, e->tsp_args, e->tsp_waves, e->tsp_passes, st);
         } else if (e->csr) {
@@ -1331,9 +1349,28 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
 
 int sga_set_update_rule(sga_engine *e, int rule) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
-    if (rule < SGA_RULE_METROPOLIS || rule > SGA_RULE_HEAT_BATH)
+    if (rule < SGA_RULE_METROPOLIS || rule > SGA_RULE_WOLFF)
         return fail(SGA_ERR_UNSUPPORTED, "update rule not implemented by the engine");
+    if (rule == SGA_RULE_WOLFF && e->tsp)
+        return fail(SGA_ERR_UNSUPPORTED, "the Wolff rule is not implemented for sga_set_tsp problems");
     e->rule = rule;
+    return SGA_OK;
+}
+
+int sga_set_wolff_replay(sga_engine *e, const float *u, int64_t capacity) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    dev_free(e->wolff_u);
+    dev_free(e->wolff_cursor);
+    e->wolff_cap = 0;
+    if (!u || capacity <= 0) return SGA_OK;
+    HIPCHK(hipMalloc(&e->wolff_u, sizeof(float) * (size_t)e->R * (size_t)capacity));
+    HIPCHK(hipMalloc(&e->wolff_cursor, sizeof(long long) * (size_t)e->R));
+    HIPCHK(hipMemcpy(e->wolff_u, u, sizeof(float) * (size_t)e->R * (size_t)capacity, hipMemcpyDefault));
+    HIPCHK(hipMemset(e->wolff_cursor, 0, sizeof(long long) * (size_t)e->R));
+    e->wolff_cap = capacity;
     return SGA_OK;
 }
 
@@ -1358,6 +1395,8 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         std::memcpy(hs.data(), sites, sizeof(int32_t) * hs.size());
     for (int32_t v : hs)
         if (v < 0 || v >= e->n) return fail(SGA_ERR_INVALID, "site index out of range");
+    if (op == 2 && e->rule == SGA_RULE_WOLFF)
+        return fail(SGA_ERR_UNSUPPORTED, "sga_update applies single-site rules; Wolff moves run through sga_sweep");
     if (e->tsp) {  // structured couplings: local fields only (flip / update go through sweeps)
         if (op != 0)
             return fail(SGA_ERR_UNSUPPORTED, "single-site flip / update are not implemented for sga_set_tsp problems");

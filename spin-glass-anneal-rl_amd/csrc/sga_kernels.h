@@ -77,6 +77,14 @@ struct TspArgs {
 };
 size_t tsp_lds_bytes(int n_cities, int npad);
 
+// Wolff cluster rule (sweep_wolff.hip): recorded uniforms for the parity tests (null: Philox)
+struct WolffArgs {
+    const float *replay_u;   // [R][capacity], consumed in draw order from cursor[r]
+    long long capacity;
+    long long *cursor;       // [R]
+};
+size_t wolff_lds_bytes(int n);
+
 struct EnergyArgs {
     int reps_per_model, replica_base;  // many-model batches, as in SweepArgs
     long long model_stride_j;
@@ -122,6 +130,7 @@ hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStre
 hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned int *planes,
                                long long row_bits, float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
+hipError_t launch_sweep_wolff(const SweepArgs &a, const WolffArgs &wa, bool csr, bool j_is_i8, hipStream_t st);
 hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st);
 hipError_t launch_energy_tsp(const EnergyArgs &a, const TspArgs &t, hipStream_t st);
 hipError_t launch_fields_tsp(const TspArgs &t, const int8_t *spins, const float *h, const int32_t *sites,

@@ -299,6 +299,16 @@ class AnnealEngine:
     def set_update_rule(self, rule: int):
         N.check(self._lib.sga_set_update_rule(self._h, int(rule)), "sga_set_update_rule")
 
+    def set_wolff_replay(self, u):
+        """Recorded uniforms for the Wolff rule's candidate bonds, [R, capacity] float32, consumed in
+        draw order by the following Wolff sweeps (parity tests); None: back to Philox."""
+        if u is None:
+            N.check(self._lib.sga_set_wolff_replay(self._h, None, 0), "sga_set_wolff_replay")
+            return
+        a = np.ascontiguousarray(u, dtype=np.float32).reshape(self.R, -1)
+        N.check(self._lib.sga_set_wolff_replay(self._h, a.ctypes.data_as(C.c_void_p), int(a.shape[1])),
+                "sga_set_wolff_replay")
+
     def recompute_energies(self):
         N.check(self._lib.sga_recompute_energies(self._h), "sga_recompute_energies")
 

@@ -2,8 +2,9 @@
 
 API of the reference's spin_glass_rl/core/spin_dynamics.py:11-429 for the Metropolis rule
 (`sweep`, `single_spin_update`, acceptance statistics, histories).  A sweep is one kernel
-launch (n random-site updates, Philox stream).  Metropolis, Glauber and heat-bath run in the
-kernels; the Wolff cluster rule is not on the accelerated path and raises.
+launch (n random-site updates, Philox stream).  Metropolis, Glauber and heat-bath are modes of
+the sweep kernels; the Wolff cluster rule (reference :193-255) has its own kernel and runs through
+`sweep()` (a sweep = n cluster moves), not through `single_spin_update`.
 """
 from enum import Enum
 from typing import Optional, Tuple
@@ -23,16 +24,13 @@ class UpdateRule(Enum):
 
 
 _RULE_CODE = {UpdateRule.METROPOLIS: N.RULE_METROPOLIS, UpdateRule.GLAUBER: N.RULE_GLAUBER,
-              UpdateRule.HEAT_BATH: N.RULE_HEAT_BATH}
+              UpdateRule.HEAT_BATH: N.RULE_HEAT_BATH, UpdateRule.WOLFF: N.RULE_WOLFF}
 
 
 def rule_code(rule: UpdateRule) -> int:
-    """Engine code of a single-site rule; the Wolff cluster move (reference :193-323) does not
-    fit the one-site kernels and is not provided."""
+    """Engine code of an update rule (sga_set_update_rule)."""
     if rule not in _RULE_CODE:
-        raise AnnealingError(
-            f"update rule '{rule.value}' is not implemented in the HIP engine "
-            "(metropolis, glauber and heat_bath are)")
+        raise AnnealingError(f"update rule '{rule}' is not implemented in the HIP engine")
     return _RULE_CODE[rule]
 
 
@@ -61,7 +59,9 @@ class SpinDynamics:
         return e
 
     def single_spin_update(self, site: Optional[int] = None) -> Tuple[bool, float]:
-        """One Metropolis update; returns (accepted, dE) with dE = 0 on rejection."""
+        """One single-site update; returns (accepted, dE) with dE = 0 on rejection."""
+        if self.update_rule is UpdateRule.WOLFF:
+            raise AnnealingError("Wolff cluster moves run through sweep() on the HIP engine, not one at a time")
         if site is None:
             site = int(self._rng.integers(0, self.model.n_spins))
         u = float(np.float32(self._rng.random(dtype=np.float32)))
@@ -86,8 +86,9 @@ class SpinDynamics:
         e.sweep(1, site_mode=N.SITE_RANDOM)
         self._sweeps += 1
         acc = int(e.stats()[0][0]) - before
-        self.n_accepted += acc
-        self.n_rejected += n - acc
+        self.n_accepted += acc  # Wolff: the sum of the cluster sizes (reference :252)
+        if self.update_rule is not UpdateRule.WOLFF:
+            self.n_rejected += n - acc
         spins = e.spins(0)
         self.model.spins.copy_(self.model.spins.new_tensor(spins.astype(np.float32)))
         self.model._mark_spins_synced()

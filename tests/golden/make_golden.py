@@ -45,6 +45,8 @@ class Recorder:
     def __init__(self):
         self.sites, self.us, self.acc, self.dE = [], [], [], []
         self._pending_u = None
+        self.all_u = []   # every torch.rand(1) draw, in order (the Wolff rule draws many per update)
+        self.cluster = []  # Wolff: cluster size of each update
         self.np_log = []  # ("randint", v) / ("rand", v)
         self._orig = {}
 
@@ -56,6 +58,7 @@ class Recorder:
         self._orig["metro"] = SpinDynamics._metropolis_update
         self._orig["glauber"] = SpinDynamics._glauber_update
         self._orig["heat"] = SpinDynamics._heat_bath_update
+        self._orig["wolff"] = SpinDynamics._wolff_update
         rec = self
 
         def randint(*a, **k):
@@ -68,6 +71,7 @@ class Recorder:
             out = rec._orig["rand"](*a, **k)
             if tuple(out.shape) == (1,):
                 rec._pending_u = float(out.item())
+                rec.all_u.append(rec._pending_u)
             return out
 
         def np_randint(*a, **k):
@@ -92,6 +96,15 @@ class Recorder:
 
         metro = wrap("metro")
 
+        def wolff(self_dyn, site):
+            before = self_dyn.n_accepted
+            accepted, d = rec._orig["wolff"](self_dyn, site)
+            rec.cluster.append(int(self_dyn.n_accepted - before))
+            rec.us.append(np.nan)
+            rec.acc.append(bool(accepted))
+            rec.dE.append(float(d))
+            return accepted, d
+
         torch.randint = randint
         torch.rand = rand
         np.random.randint = np_randint
@@ -99,6 +112,7 @@ class Recorder:
         SpinDynamics._metropolis_update = metro
         SpinDynamics._glauber_update = wrap("glauber")
         SpinDynamics._heat_bath_update = wrap("heat")
+        SpinDynamics._wolff_update = wolff
         return self
 
     def __exit__(self, *exc):
@@ -109,6 +123,7 @@ class Recorder:
         SpinDynamics._metropolis_update = self._orig["metro"]
         SpinDynamics._glauber_update = self._orig["glauber"]
         SpinDynamics._heat_bath_update = self._orig["heat"]
+        SpinDynamics._wolff_update = self._orig["wolff"]
 
     def stream(self):
         assert len(self.sites) == len(self.us) == len(self.acc)
@@ -164,7 +179,9 @@ def case_sweeps(name, J, h, T, n_sweeps, seed, out, rule=UpdateRule.METROPOLIS):
         h=m.external_fields.numpy(), s0=s0, e0=np.float64(e0), T=np.float64(T),
         n_sweeps=np.int32(n_sweeps), sweep_energy=np.asarray(energies, np.float64),
         s_final=i8(m.spins), n_accepted=np.int64(dyn.n_accepted),
-        n_rejected=np.int64(dyn.n_rejected), **st)
+        n_rejected=np.int64(dyn.n_rejected),
+        # Wolff (spin_dynamics.py:193-255): cluster size per update and every torch.rand(1) draw in order
+        cluster=np.asarray(rec.cluster, np.int32), all_u=np.asarray(rec.all_u, np.float32), **st)
     print(f"{name}: updates={len(st['site'])} E0={e0} E_end={energies[-1]} acc={dyn.n_accepted}")
 
 
@@ -487,6 +504,14 @@ def main():
     if want("sweeps_glauber_gauss_n32"):
         case_sweeps("sweeps_glauber_gauss_n32", gaussian_couplings(32, 8), z(32), 0.9, 30, 23,
                     a.out, rule=UpdateRule.GLAUBER)
+    if want("sweeps_wolff_n24"):
+        # mixed-sign couplings: the reference grows clusters over J < 0 bonds between aligned spins
+        g = torch.Generator().manual_seed(31)
+        h = (torch.randint(-1, 2, (24,), generator=g)).float()
+        case_sweeps("sweeps_wolff_n24", pm1_couplings(24, 8), h, 2.5, 6, 33, a.out, rule=UpdateRule.WOLFF)
+    if want("sweeps_wolff_gauss_n20"):
+        case_sweeps("sweeps_wolff_gauss_n20", gaussian_couplings(20, 9), z(20), 1.2, 5, 34, a.out,
+                    rule=UpdateRule.WOLFF)
     if want("sa_default_n64"):
         # defaults: geometric alpha=.95 floors at sweep 135, early stop at sweep 480
         case_sa("sa_default_n64", pm1_couplings(64, 1), z(64), dict(random_seed=42), 123, a.out)

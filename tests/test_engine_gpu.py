@@ -194,6 +194,75 @@ def test_philox_glauber_heatbath_match_oracle(sg, n, R, storage, waves, rule):
         assert np.array_equal(e.stats()[0], ref["n_accepted"])
 
 
+@pytest.mark.parametrize("storage", ["f32", "i8", "csr"])
+@pytest.mark.parametrize("name,exact", [("sweeps_wolff_n24", True), ("sweeps_wolff_gauss_n20", False)])
+def test_reference_wolff_cluster_moves_replayed_on_gpu(sg, name, exact, storage):
+    """UpdateRule.WOLFF (core/spin_dynamics.py:193-255): the reference's start sites and every
+    candidate-bond uniform replayed; cluster sizes (through n_accepted), per-move dE =
+    compute_energy() after - before, per-sweep energies and final spins."""
+    g = load_golden(name)
+    if storage == "i8" and not exact:
+        pytest.skip("int8 storage needs integer couplings")
+    n, ns = g["J"].shape[0], int(g["n_sweeps"])
+    with sg.AnnealEngine(0) as e:
+        if storage == "csr":
+            e.set_csr(*csr_of(g["J"]), g["h"])
+        else:
+            e.set_dense(g["J"], g["h"], storage=storage)
+        e.set_update_rule(sg._native.RULE_WOLFF)
+        e.init_replicas(1, seed=0, s0=g["s0"][None, :])
+        e.set_temperatures([float(g["T"])])
+        e.set_wolff_replay(g["all_u"][None, :])
+        out = e.sweep(ns, site_mode=sg._native.SITE_REPLAY, replay_site=g["site"][None, :],
+                      replay_u=np.zeros((1, ns * n), np.float32), energy_trace=True, trace=True)
+        assert out["accept_trace"].all()
+        assert int(e.stats()[0][0]) == int(g["n_accepted"]) == int(g["cluster"].sum())
+        assert np.array_equal(e.spins(0), g["s_final"])
+        if exact:
+            assert np.array_equal(out["dE_trace"][0], g["dE"])
+            assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+        else:  # Gaussian J: against the reference's fp32 MKL sums the stated tolerance
+            assert np.allclose(out["dE_trace"][0], g["dE"], rtol=1e-5, atol=1e-4)
+            assert np.allclose(out["energy_trace"][:, 0], g["sweep_energy"], rtol=1e-5, atol=1e-4)
+        # single-site updates are not defined for a cluster rule
+        with pytest.raises(sg.AnnealingError):
+            e.update(0, 1, 1.0, 0.5)
+
+
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+@pytest.mark.parametrize("integer", [True, False])
+def test_philox_wolff_sweeps_match_oracle(sg, kind, integer):
+    n, R, ns, seed = 300, 5, 2, 2024
+    rng = np.random.RandomState(6)
+    mask = np.triu(rng.rand(n, n) < 0.05, 1)
+    J = (mask * (rng.randint(-2, 3, (n, n)) if integer else rng.randn(n, n))).astype(np.float32)
+    J = J + J.T
+    h = (rng.randint(-1, 2, n) if integer else rng.randn(n)).astype(np.float32)
+    temps = ladder(R, 6.0, 1.0)
+    prob = oracle.Problem(J=J, h=h) if kind == "dense" else oracle.Problem(csr=csr_of(J), h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, rule=oracle.RULE_WOLFF, seed=seed, recompute_energy=True,
+                        n_threads=R)
+    with sg.AnnealEngine(0) as e:
+        if kind == "dense":
+            e.set_dense(J, h)
+        else:
+            e.set_csr(*csr_of(J), h)
+        e.set_update_rule(sg._native.RULE_WOLFF)
+        e.init_replicas(R, seed=seed)
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"]) and ref["n_accepted"].min() > ns * n
+        if integer:
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        else:
+            assert np.allclose(out["energy_trace"], ref["energy_trace"], rtol=1e-6, atol=1e-5)
+        for r in range(R):
+            be, bs, _ = e.best(r)
+            assert np.isclose(be, ref["best_energy"][r], rtol=1e-6, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["sa_default_n64", "sa_linear_n20"])
 def test_reference_sa_run_replayed_on_gpu(sg, name):
     g = load_golden(name)

@@ -154,8 +154,9 @@ def test_config_validation():
         sg.MultiGPUConfig(gpu_ids=[0], strategy="pipeline")
     with pytest.raises(ValueError):
         sg.MultiGPUConfig(gpu_ids=[0], communication_backend="smoke-signals")
-    with pytest.raises(sg.AnnealingError):
-        sg.SpinDynamics(sg.IsingModel(sg.IsingModelConfig(n_spins=3)), update_rule=sg.UpdateRule.WOLFF)
+    with pytest.raises(sg.AnnealingError):   # Wolff moves are sweeps, not single-site updates
+        sg.SpinDynamics(sg.IsingModel(sg.IsingModelConfig(n_spins=3)),
+                        update_rule=sg.UpdateRule.WOLFF).single_spin_update(0)
 
 
 # ----------------------------------------------------------------------------- model container

@@ -160,6 +160,27 @@ def test_sa_replay_matches_reference(name):
     assert np.array_equal(s[0], g["s_final"])
 
 
+@pytest.mark.parametrize("name,exact", [("sweeps_wolff_n24", True), ("sweeps_wolff_gauss_n20", False)])
+def test_wolff_cluster_moves_replay_matches_reference(name, exact):
+    """UpdateRule.WOLFF (spin_dynamics.py:193-255): start sites and every candidate-bond uniform
+    replayed from the reference's stream; cluster sizes, per-move dE, per-sweep energies, spins."""
+    g = load_golden(name)
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    n, ns = prob.n, int(g["n_sweeps"])
+    s = g["s0"].copy()[None, :]
+    out = oracle.sweeps(prob, s, float(g["T"]), ns, site_mode=oracle.SITE_REPLAY, rule=oracle.RULE_WOLFF,
+                        replay_site=g["site"][None, :], replay_u=g["all_u"][None, :], u_compact=True,
+                        energy=np.asarray([float(g["e0"])]), recompute_energy=True, trace=True)
+    assert out["accept_trace"].all() and int(out["n_accepted"][0]) == int(g["n_accepted"]) == g["cluster"].sum()
+    assert np.array_equal(s[0], g["s_final"])
+    if exact:
+        assert np.array_equal(out["dE_trace"][0], g["dE"])
+        assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+    else:  # Gaussian J: the reference's fp32 MKL sums, stated tolerance
+        assert np.allclose(out["dE_trace"][0], g["dE"], rtol=1e-5, atol=1e-4)
+        assert np.allclose(out["energy_trace"][:, 0], g["sweep_energy"], rtol=1e-5, atol=1e-4)
+
+
 # ----------------------------------------------------------------------------- PT driver
 @pytest.mark.parametrize("name", ["pt_small_n16_r4", "pt_c1_n64_r8"])
 def test_pt_replay_matches_reference(name):
