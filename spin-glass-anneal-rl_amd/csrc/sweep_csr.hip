@@ -257,11 +257,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             if constexpr (!CANON) {
                 // exact sums (set-time classification): any order, one wave reduction
                 acc_t tot = wave_sum(acc[0]);
-#ifndef SGA_EXPERIMENT_NO_BARRIER   // (timing experiment only: wrong results)
                 if constexpr (WIDE) {
-#else
-                if constexpr (false) {
-#endif
                     acc_t *slot = reinterpret_cast<acc_t *>(part + pp * CSR_MAX_WIDE);
                     if (lane == 0) slot[w] = tot;
                     __syncthreads();
@@ -362,8 +358,10 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         // multiple of NH so that every index is a compile-time constant after unrolling).  The
         // extent of a row has to be back before its entries can be requested; vmcnt retires in
         // order, so the gap NB - NH keeps that wait from draining the rows requested in between.
-        // +7 % there; the cache-resident C4 (240 MB) loses 9 % to the same loop and keeps the
-        // pair loop below, as do the traced / replayed variants.
+        // +7 % there.  (A two-update look-ahead -- both rows reduced together, one barrier, the second
+        // row sum corrected by -2 J[B][A] s_A when the first flips -- was built, verified against the
+        // oracle and measured in round 2: 25 % SLOWER at C4, 16 % at C5-1000, with 128 or 256 VGPRs;
+        // see profiles/r02_experiments.md.  The chain, not the barrier, is what an update costs.)
         constexpr int NH = CSR_WIDE_ROWS_AHEAD + 1, NB = 2 * NH;
         struct Pending {
             int site;

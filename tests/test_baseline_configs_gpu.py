@@ -475,6 +475,50 @@ def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
     monkeypatch.delenv("SGA_FORCE_CSR_ACC", raising=False)
 
 
+@pytest.mark.parametrize("kind", ["integer", "fixed_point"])
+@pytest.mark.parametrize("n,dens", [(901, 0.4), (257, 0.9), (4001, 0.05)])
+def test_csr_wide_bit_forms_on_awkward_shapes(sg, kind, n, dens, monkeypatch):
+    """The bit-spin wide builds on shapes the other CSR tests do not hit: odd n (the last Philox pair
+    of a sweep is half used), nearly dense rows (consecutive sites are neighbours most of the time),
+    tiny n (the same site twice in a row ~ once per 257 updates), rows beyond the eight head slots
+    (n = 4001 at one wave).  (Written for a two-update look-ahead form that was measured slower and
+    dropped, profiles/r02_experiments.md; `SGA_NO_LOOK_AHEAD` is a no-op for CSR problems.)"""
+    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    rng = np.random.RandomState(n)
+    mask = np.triu(rng.rand(n, n) < dens, 1)
+    vals = rng.randint(-3, 4, (n, n)).astype(np.float64) if kind == "integer" else \
+        np.rint(rng.rand(n, n) * 141.0 * 1024.0) / 1024.0 / 4.0
+    J = (mask * vals).astype(np.float32)
+    J = J + J.T
+    h = rng.randint(-2, 3, n).astype(np.float32) if kind == "integer" else rng.randn(n).astype(np.float32)
+    csr = csr_of(J)
+    R, ns, seed = 3, 3, 7 + n
+    temps = ladder(R, 30.0, 1.0)
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
+    for waves in (1, 2, 8):
+        got = {}
+        for look in (True, False):
+            if look:
+                monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+            else:
+                monkeypatch.setenv("SGA_NO_LOOK_AHEAD", "1")
+            with sg.AnnealEngine(0) as e:
+                e.set_tuning(waves_per_replica=waves)
+                e.set_csr(*csr, h)
+                e.init_replicas(R, seed=seed)
+                assert "spins=lds-bits" in e.describe() and f"waves_per_replica={waves} " in e.describe()
+                e.set_temperatures(temps)
+                out = e.sweep(ns, energy_trace=True)
+                got[look] = (out["energy_trace"], e.spins(), e.stats()[0])
+                assert np.array_equal(e.spins(), s), (e.describe(), look)
+                assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (e.describe(), look)
+                assert np.array_equal(e.stats()[0], ref["n_accepted"])
+        assert all(np.array_equal(x, y) for x, y in zip(got[True], got[False]))
+    monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+
+
 def test_single_site_operators_use_the_canonical_order_dense(sg):
     n = 3000
     rng = np.random.RandomState(12)
