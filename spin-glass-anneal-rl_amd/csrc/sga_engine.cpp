@@ -127,6 +127,7 @@ struct sga_engine {
     int n_models = 1;  // dense batches: models stacked row-wise, replicas split evenly
     bool csr = false;
     bool want_i8 = false, acc64 = false;
+    bool acc_canon = false;  // acc64 and the fp64 row sum is not provably exact: canonical summation order
     bool use_t2 = false;           // ternary J as two bit-planes for the production sweeps
     unsigned int *J_bits = nullptr;  // [2][n][ld/32]
     float *row_nnz = nullptr;        // [n]
@@ -342,7 +343,7 @@ int ensure_packed(sga_engine *e) {
         choose_geometry(e->n, elems_per_chunk(e->want_i8), std::max(e->R, 1), e->tune_waves, W, CPW);
         ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
         if (e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
-        if (sga::sweep_dense_lds_bytes(ld, e->table_m, e->acc64) > 160 * 1024)
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m, e->acc_canon) > 160 * 1024)
             return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     }
     e->waves = W;
@@ -380,7 +381,7 @@ int pack_dense(sga_engine *e, const float *src, long long ld_src) {
 extern "C" {
 
 const char *sga_last_error(void) { return g_last_error.c_str(); }
-int sga_version(void) { return 100; }
+int sga_version(void) { return 200; }  // round 2: + sga_exchange_pairs, sga_set_tsp, sga_set_wolff_replay, state blob v2
 
 int sga_create(int device, sga_engine **out) {
     if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
@@ -650,8 +651,8 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // symmetric with a zero diagonal (dE of the rule == energy change)?
     int *flags = e->d_flags;  // [0..3] value scans, [4] symmetry / diagonal
     unsigned int *uflags = reinterpret_cast<unsigned int *>(flags) + 2;
-    int hflags[5] = {1, 1, 0, 1, 1};
-    HIPCHK(hipMemsetAsync(flags, 0, 5 * sizeof(int), e->stream));
+    int hflags[7] = {1, 1, 0, 1, 1, 0, 0};
+    HIPCHK(hipMemsetAsync(flags, 0, 7 * sizeof(int), e->stream));
     HIPCHK(sga::launch_scan_values(src, rows, n, ld_src, flags, e->stream));
     HIPCHK(sga::launch_dense_row_abs_max(src, ld_src, e->h, rows, n, uflags, e->stream));
     HIPCHK(sga::launch_check_symmetric(src, ld_src, rows, n, flags + 4, e->stream));
@@ -672,6 +673,18 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // fp32 partial sums are exact (any order) when J is integer valued and no row's sum of
     // |J| reaches 2^24; otherwise the row sum is accumulated in fp64
     e->acc64 = !e->want_i8 && !((nonint & 1u) == 0u && m < 16777216.0f);
+    {
+        // ... and the fp64 sum of a row's (exact) fp32 products is exact in ANY order when the set bits
+        // of all J lie within 53 binary places of each other, the row's carries included; only
+        // couplings of a wider dynamic range (e.g. Gaussian J: tiny values next to large ones) need the
+        // canonical summation order and its one tree per 256-element chunk
+        int carry = 0;
+        while ((1ll << carry) < n) ++carry;
+        const bool any = hflags[5] != 0;
+        const int span = (hflags[5] - 1024) - (1024 - hflags[6]) + 1;
+        e->acc_canon = e->acc64 && any && span + carry > 52;
+        if (std::getenv("SGA_FORCE_DENSE_CANON") != nullptr) e->acc_canon = e->acc64;  // parity tests
+    }
     // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
     if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
     int rc = pack_dense(e, src, ld_src);
@@ -1313,7 +1326,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2,
                                             st);
         } else {
-            le = sga::launch_sweep_dense(a, e->want_i8, e->acc64, e->waves,
+            le = sga::launch_sweep_dense(a, e->want_i8, e->acc64 ? (e->acc_canon ? 2 : 1) : 0, e->waves,
                                          e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
         }
         if (e->timing) {
@@ -1956,7 +1969,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       "dense n=%d models=%d storage=%s acc=%s R=%d waves_per_replica=%d "
                       "chunks_per_wave=%d%s ld=%lld row_bytes=%lld table_m=%d look_ahead=%d",
                       e->n, e->n_models, e->use_t2 ? "t2" : (e->want_i8 ? "i8" : "f32"),
-                      e->want_i8 ? "i32" : (e->acc64 ? "f64" : "f32"), e->R,
+                      e->want_i8 ? "i32" : (e->acc64 ? (e->acc_canon ? "f64-canonical" : "f64-exact") : "f32"), e->R,
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
                       (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
                       e->use_t2 ? t2_row_bits(e->n) / 4 : e->ldj * (e->want_i8 ? 1 : 4), e->table_m,

@@ -119,8 +119,8 @@ struct ExchangeArgs {
 };
 
 // launchers (defined in the .hip files); all return hipGetLastError() after the launch
-hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
-                              hipStream_t st);
+hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, int acc64, int waves, int cpw,
+                              hipStream_t st);  // acc64: 0 fp32 | 1 fp64 any order (exact) | 2 fp64 canonical
 // updates reduced together by the production sweeps of an integer problem with this layout (1 =
 // one at a time): sweep_dense_impl.h, look-ahead form
 int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R);
@@ -153,6 +153,8 @@ hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, in
                                long long ld, bool to_i8, float *diag, hipStream_t st);
 // flags[0] = 1 if some J is not an integer in [-127,127]; flags[1] = 1 if some J is outside
 // {-1, 0, +1} (ternary couplings can be held as two bit-planes)
+// ... flags[5] = 1024 + highest binary exponent of a non-zero value, flags[6] = 1024 - exponent of
+// the lowest set bit (0: no non-zero value): is the fp64 sum of a row exact in any order?
 hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,
                               int *flags, hipStream_t st);
 hipError_t launch_pad_spins(const int8_t *src, int n, int8_t *dst, int sstride, int R,

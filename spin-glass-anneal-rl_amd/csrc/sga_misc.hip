@@ -46,6 +46,7 @@ hipError_t launch_repack_dense(const float *J, long long ldJ, long long rows, in
 __global__ void scan_values_kernel(const float *__restrict__ v, long long rows, long long cols,
                                    long long ld, int *flags) {
     int not_i8 = 0, not_small_int = 0;  // second flag: not ternary
+    int exp_hi = 0, exp_lo = 0;
     const long long total = rows * cols;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -54,9 +55,18 @@ __global__ void scan_values_kernel(const float *__restrict__ v, long long rows, 
         const bool is_int = (x == __builtin_rintf(x));
         if (!is_int || !(__builtin_fabsf(x) <= 127.0f)) not_i8 = 1;
         if (!is_int || !(__builtin_fabsf(x) <= 1.0f)) not_small_int = 1;
+        if (x != 0.0f) {  // binary exponents of the value's highest and lowest set bits
+            const unsigned int bits = __float_as_uint(x);
+            const int ef = (int)((bits >> 23) & 255u);
+            const unsigned int mant = (bits & 0x7FFFFFu) | (ef ? 0x800000u : 0u);
+            exp_hi = max(exp_hi, (ef ? ef - 127 : -127) + 1024);
+            exp_lo = max(exp_lo, 1024 - ((ef ? ef - 127 : -126) - 23 + __builtin_ctz(mant ? mant : 1u)));
+        }
     }
     if (not_i8) atomicOr(&flags[0], 1);
     if (not_small_int) atomicOr(&flags[1], 1);  // some J outside {-1, 0, +1}
+    if (exp_hi) atomicMax(&flags[5], exp_hi);
+    if (exp_lo) atomicMax(&flags[6], exp_lo);
 }
 
 hipError_t launch_scan_values(const float *v, long long rows, long long cols, long long ld,

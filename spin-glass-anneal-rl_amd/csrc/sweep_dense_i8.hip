@@ -6,13 +6,17 @@ hipError_t launch_sweep_dense_i8(const SweepArgs &a, int waves, int cpw, hipStre
 }
 hipError_t launch_sweep_dense_f32(const SweepArgs &, int, int, hipStream_t);
 hipError_t launch_sweep_dense_f32acc64(const SweepArgs &, int, int, hipStream_t);
+hipError_t launch_sweep_dense_f32acc64c(const SweepArgs &, int, int, hipStream_t);
 
-hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, bool acc64, int waves, int cpw,
+// acc64: 0 = fp32 accumulation (exact: integer J), 1 = fp64 in any order (exact: set-time scan),
+// 2 = fp64 in the canonical order
+hipError_t launch_sweep_dense(const SweepArgs &a, bool j_is_i8, int acc64, int waves, int cpw,
                               hipStream_t st) {
     if (waves < 1 || waves > MAX_WAVES || cpw < 0 || cpw > MAX_CPW) return hipErrorInvalidValue;
     if (j_is_i8) return launch_sweep_dense_i8(a, waves, cpw, st);
-    return acc64 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
-                 : launch_sweep_dense_f32(a, waves, cpw, st);
+    return acc64 == 2 ? launch_sweep_dense_f32acc64c(a, waves, cpw, st)
+         : acc64 == 1 ? launch_sweep_dense_f32acc64(a, waves, cpw, st)
+                      : launch_sweep_dense_f32(a, waves, cpw, st);
 }
 int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int R) {
     if (acc64 || cpw < 1) return 1;

@@ -103,7 +103,9 @@ constexpr int dense_max_threads() {
 // SINGLE = built for one wave per replica: the wave count, the owner-wave tests and the partial-sum
 // exchange fold away (small problems run one wave per SIMD and are bound by the length of the
 // instruction stream).
-template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false, bool SINGLE = false>
+// CANON (real-valued fp32 couplings only): the fp64 row sum is formed in the canonical order; without
+// it the engine has proved at set time that the fp64 sum is exact, so that the order is free.
+template <typename JT, int CPW, bool ACC64, bool LEAN, bool BATCH = false, bool SINGLE = false, bool CANON = false>
 __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATCH>())) sweep_dense_kernel(const SweepArgs a) {
     const int rule = a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
@@ -335,11 +337,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // one Metropolis update at `site` using the row held in `buf`
     auto step = [&](const vec_t(&buf)[NBUF], int site, float u, float h_site, float d_site,
                     long long upd) {
-#ifdef SGA_EXPERIMENT_ACC64_ANYORDER   // timing experiment: the geometry-dependent order of round 1
-        constexpr bool CANON64 = false;
-#else
-        constexpr bool CANON64 = ACC64;
-#endif
+        constexpr bool CANON64 = ACC64 && CANON;
         acc_t tot;
         if constexpr (CANON64) {
             // CANONICAL ORDER for real-valued J: each 256-element chunk c is summed by itself --
@@ -724,10 +722,10 @@ constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hi
     return !ACC64 && CPW >= 1 && CPW <= (std::is_same<JT, Tern2>::value ? 4 : 6);
 }
 
-template <typename JT, bool ACC64, int CPW>
+template <typename JT, bool ACC64, int CPW, bool CANON = false>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     constexpr bool BITS = std::is_same<JT, Tern2>::value;
-    const size_t lds = ACC64 ? (size_t)(dense_canon_offset(a.ld, a.table_m) +
+    const size_t lds = CANON ? (size_t)(dense_canon_offset(a.ld, a.table_m) +
                                         dense_canon_bytes(a.ld, 64 * JTraits<JT>::EPL))
                              : (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
                                    sizeof(float) * (size_t)(a.table_m + 1);
@@ -747,11 +745,11 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
             if (!lean || a.rule != SGA_RULE_METROPOLIS) return hipErrorInvalidValue;  // engine: int8 copy
             kern = sweep_dense_kernel<JT, CPW, ACC64, true>;
         } else {
-            kern = lean ? sweep_dense_kernel<JT, CPW, ACC64, true>
-                        : sweep_dense_kernel<JT, CPW, ACC64, false>;
+            kern = lean ? sweep_dense_kernel<JT, CPW, ACC64, true, false, false, CANON>
+                        : sweep_dense_kernel<JT, CPW, ACC64, false, false, false, CANON>;
             // real-valued small problems: the one-wave build of the one-update-at-a-time form
             if constexpr (CPW >= 1 && CPW <= 4) {
-                if (lean && waves == 1) kern = sweep_dense_kernel<JT, CPW, ACC64, true, false, true>;
+                if (lean && waves == 1) kern = sweep_dense_kernel<JT, CPW, ACC64, true, false, true, CANON>;
             }
         }
     }
@@ -763,20 +761,20 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <typename JT, bool ACC64>
+template <typename JT, bool ACC64, bool CANON = false>
 static hipError_t launch_variant(const SweepArgs &a, int waves, int cpw, hipStream_t st) {
     switch (cpw) {
-        case 0: return launch_one<JT, ACC64, 0>(a, waves, st);  // streaming form
-        case 1: return launch_one<JT, ACC64, 1>(a, waves, st);
-        case 2: return launch_one<JT, ACC64, 2>(a, waves, st);
-        case 3: return launch_one<JT, ACC64, 3>(a, waves, st);
-        case 4: return launch_one<JT, ACC64, 4>(a, waves, st);
-        case 5: return launch_one<JT, ACC64, 5>(a, waves, st);
-        case 6: return launch_one<JT, ACC64, 6>(a, waves, st);
-        case 7: return launch_one<JT, ACC64, 7>(a, waves, st);
-        case 8: return launch_one<JT, ACC64, 8>(a, waves, st);
-        case 9: return launch_one<JT, ACC64, 9>(a, waves, st);
-        case 10: return launch_one<JT, ACC64, 10>(a, waves, st);
+        case 0: return launch_one<JT, ACC64, 0, CANON>(a, waves, st);  // streaming form
+        case 1: return launch_one<JT, ACC64, 1, CANON>(a, waves, st);
+        case 2: return launch_one<JT, ACC64, 2, CANON>(a, waves, st);
+        case 3: return launch_one<JT, ACC64, 3, CANON>(a, waves, st);
+        case 4: return launch_one<JT, ACC64, 4, CANON>(a, waves, st);
+        case 5: return launch_one<JT, ACC64, 5, CANON>(a, waves, st);
+        case 6: return launch_one<JT, ACC64, 6, CANON>(a, waves, st);
+        case 7: return launch_one<JT, ACC64, 7, CANON>(a, waves, st);
+        case 8: return launch_one<JT, ACC64, 8, CANON>(a, waves, st);
+        case 9: return launch_one<JT, ACC64, 9, CANON>(a, waves, st);
+        case 10: return launch_one<JT, ACC64, 10, CANON>(a, waves, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -366,7 +366,7 @@ def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
             e.set_dense(J, h)
             e.init_replicas(R, seed=seed)
             d = e.describe()
-            assert "acc=f64" in d and f"waves_per_replica={g} " in d, d
+            assert "acc=f64-canonical" in d and f"waves_per_replica={g} " in d, d
             assert ("(streaming)" in d) == ((n + 255) // 256 > 10 * g), d
             e.set_temperatures(temps)
             for traced in (True, False):   # general and production variants
@@ -379,6 +379,40 @@ def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
                     assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
                 assert np.array_equal(e.spins(), s), d
                 assert np.array_equal(e.stats()[0], ref["n_accepted"])
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced, monkeypatch):
+    """Real-valued couplings whose set bits span few binary places (distances on a 2^-12 grid,
+    weights with a few decimals): the fp64 sum of a row is exact, so the kernels keep one tree per
+    update in whatever order the geometry gives -- and still equal the oracle's canonical sum bit for
+    bit under every geometry.  `forced`: the same problem through the canonical-order build."""
+    if forced:
+        monkeypatch.setenv("SGA_FORCE_DENSE_CANON", "1")
+    n, R, ns, seed = 2600, 3, 2, 404
+    rng = np.random.RandomState(n)
+    J = np.triu(np.rint(rng.rand(n, n) * 141.0 * 1024.0) / 1024.0 / 4.0 * (rng.rand(n, n) < 0.7), 1).astype(np.float32)
+    J = J + J.T
+    h = rng.randn(n).astype(np.float32)
+    temps = ladder(R, 300.0, 30.0)
+    prob = oracle.Problem(J=J, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
+    for g in (1, 3, 4, 11):
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=g)
+            e.set_dense(J, h)
+            e.init_replicas(R, seed=seed)
+            d = e.describe()
+            assert ("acc=f64-canonical" if forced else "acc=f64-exact") in d and f"waves_per_replica={g} " in d, d
+            e.set_temperatures(temps)
+            out = e.sweep(ns, trace=True)
+            assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
+            assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            e.sweep(ns)
+            assert np.array_equal(e.spins(), s), d
 
 
 @pytest.mark.parametrize("big", [False, True])
