@@ -246,6 +246,11 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus)  # before anything here has touched the GPU
+    # stdout carries ONE JSON line and nothing else: whatever libraries print while the process
+    # group comes up (gloo's "[Gloo] Rank 0 is connected to ..." goes to fd 1) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -549,7 +554,8 @@ def main():
     else:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

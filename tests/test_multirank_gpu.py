@@ -45,8 +45,8 @@ def test_bench_gpus_2_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout[:500]      # ONE JSON line and nothing else on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak"
     assert d["backend"] == ("nccl" if two_gpus else "gloo")
