@@ -222,6 +222,10 @@ int sga_get_stats(sga_engine *e, int64_t *accepted /* [R_local] */,
 int sga_get_slot_map(sga_engine *e, int32_t *slot_to_rep /* [R_global] */);
 int sga_get_exchange_stats(sga_engine *e, int64_t *attempts /* [R_global] */,
                            int64_t *accepts /* [R_global] */);
+/* What a tempering host loop reads at an event -- energies [R_local], acceptance counters
+ * [R_local], the ladder permutation [R_global] (any may be NULL) -- with ONE synchronisation
+ * (ParallelTempering._record_statistics / acceptance bookkeeping, parallel_tempering.py:295-301). */
+int sga_snapshot(sga_engine *e, double *energies, int64_t *accepted, int32_t *slot_to_rep);
 /* Philox key of all later draws (sweeps, exchanges); the counters are unchanged. */
 int sga_set_seed(sga_engine *e, uint64_t seed);
 int sga_get_sweep_counter(sga_engine *e, uint32_t *sweeps_done, uint32_t *exchange_rounds);

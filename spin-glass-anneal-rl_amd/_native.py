@@ -53,6 +53,7 @@ SYMBOLS = [
     ("sga_get_stats", _i, [_p, _p, _p]),
     ("sga_get_slot_map", _i, [_p, _p]),
     ("sga_get_exchange_stats", _i, [_p, _p, _p]),
+    ("sga_snapshot", _i, [_p, _p, _p, _p]),
     ("sga_set_seed", _i, [_p, _u64]),
     ("sga_get_sweep_counter", _i, [_p, C.POINTER(_u32), C.POINTER(_u32)]),
     ("sga_set_sweep_counter", _i, [_p, _u32, _u32]),

@@ -141,6 +141,7 @@ struct sga_engine {
     int32_t *rowslot = nullptr;  // slotted layout: row extents in 64-entry slots (wide sweep forms)
     bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
     long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
+    long long max_row_len = 0;     // entries of the longest row
     bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
     int big_form = 0;  // 0 int8 spins | 1 bits, one replica per workgroup, 64-bit extents | 2 bits, narrow
     float *val = nullptr;   // colidx / val: only while the structure is being checked
@@ -705,6 +706,8 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
         dst[(size_t)i] = at;
         if (slotted) slots[(size_t)i] = (int32_t)(at >> 6);
         const long long len = src[(size_t)i + 1] - src[(size_t)i];
+        // (src may be a padded layout being re-padded: slot padding never adds a slot)
+        e->max_row_len = i == 0 ? len : std::max(e->max_row_len, len);
         at += slotted ? (len + 63) / 64 * 64 : len;
     }
     dst[(size_t)n] = at;
@@ -1258,6 +1261,11 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.rowptr64 = e->rowptr64;
         a.rowslot = e->rowslot;
         a.csr_acc = e->csr_acc;  // (the table form needs its table: set below once table_m is final)
+        {   // head slots per wave that the longest row needs (the wide bit forms are built per count)
+            const long long slots = (e->max_row_len + 63) / 64;
+            const long long need = (slots + std::max(e->waves, 1) - 1) / std::max(e->waves, 1);
+            a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 8);
+        }
         a.big = e->big_form;
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
@@ -1781,6 +1789,21 @@ int sga_get_exchange_stats(sga_engine *e, int64_t *attempts, int64_t *accepts) {
     return SGA_OK;
 }
 
+int sga_snapshot(sga_engine *e, double *energies, int64_t *accepted, int32_t *slot_to_rep) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    if (slot_to_rep && e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
+    HIPCHK(hipSetDevice(e->device));
+    if (energies)
+        HIPCHK(hipMemcpyAsync(energies, e->energy, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    if (accepted)
+        HIPCHK(hipMemcpyAsync(accepted, e->n_acc, sizeof(int64_t) * e->R, hipMemcpyDefault, e->stream));
+    if (slot_to_rep)
+        HIPCHK(hipMemcpyAsync(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
+}
+
 int sga_set_seed(sga_engine *e, uint64_t seed) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     e->seed = seed;
@@ -1979,8 +2002,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                                                   e->use_t2 ? e->waves_t2 : e->waves, e->R)
                           : 1);
     if (e->csr && e->slotted)
-        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp), " rows=64-entry-slots(+%.1f%%)",
-                      e->nnz > 0 ? 100.0 * (double)(e->layout_entries - e->nnz) / (double)e->nnz : 0.0);
+        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                      " rows=64-entry-slots(+%.1f%%) longest_row_slots=%lld",
+                      e->nnz > 0 ? 100.0 * (double)(e->layout_entries - e->nnz) / (double)e->nnz : 0.0,
+                      (e->max_row_len + 63) / 64);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

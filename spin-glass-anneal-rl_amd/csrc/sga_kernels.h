@@ -60,6 +60,7 @@ struct SweepArgs {
                   // extents (n > ~160k, nnz >= 2^31, long rows), 2 = narrow form, several replicas per
                   // workgroup (short rows)
     int csr_acc;         // CSR: one of CSR_ACC_* (how a row sum is formed)
+    int csr_head;        // CSR wide bit forms: head slots per wave the longest row needs (0: eight)
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     uint32_t seed_lo, seed_hi, sweep0, replica0;

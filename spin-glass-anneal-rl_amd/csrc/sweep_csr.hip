@@ -1,454 +1,10 @@
-// sweep_csr.hip -- single-spin sweep over CSR couplings (BASELINE config 3: N = 10k, degree
-// ~32, 4096 replicas).
-//
-// Replaces the same reference functions as the dense kernel (core/spin_dynamics.py:73-94,
-// core/ising_model.py:176-185) for IsingModelConfig(use_sparse=True) models; the reference's
-// own sparse branch (ising_model.py:133-135) raises under the container's torch, so the math
-// is the dense path's with the row restricted to its stored entries.
-//
-// Mapping: one replica per wavefront, up to CSR_WAVES_PER_BLOCK independent replicas per
-// workgroup (as many as fit LDS: 4 up to n = 40k, 2 up to 80k, 1 up to 160k) (no workgroup barrier anywhere: each wave owns a private LDS slice holding its
-// replica's spins).  A row has ~32 entries, i.e. one (colidx, val) wave-load each; the spin
-// gather goes through LDS; the dot is a DPP wave sum.  The structure (2.6 MB at C3) is
-// L2-resident, so the kernel is bound by instruction issue and the dependent-load chain,
-// not by HBM; hence:
-//   * the site sequence is known ahead of time (counter RNG): row extents are loaded one
-//     PAIR of updates ahead and row entries one update ahead, so no update waits on a
-//     rowptr -> colidx dependent load;
-//   * FAST variant (integer-valued J and h, sum_j |J_ij| + |h_i| <= M small): the row sum is
-//     accumulated in fp32 (exact), and the Metropolis probability exp(float32(-dE/T)) of the
-//     M possible uphill moves dE = 2k is tabulated in LDS once per sweep -- the same function
-//     of the same arguments, so decisions are bit-identical to the general path -- which
-//     removes the fp64 divide and the exp from the per-update chain.
-#include "sweep_common.h"
+// sweep_csr.hip -- launchers of the CSR sweep kernels (sweep_csr_impl.h): the narrow forms (one wave
+// per replica, several replicas per workgroup) are built here, the wide forms in sweep_csr_wide*.hip.
+#include "sweep_csr_impl.h"
 
 namespace sga {
 
-constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight together
-#ifndef CSR_WIDE_ROWS_AHEAD
-#define CSR_WIDE_ROWS_AHEAD 2    // wide forms: rows requested this many updates before their reduction
-#endif
-constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (16 measured slower)
-
-// WIDE = several waves per replica (long rows, few replicas): one replica per workgroup, the
-// row's entries are dealt to the waves in 64-entry slices, the per-wave sums meet in LDS with
-// one barrier per update (double-buffered slots, as in the dense kernel).  Every wave applies
-// an accepted flip to the shared spin byte itself before its next gather (same value from all
-// waves), so no second barrier is needed.
-//
-// BIG (a WIDE form) = problems beyond the int8 LDS capacity (n > ~160k; BASELINE config 5 at 1000
-// cities is n = 10^6) or with nnz >= 2^31: the replica's spins sit in LDS as one bit each (1 =
-// spin down; 125 KB at n = 10^6), row extents are 64-bit, flips are idempotent LDS atomics
-// (or / and-not) so that every wave can still apply them itself.
-//
-// Real-valued problems (FAST = false) sum a row in a CANONICAL ORDER that no launch geometry
-// changes: entry e of the row (storage order) belongs to lane e % 64 of virtual wave (e / 64) % 8;
-// a virtual lane adds its entries in storage order (fp64), each virtual wave folds its 64 lanes by
-// the adjacent-pairs tree (wave_sum), and the 8 wave sums are added in order.  A replica dealt to
-// NW = 1, 2, 4 or 8 real waves reproduces that exactly with 8 / NW accumulators per lane (NW is a
-// template parameter of the wide real-valued builds, so every accumulator index is a constant);
-// the CPU checker forms the same sum.
-// ACC = how a row sum is formed (CSR_ACC_*, chosen at set time): fp32 where that is exact
-// (integer J), with the accept table if h is integer too and the moves are few; fp64 in any order
-// where THAT is exact (all J within 53 binary places of each other, row length included -- e.g. the
-// TSP distances); the canonical fp64 order otherwise.
-template <int ACC, bool LEAN, bool WIDE, bool BIG, int NW = 0>
-__global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
-    sweep_csr_kernel(const SweepArgs a) {
-    constexpr bool FAST = ACC == CSR_ACC_F32_TABLE || ACC == CSR_ACC_F32;  // fp32 accumulation
-    constexpr bool TABLE = ACC == CSR_ACC_F32_TABLE;
-    constexpr bool CANON = ACC == CSR_ACC_F64_CANON;
-    static_assert(!CANON || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
-                  "canonical-order wide builds are made per wave count");
-    // (the production wide builds are made per wave count as well: with the slot arithmetic and
-    // the cross-wave sum on constants the 1000-city instance runs 12 % faster)
-    // Row extents: the narrow forms (one wave per replica) index entries (a.rowptr, 32 bit); the
-    // wide forms address a row by its 64-entry SLOTS (a.rowslot: rows are padded to whole slots,
-    // pad entries carry the value 0), so a slot number is wave-uniform: the address arithmetic is
-    // scalar and no lane tests a bound.  32-bit slot numbers cover nnz >= 2^31 (config 5 at 1000
-    // cities: 63 M slots).
-    using rp_t = int;
-    const rp_t *rowptr = WIDE ? a.rowslot : a.rowptr;
-    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;  // (a run-time rule costs C3 12 %: issue bound)
-    const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int nw = blockDim.x >> 6;                     // waves in the workgroup
-    const int r = WIDE ? (int)blockIdx.x : (int)blockIdx.x * nw + w;
-    if (!WIDE && r >= a.R) return;  // wave-uniform; the narrow form has no barriers
-    const int n = a.n;
-    const int slots = WIDE ? 1 : nw;                    // replicas sharing this workgroup's LDS
-    const int me = WIDE ? 0 : w;
-    const int stride_lanes = WIDE ? 64 * nw : 64;       // entries between a lane's row elements
-    const int first_lane = WIDE ? w * 64 + lane : lane; // this lane's first entry of a row
-    const long long sbytes = BIG ? a.sstride / 8 : a.sstride;  // LDS bytes of one replica's spins
-    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)me * sbytes;
-    unsigned int *sbits = reinterpret_cast<unsigned int *>(smem + (long long)me * sbytes);
-    float *ptab = reinterpret_cast<float *>(smem + (long long)slots * sbytes) +
-                  (long long)me * (a.table_m + 1);
-    double *part = reinterpret_cast<double *>(smem + (long long)slots * sbytes +
-                                              sizeof(float) * ((a.table_m + 2) & ~1) * slots);
-    int pp = 0;
-    const int cstep = WIDE ? (int)blockDim.x : 64, cfirst = WIDE ? tid : lane;
-    if constexpr (BIG) {
-        spins_to_bits(a.spins + (long long)r * a.sstride, sbits, a.sstride, cfirst, cstep);
-    } else {
-        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
-        int4 *dst = reinterpret_cast<int4 *>(s);
-        for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
-    }
-    if constexpr (WIDE) __syncthreads();
-    // value * spin of column c: with bit spins the sign bit is XORed in (3 VALU ops instead of a
-    // compare, a select and a multiply -- the wide forms spend most of their time here)
-    auto term = [&](float v, int c) -> float {
-        if constexpr (BIG) {
-            const unsigned int sign = (sbits[c >> 5] >> (c & 31)) << 31;
-            return __int_as_float(__float_as_int(v) ^ (int)sign);
-        } else {
-            return v * (float)s[c];
-        }
-    };
-    auto spin_i = [&](int c) -> int {
-        if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1 : 1;
-        else return s[c];
-    };
-    auto store_spins = [&](int8_t *dst_row) {
-        if constexpr (BIG) {
-            bits_to_spins(sbits, dst_row, a.sstride, n, cfirst, cstep);
-        } else {
-            int4 *dst = reinterpret_cast<int4 *>(dst_row);
-            const int4 *src = reinterpret_cast<const int4 *>(s);
-            for (int i = cfirst; i < a.sstride / 16; i += cstep) dst[i] = src[i];
-        }
-    };
-    const bool arith32 = arith == SGA_ARITH_F32;
-    double E = a.energy[r], bestE = a.best_energy[r];
-    unsigned long long nacc = 0;
-
-    struct Extent {  // what is indexed by the site alone
-        rp_t beg, end;
-        float h, d;
-    };
-    // The entries of a row requested one update ahead: its first 64 (one per lane) in the narrow
-    // form, where that is the whole row at degree ~32; HEAD per lane in the wide forms, so that a
-    // row of up to HEAD * 64 * waves entries is in flight while the previous update is reduced.
-    constexpr int HEAD = WIDE ? TAIL_UNROLL : 1;
-    struct Head {
-        int col[HEAD];
-        float val[HEAD];
-        int len;                  // wide forms: the row's slot count (wave-uniform)
-        const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer)
-    };
-    // wave-uniform value -> SGPR
-    auto uniform = [&](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
-    // this lane's entry of slot `slot` (wave-uniform) of the row starting at `row` (wave-uniform):
-    // scalar base + one constant 32-bit lane offset = the scalar-base load form
-    const unsigned int lane8 = (unsigned int)lane * 8u;
-    auto slot_entry = [&](const int2 *row, int slot) -> int2 {
-        const unsigned char *p = reinterpret_cast<const unsigned char *>(row) +
-                                 ((unsigned long long)(unsigned int)slot << 9);
-        // the lane offset stays a 32-bit value opaque to the optimiser (a hoisted 64-bit
-        // zero extension of it loses the base + zext(VGPR) address form)
-        unsigned int off = lane8;
-        asm volatile("" : "+v"(off));
-        return *reinterpret_cast<const int2 *>(p + off);
-    };
-    const int nwc = (WIDE && NW > 0) ? NW : nw;  // waves of this replica (a constant in the real-valued wide builds)
-    auto load_extent = [&](int site) {
-        Extent o;
-        o.beg = rowptr[site];
-        o.end = rowptr[site + 1];
-        o.h = a.h[site];
-        o.d = arith32 ? a.diag[site] : 0.0f;
-        return o;
-    };
-    auto load_head = [&](const Extent &x) {
-        Head o;
-        o.len = 0;
-        o.row = nullptr;
-        if constexpr (WIDE) {
-            // HEAD slots per wave: slot w + nw q of the row, q = 0..HEAD-1.  The extent arrived
-            // updates ago: pin it to SGPRs.  A slot past the row's end re-reads slot 0 (no extra
-            // traffic) and its values are zeroed by a wave-uniform select when used.
-            const int beg = uniform(x.beg);
-            o.len = uniform(x.end) - beg;
-            o.row = a.cv + ((long long)beg << 6);
-#pragma unroll
-            for (int q = 0; q < HEAD; ++q) {
-                const int sq = w + nwc * q;
-                const int2 ent = slot_entry(o.row, sq < o.len ? sq : 0);
-                o.col[q] = ent.x;
-                o.val[q] = __int_as_float(ent.y);
-            }
-            return o;
-        }
-#pragma unroll
-        for (int q = 0; q < HEAD; ++q) {
-            const rp_t j = x.beg + first_lane + (rp_t)stride_lanes * q;
-            const bool in = j < x.end;
-            const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-            o.col[q] = ent.x;
-            o.val[q] = __int_as_float(ent.y);
-        }
-        return o;
-    };
-
-    double T = 1.0;
-    auto update = [&](int site, float u, const Extent &x, const Head &hd, long long upd) {
-        // read s_i before any wave can have applied THIS update's flip (WIDE: before the barrier)
-        const int si = spin_i(site);
-        // J[site,:].s over the stored entries; products val * (+-1) are exact
-        float dot;
-        {
-            // one code path for the four row-sum forms: fp32 | fp64 accumulators, one per virtual wave
-            // of the canonical order (a single one in the exact forms, where the order is free)
-            using acc_t = typename std::conditional<FAST, float, double>::type;
-            constexpr int NVA = !CANON ? 1 : (WIDE ? 8 / (NW > 0 ? NW : 8) : 8);
-            acc_t acc[NVA];
-#pragma unroll
-            for (int j = 0; j < NVA; ++j) acc[j] = 0;
-            if constexpr (WIDE) {
-                // Every head slot is computed; the values of a slot past the row's end are zeroed by a
-                // wave-uniform select.  Measured against one wave-uniform branch per slot and against a
-                // straight-line block per valid-slot count (same box, profiles/r02_experiments.md): the
-                // branch-free form wins on both graded instances -- C4 49.3 vs 57.8 / 55.4 ms per sweep,
-                // C5 at 1000 cities 1478 vs 1699 / 1597 ms -- because the LDS gathers of all eight
-                // slots stay in flight together.  Virtual wave of slot q: (w + nw q) % 8 -> q % NVA.
-#pragma unroll
-                for (int q = 0; q < HEAD; ++q)
-                    acc[q % NVA] += (acc_t)term((w + nwc * q) < hd.len ? hd.val[q] : 0.0f, hd.col[q]);
-                // rows beyond HEAD slots per wave (degree > 4096 at 8 waves): eight more slots per pass
-                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const int sq = s0 + w + nwc * q;
-                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
-                        c[q] = ent.x;
-                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NVA] += (acc_t)term(v[q], c[q]);
-                }
-            } else {
-                // one wave: entry q' = 0 is the head, the tail batch t holds q' = 1 + 8 t + q, i.e.
-                // virtual wave (1 + q) % 8 of the canonical order
-                static_assert(WIDE || (TAIL_UNROLL == 8 && HEAD == 1), "virtual wave of a tail entry = (1 + q) % 8");
-                acc[0] += (acc_t)term(hd.val[0], hd.col[0]);
-                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                     j0 += stride_lanes * TAIL_UNROLL) {
-                    int c[TAIL_UNROLL];
-                    float v[TAIL_UNROLL];
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const rp_t j = j0 + stride_lanes * q;
-                        const bool in = j < x.end;
-                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-                        c[q] = ent.x;
-                        v[q] = __int_as_float(ent.y);
-                    }
-#pragma unroll
-                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[(1 + q) % NVA] += (acc_t)term(v[q], c[q]);
-                }
-            }
-            if constexpr (!CANON) {
-                // exact sums (set-time classification): any order, one wave reduction
-                acc_t tot = wave_sum(acc[0]);
-                if constexpr (WIDE) {
-                    acc_t *slot = reinterpret_cast<acc_t *>(part + pp * CSR_MAX_WIDE);
-                    if (lane == 0) slot[w] = tot;
-                    __syncthreads();
-                    acc_t t = slot[0];
-                    if constexpr (NW > 0) {
-#pragma unroll
-                        for (int i = 1; i < NW; ++i) t += slot[i];
-                    } else {
-                        for (int i = 1; i < nw; ++i) t += slot[i];
-                    }
-                    tot = t;
-                    pp ^= 1;
-                }
-                dot = (float)tot;  // fp64: rounded to fp32 once (core/ising_model.py:183)
-            } else if constexpr (WIDE) {
-                // canonical order: one tree per virtual wave, all 8 slots written, summed in order
-                double *slot = part + pp * CSR_MAX_WIDE;
-#pragma unroll
-                for (int j = 0; j < NVA; ++j) {
-                    const double sv = wave_sum(acc[j]);  // (+0 when the row has no slot of that wave)
-                    if (lane == 0) slot[w + (NW > 0 ? NW : 8) * j] = sv;
-                }
-                __syncthreads();
-                double t = slot[0];
-#pragma unroll
-                for (int v = 1; v < CSR_MAX_WIDE; ++v) t += slot[v];
-                pp ^= 1;
-                dot = (float)t;
-            } else {
-                const int len = (int)(x.end - x.beg);
-                double t = wave_sum(acc[0]);
-#pragma unroll
-                for (int j = 1; j < NVA; ++j)
-                    if (len > 64 * j) t += wave_sum(acc[j]);  // wave-uniform test
-                dot = (float)t;
-            }
-        }
-        double dE;
-        bool flip;
-        if (TABLE && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
-            // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2k exactly
-            const float fk = (float)si * (dot + x.h);
-            dE = (double)(2.0f * fk);
-            if (fk <= 0.0f) flip = true;
-            else if (fk <= (float)a.table_m) flip = u < ptab[(int)fk];
-            else flip = (dE > T * 104.0) ? false : (u < expf_det((float)(-dE / T)));  // beyond the table (p == 0 past -104)
-        } else {
-            flip = metropolis_accept(rule, arith, dot, si, x.h, x.d, T, u, dE);
-        }
-        if (flip) {
-            E += dE;
-            ++nacc;
-            if (lane == 0) {
-                if constexpr (BIG) {  // the same idempotent operation from every wave
-                    if (si > 0) atomicOr(&sbits[site >> 5], 1u << (site & 31));
-                    else atomicAnd(&sbits[site >> 5], ~(1u << (site & 31)));
-                } else {
-                    s[site] = (int8_t)(-si);
-                }
-            }
-        }
-        if constexpr (!LEAN) {
-            if (lane == 0) {
-                if (a.accept_trace)
-                    a.accept_trace[(long long)r * a.replay_stride + upd] = flip ? 1 : 0;
-                if (a.dE_trace)
-                    a.dE_trace[(long long)r * a.replay_stride + upd] =
-                        flip ? (rule == SGA_RULE_HEAT_BATH ? -dE : dE) : 0.0;
-            }
-        }
-    };
-
-    auto sweep_start = [&](int k) {
-        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-        if constexpr (TABLE) {  // exp(float32(-dE / T)) for dE = 2k, k = 0..M
-            if constexpr (WIDE) __syncthreads();  // nobody still reads last sweep's table
-            for (int q = first_lane; q <= a.table_m; q += stride_lanes)
-                ptab[q] = expf_det((float)(-(double)(2 * q) / T));
-            if constexpr (WIDE) __syncthreads();
-        }
-    };
-    auto sweep_end = [&](int k) {
-        if (lane == 0 && (!WIDE || w == 0) && a.energy_trace)
-            a.energy_trace[(long long)k * a.R + r] = E;
-        if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
-            bestE = E;
-            if constexpr (WIDE) __syncthreads();  // every wave has applied the last flip
-            store_spins(a.best_spins + (long long)r * a.sstride);
-            if constexpr (WIDE) __syncthreads();
-        }
-    };
-
-    PairSource<LEAN> rng;
-    if constexpr (BIG && WIDE && LEAN) {
-        // HBM-resident structures (C5 at 500 / 1000 cities: 4 / 32 GB): an update lasts ~2 us
-        // (row gather + reduce + barrier), about one loaded HBM round trip, so rows are requested
-        // NH - 1 = 2 updates ahead and their extents NB - 1 updates ahead (two rings, NB a
-        // multiple of NH so that every index is a compile-time constant after unrolling).  The
-        // extent of a row has to be back before its entries can be requested; vmcnt retires in
-        // order, so the gap NB - NH keeps that wait from draining the rows requested in between.
-        // +7 % there.  (A two-update look-ahead -- both rows reduced together, one barrier, the second
-        // row sum corrected by -2 J[B][A] s_A when the first flips -- was built, verified against the
-        // oracle and measured in round 2: 25 % SLOWER at C4, 16 % at C5-1000, with 128 or 256 VGPRs;
-        // see profiles/r02_experiments.md.  The chain, not the barrier, is what an update costs.)
-        constexpr int NH = CSR_WIDE_ROWS_AHEAD + 1, NB = 2 * NH;
-        struct Pending {
-            int site;
-            float u;
-            Extent x;
-        };
-        Pending er[NB];
-        Head hr[NH];
-        UpdatePair pairP{0, 0, 2.0f, 2.0f};
-        int kP = 0, tP = 0;  // producer cursor: next update whose extent is requested
-        auto request_extent = [&](Pending &sl) {
-            const bool second = tP & 1;
-            if (!second) pairP = rng.get(a, r, kP, tP >> 1, kP < a.n_sweeps, lane);  // past the end: site 0
-            const int sA = pairP.sA, sB = pairP.sB;  // values first, then select (no scratch)
-            const float uA = pairP.uA, uB = pairP.uB;
-            sl.site = second ? sB : sA;
-            sl.u = second ? uB : uA;
-            sl.x = load_extent(sl.site);
-            if (++tP == n) {
-                tP = 0;
-                ++kP;
-            }
-        };
-#pragma unroll
-        for (int j = 0; j + 1 < NB; ++j) request_extent(er[j]);
-#pragma unroll
-        for (int j = 0; j + 1 < NH; ++j) hr[j] = load_head(er[j].x);
-        const long long total = (long long)a.n_sweeps * n;
-        int k = 0, t = 0;
-        for (long long g0 = 0; g0 < total; g0 += NB) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (g0 + j >= total) break;  // workgroup-uniform
-                if (t == 0) sweep_start(k);
-                request_extent(er[(j + NB - 1) % NB]);
-                hr[(j + NH - 1) % NH] = load_head(er[(j + NH - 1) % NB].x);
-                update(er[j].site, er[j].u, er[j].x, hr[j % NH], g0 + j);
-                if (++t == n) {
-                    sweep_end(k);
-                    t = 0;
-                    ++k;
-                }
-            }
-        }
-    } else {
-        const int nb = (n + 1) >> 1;
-        UpdatePair cur = rng.get(a, r, 0, 0, a.n_sweeps > 0, lane);
-        Extent xA = load_extent(cur.sA), xB = load_extent(cur.sB);
-        Head hA = load_head(xA);
-        for (int k = 0; k < a.n_sweeps; ++k) {
-            sweep_start(k);
-            for (int b = 0; b < nb; ++b) {
-                const bool last = (b + 1 == nb);
-                const int kn = last ? k + 1 : k, bn = last ? 0 : b + 1;
-                const UpdatePair nxt = rng.get(a, r, kn, bn, kn < a.n_sweeps, lane);
-                const bool hasB = (2 * b + 1) < n;
-                const Extent nA = load_extent(nxt.sA), nB = load_extent(nxt.sB);  // a pair ahead
-                Head hB{};
-                if (hasB) hB = load_head(xB);  // in flight while A is reduced
-                update(cur.sA, cur.uA, xA, hA, (long long)k * n + 2 * b);
-                const Head hN = load_head(nA);  // in flight while B is reduced
-                if (hasB) update(cur.sB, cur.uB, xB, hB, (long long)k * n + 2 * b + 1);
-                cur = nxt;
-                xA = nA;
-                xB = nB;
-                hA = hN;
-            }
-            sweep_end(k);
-        }
-    }
-    if constexpr (WIDE) __syncthreads();
-    store_spins(a.spins + (long long)r * a.sstride);
-    if (lane == 0 && (!WIDE || w == 0)) {
-        a.energy[r] = E;
-        a.best_energy[r] = bestE;
-        a.n_accepted[r] += nacc;
-    }
-}
-
-static size_t csr_lds_per_replica(int sstride, int table_m, bool big = false) {
-    // spins (bytes | bits) + accept table (>= 8 B)
-    return (size_t)(big ? sstride / 8 : sstride) + sizeof(float) * (size_t)((table_m + 2) & ~1);
-}
-
-size_t csr_lds_bytes(int sstride, int table_m, bool bits) {
-    return csr_lds_per_replica(sstride, table_m, bits);
-}
+size_t csr_lds_bytes(int sstride, int table_m, bool bits) { return csr_lds_per_replica(sstride, table_m, bits); }
 
 constexpr size_t CSR_LDS_BUDGET = 160 * 1024 - 256;
 
@@ -468,65 +24,28 @@ int csr_bits_waves_per_block(int sstride, int table_m) {  // narrow bit-spin for
     return wpb > CSR_WAVES_PER_BLOCK ? CSR_WAVES_PER_BLOCK : wpb;
 }
 
-template <bool WIDE, bool BIG>
-static hipError_t launch_csr(const SweepArgs &a, int waves, hipStream_t st) {
-    const bool lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
-    const int slots = WIDE ? 1 : waves;
-    const size_t lds = csr_lds_per_replica(a.sstride, a.table_m, BIG) * slots +
-                       2 * CSR_MAX_WIDE * sizeof(double);
-    // the accept table is a specialisation of the production (LEAN) builds
-    int acc = a.csr_acc;
-    if (acc == CSR_ACC_F32_TABLE && (!lean || a.table_m <= 0)) acc = CSR_ACC_F32;
+template <bool BIG>
+static hipError_t launch_csr_narrow(const SweepArgs &a, int waves, hipStream_t st) {
+    const bool lean = csr_args_are_lean(a);
     void (*kern)(const SweepArgs) = nullptr;
-    if constexpr (!WIDE) {
-        switch (acc) {
-            case CSR_ACC_F32_TABLE: kern = sweep_csr_kernel<CSR_ACC_F32_TABLE, true, false, BIG>; break;
-            case CSR_ACC_F32:
-                kern = lean ? sweep_csr_kernel<CSR_ACC_F32, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F32, false, false, BIG>;
-                break;
-            case CSR_ACC_F64:
-                kern = lean ? sweep_csr_kernel<CSR_ACC_F64, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F64, false, false, BIG>;
-                break;
-            default:
-                kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, false, BIG>
-                            : sweep_csr_kernel<CSR_ACC_F64_CANON, false, false, BIG>;
-        }
-    } else {
-        // wide forms: 1, 2, 4 or 8 waves per replica (the engine rounds up); the production builds and
-        // the canonical-order builds are made per wave count, the other traced builds take it at run time
-#define SGA_WIDE_PICK(ACC_, NW_)                                                                      \
-    (lean ? sweep_csr_kernel<ACC_, true, true, BIG, NW_>                                              \
-          : sweep_csr_kernel<ACC_, false, true, BIG, (ACC_ == CSR_ACC_F64_CANON ? NW_ : 0)>)
-#define SGA_WIDE_NW(ACC_)                                                                             \
-    (waves == 1 ? SGA_WIDE_PICK(ACC_, 1) : waves == 2 ? SGA_WIDE_PICK(ACC_, 2)                        \
-     : waves == 4 ? SGA_WIDE_PICK(ACC_, 4) : SGA_WIDE_PICK(ACC_, 8))
-        if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return hipErrorInvalidValue;
-        switch (acc) {
-            case CSR_ACC_F32_TABLE:
-                kern = waves == 1 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 1>
-                     : waves == 2 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 2>
-                     : waves == 4 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 4>
-                                  : sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 8>;
-                break;
-            case CSR_ACC_F32: kern = SGA_WIDE_NW(CSR_ACC_F32); break;
-            case CSR_ACC_F64: kern = SGA_WIDE_NW(CSR_ACC_F64); break;
-            default: kern = SGA_WIDE_NW(CSR_ACC_F64_CANON); break;
-        }
-#undef SGA_WIDE_NW
-#undef SGA_WIDE_PICK
+    switch (csr_effective_acc(a, lean)) {
+        case CSR_ACC_F32_TABLE: kern = sweep_csr_kernel<CSR_ACC_F32_TABLE, true, false, BIG>; break;
+        case CSR_ACC_F32:
+            kern = lean ? sweep_csr_kernel<CSR_ACC_F32, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F32, false, false, BIG>;
+            break;
+        case CSR_ACC_F64:
+            kern = lean ? sweep_csr_kernel<CSR_ACC_F64, true, false, BIG> : sweep_csr_kernel<CSR_ACC_F64, false, false, BIG>;
+            break;
+        default:
+            kern = lean ? sweep_csr_kernel<CSR_ACC_F64_CANON, true, false, BIG>
+                        : sweep_csr_kernel<CSR_ACC_F64_CANON, false, false, BIG>;
     }
-    {
-        hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
-        if (e != hipSuccess) return e;
-    }
-    const int blocks = WIDE ? a.R : (a.R + waves - 1) / waves;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, st, a);
-    return hipGetLastError();
+    return launch_csr_kernel(kern, a, false, BIG, waves, st);
 }
 
 // waves_per_replica == 1: several replicas per workgroup (as many as fit LDS), no barriers;
-// > 1: one replica per workgroup, its rows dealt to that many waves.  a.big: the bit-spin form,
-// always one replica per workgroup (1..CSR_MAX_WIDE waves).
+// > 1: one replica per workgroup, its rows dealt to that many waves (1, 2, 4 or 8: the engine rounds
+// up).  a.big: the bit-spin forms -- 2 = narrow, 1 = one replica per workgroup (1..8 waves).
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st) {
     if (a.big) {
         if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !csr_big_fits(a.sstride, a.table_m))
@@ -534,19 +53,19 @@ hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream
         if (waves_per_replica == 1 && a.rowptr && a.big == 2) {  // several replicas per workgroup
             const int wpb = csr_bits_waves_per_block(a.sstride, a.table_m);
             if (wpb < 1) return hipErrorInvalidValue;
-            return launch_csr<false, true>(a, wpb, st);
+            return launch_csr_narrow<true>(a, wpb, st);
         }
         if (!a.rowslot) return hipErrorInvalidValue;  // wide forms read the slotted layout
-        return launch_csr<true, true>(a, waves_per_replica, st);
+        return launch_csr_wide_bits(a, waves_per_replica, a.csr_head, st);
     }
     if (waves_per_replica > 1) {
         if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1 || !a.rowslot)
             return hipErrorInvalidValue;
-        return launch_csr<true, false>(a, waves_per_replica, st);
+        return launch_csr_wide_bytes(a, waves_per_replica, st);
     }
     const int wpb = csr_waves_per_block(a.sstride, a.table_m);
     if (wpb < 1 || !a.rowptr) return hipErrorInvalidValue;
-    return launch_csr<false, false>(a, wpb, st);
+    return launch_csr_narrow<false>(a, wpb, st);
 }
 
 }  // namespace sga

@@ -396,6 +396,14 @@ class AnnealEngine:
                                         att.ctypes.data_as(C.c_void_p)), "sga_get_stats")
         return acc, att
 
+    def snapshot(self, slots: bool = True):
+        """(energies, accepted counters, ladder permutation | None) with one synchronisation."""
+        en, acc = np.zeros(self.R, np.float64), np.zeros(self.R, np.int64)
+        sm = np.zeros(self.R_global, np.int32) if (slots and self.n_ladders > 0) else None
+        N.check(self._lib.sga_snapshot(self._h, en.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p),
+                                       None if sm is None else sm.ctypes.data_as(C.c_void_p)), "sga_snapshot")
+        return en, acc, sm
+
     def slot_map(self) -> np.ndarray:
         out = np.zeros(self.R_global, np.int32)
         N.check(self._lib.sga_get_slot_map(self._h, out.ctypes.data_as(C.c_void_p)),

@@ -103,12 +103,8 @@ class ParallelTempering:
                     site = _replay["site"][sweep:stop + 1][:, inv].transpose(1, 0, 2).reshape(R, -1)
                     u = _replay["u"][sweep:stop + 1][:, inv].transpose(1, 0, 2).reshape(R, -1)
                     eng.sweep(count, site_mode=N.SITE_REPLAY, replay_site=site, replay_u=u)
-                # per-slot acceptance bookkeeping (the reference's SpinDynamics stay with slots)
-                acc_now = eng.stats()[0]
-                acc_slot += (acc_now - acc_prev)[slot_to_rep]
-                att_slot += count * n
-                acc_prev = acc_now
-                if stop % cfg.exchange_interval == 0 and stop > 0 and all_pairs:
+                exchange_now = stop % cfg.exchange_interval == 0 and stop > 0  # reference :113
+                if exchange_now and all_pairs:
                     if _replay is None:
                         gates = gate_rng.rand(len(pair_list)) < 0.1
                         eng.exchange_pairs([p for p, g in zip(pair_list, gates) if g])
@@ -123,21 +119,28 @@ class ParallelTempering:
                                 ucur += 1
                         eng.exchange_pairs(chosen, u=np.asarray(uu, np.float64))
                     rnd += 1
-                    slot_to_rep = eng.slot_map()
-                elif stop % cfg.exchange_interval == 0 and stop > 0:  # reference :113
+                elif exchange_now:
                     if _replay is None:
-                        eng.exchange()
+                        eng.exchange(count=False)  # enqueued behind the sweeps, no host round trip
                     else:
                         start = int(_replay["exch_start"][rnd])
                         npairs = len(range(start, R - 1, 2))
                         uu = np.zeros(R // 2)
                         uu[:npairs] = _replay["exch_u"][ucur:ucur + npairs]
-                        eng.exchange(start=[start], u=uu)
+                        eng.exchange(start=[start], u=uu, count=False)
                         ucur += npairs
                     rnd += 1
-                    slot_to_rep = eng.slot_map()
+                # one synchronisation per event: energies (an exchange moves labels, not energies),
+                # acceptance counters, ladder permutation
+                en_rep, acc_now, new_map = eng.snapshot()
+                # per-slot acceptance bookkeeping (the reference's SpinDynamics stay with slots):
+                # these sweeps ran under the permutation in force BEFORE the exchange
+                acc_slot += (acc_now - acc_prev)[slot_to_rep]
+                att_slot += count * n
+                acc_prev = acc_now
+                slot_to_rep = new_map
                 if stop % cfg.record_interval == 0:  # reference :117-125
-                    en = eng.energies()[slot_to_rep]
+                    en = en_rep[slot_to_rep]
                     for i in range(R):
                         self.energy_histories[i].append(float(en[i]))
                         self.temp_histories[i].append(float(temps[i]))
