@@ -1060,6 +1060,13 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             // 1.17e9 vs 1.74e9); against the narrow bit form residency decides.
             if (R_local > res_i8 && res_bits > res_i8 && (narrow_bits || wide_i8 || rpb <= 2)) bits = true;
         }
+        // Long rows with MANY replicas (C5 at 100 cities: degree 396, 2048 replicas): one wave per
+        // replica either way, but the slot-addressed bit form (one replica per workgroup, scalar
+        // addressing, no per-lane bounds tests) beats the entry-addressed int8 form with four replicas
+        // per workgroup: 10.6 vs 11.9 ms per sweep.
+        const bool many_long = long_rows && R_local > 1024 && e->tune_waves == 0 && bits_fit && e->slotted &&
+                               std::getenv("SGA_NO_CSR_BITS") == nullptr;
+        if (many_long) bits = true;
         e->big = bits;
         e->big_form = !bits ? 0 : (narrow_bits ? 2 : 1);
         if (bits) {
@@ -1073,7 +1080,7 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
                 // one workgroup per replica: deal a long row to as many waves as the 8 entries per
                 // lane requested ahead need to cover it (profiles/r01_experiments.md: 500 cities,
                 // degree 1996: 4 waves; 1000 cities, 3996: 8)
-                const int wpr = e->tune_waves > 0 ? e->tune_waves : (int)std::ceil(deg / 512.0);
+                const int wpr = e->tune_waves > 0 ? e->tune_waves : (many_long ? 1 : (int)std::ceil(deg / 512.0));
                 e->waves = std::max(1, std::min(wpr, 8));
             }
         } else {
