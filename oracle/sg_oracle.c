@@ -165,17 +165,18 @@ static inline float row_dot_f32(int n, const float *J, int64_t ld, const int32_t
             return acc;
         }
         /* Real-valued J: fp32 products (exact), summed in double in the CANONICAL ORDER the HIP
-         * kernels use for every launch geometry (sweep_dense_impl.h): 256-element chunks; within
-         * a chunk lane l of 64 adds its four products ((e0 + e1) + e2) + e3 starting from +0,
-         * the 64 lane sums are folded by an adjacent-pairs tree, and the chunk sums are added in
-         * chunk order.  The double sum is rounded to fp32 once (torch.dot returns fp32). */
+         * kernels use for every launch geometry (sweep_dense_impl.h): super-chunks of 1024 elements;
+         * lane l of 64 adds its sixteen products -- chunk j = 0..3 of the super-chunk, elements
+         * 4l .. 4l+3 of each, in that order -- starting from +0, the 64 lane sums are folded by an
+         * adjacent-pairs tree, and the super-chunk sums are added in order.  The double sum is
+         * rounded to fp32 once (torch.dot returns fp32). */
         double total = 0.0;
-        for (int c0 = 0; c0 < n; c0 += 256) {
+        for (int c0 = 0; c0 < n; c0 += 1024) {
             double lane[64];
             for (int l = 0; l < 64; ++l) {
                 double p = 0.0;
-                for (int q = 0; q < 4; ++q) {
-                    int j = c0 + 4 * l + q;
+                for (int q = 0; q < 16; ++q) {
+                    int j = c0 + 256 * (q >> 2) + 4 * l + (q & 3);
                     if (j < n) p += (double)(row[j] * (float)s[j]);
                 }
                 lane[l] = p;

@@ -340,11 +340,21 @@ int ensure_packed(sga_engine *e) {
             return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
         e->waves_t2 = Wb;
         e->cpw_t2 = Cb;
+    } else if (e->acc_canon) {
+        // canonical summation order: a wave owns whole super-chunks of 4 chunks (1024 fp32 elements),
+        // one or two of them in registers; longer rows take the streaming form on 16 waves
+        int S;
+        choose_geometry(e->n, 4 * elems_per_chunk(false), std::max(e->R, 1), e->tune_waves, W, S, 2);
+        CPW = 4 * S;
+        ld = (long long)W * CPW * elems_per_chunk(false);
+        if (e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m, true) > 160 * 1024)
+            return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     } else {
         choose_geometry(e->n, elems_per_chunk(e->want_i8), std::max(e->R, 1), e->tune_waves, W, CPW);
         ld = (long long)W * CPW * elems_per_chunk(e->want_i8);
         if (e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
-        if (sga::sweep_dense_lds_bytes(ld, e->table_m, e->acc_canon) > 160 * 1024)
+        if (sga::sweep_dense_lds_bytes(ld, e->table_m, false) > 160 * 1024)
             return fail(SGA_ERR_UNSUPPORTED, "replica spins do not fit LDS (n too large)");
     }
     e->waves = W;
@@ -545,8 +555,8 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
         return rc;
     };
 
-    const int epc = e->use_t2 ? T2_ELEMS_PER_CHUNK : elems_per_chunk(e->want_i8);
-    const int max_cpw = e->use_t2 ? sga::T2_MAX_CPW : 8;
+    const int epc = e->use_t2 ? T2_ELEMS_PER_CHUNK : (e->acc_canon ? 4 : 1) * elems_per_chunk(e->want_i8);
+    const int max_cpw = e->use_t2 ? sga::T2_MAX_CPW : (e->acc_canon ? 2 : 8);
     const int C = (n + epc - 1) / epc;
     int best_w = -1;
     double best = 1e300;

@@ -820,7 +820,7 @@ template <typename JT, bool CSR>
 __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
     constexpr int EPL = 16 / sizeof(JT), EPC = 64 * EPL;
     __shared__ double red[8];
-    // dense fp32: per-chunk sums of the canonical summation order (n <= 163 840: 640 chunks)
+    // dense fp32: per-super-chunk sums of the canonical summation order (n <= 163 840: 160 of them)
     __shared__ double csum[(!CSR && sizeof(JT) == 4) ? 640 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -855,20 +855,24 @@ __global__ void __launch_bounds__(256) point_op_kernel(const PointArgs a) {
             for (int v = 1; v < 8; ++v) t += red[v];
             dot = (float)t;
         } else if constexpr (sizeof(JT) == 4) {
-            // canonical order of sweep_dense_impl.h: 256-element chunks, lane partial
-            // ((e0 + e1) + e2) + e3, adjacent-pairs tree, chunk sums added in chunk order
+            // canonical order of sweep_dense_impl.h: 1024-element super-chunks; lane l adds its 16
+            // products (chunk j = 0..3, elements 4l..4l+3 of each) from +0, adjacent-pairs tree,
+            // super-chunk sums added in order
             const JT *row = reinterpret_cast<const JT *>(a.J) + a.model_offset_j + (long long)site * a.ldj;
-            const int C = (a.n + EPC - 1) / EPC;
+            const int C = (a.n + 4 * EPC - 1) / (4 * EPC);
             for (int c = w; c < C; c += 4) {
-                const long long col = (long long)c * EPC + lane * EPL;
                 double p = 0.0;
-                if (col < a.ldj) {  // J's row pad and the spins' pad are zero
-                    const float4 x = *reinterpret_cast<const float4 *>(row + col);
-                    const int sw = *reinterpret_cast<const int *>(a.spins + col);
-                    p += (double)(x.x * (float)(int8_t)(sw));
-                    p += (double)(x.y * (float)(int8_t)(sw >> 8));
-                    p += (double)(x.z * (float)(int8_t)(sw >> 16));
-                    p += (double)(x.w * (float)(sw >> 24));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long long col = ((long long)c * 4 + j) * EPC + lane * EPL;
+                    if (col < a.ldj) {  // J's row pad and the spins' pad are zero
+                        const float4 x = *reinterpret_cast<const float4 *>(row + col);
+                        const int sw = *reinterpret_cast<const int *>(a.spins + col);
+                        p += (double)(x.x * (float)(int8_t)(sw));
+                        p += (double)(x.y * (float)(int8_t)(sw >> 8));
+                        p += (double)(x.z * (float)(int8_t)(sw >> 16));
+                        p += (double)(x.w * (float)(sw >> 24));
+                    }
                 }
                 const double cs = wave_sum(p);
                 if (lane == 0) csum[c] = cs;

@@ -28,7 +28,7 @@ int dense_look_ahead(bool t2, bool j_is_i8, bool acc64, int cpw, int waves, int 
 }
 size_t sweep_dense_lds_bytes(long long ld, int table_m, bool acc64) {
     if (acc64)  // fp32 couplings, real valued: + the per-chunk sums of the canonical order
-        return (size_t)(dense_canon_offset(ld, table_m) + dense_canon_bytes(ld, 256));
+        return (size_t)(dense_canon_offset(ld, table_m) + dense_canon_bytes(ld, 1024));
     return (size_t)ld + DENSE_LDS_EXTRA + sizeof(float) * (size_t)(table_m + 1);
 }
 }  // namespace sga

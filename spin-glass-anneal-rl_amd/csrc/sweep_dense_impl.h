@@ -81,7 +81,7 @@ constexpr int LOOK_SLOT_BYTES = 4 * LOOK;  // one wave's LOOK partial sums (floa
 // behind the spins: [2][MAX_WAVES] partial-sum slots (8 B, or 16 B in the look-ahead form), then
 // the spin(s) at the update site(s) published by their owner waves
 constexpr int DENSE_LDS_EXTRA = 2 * MAX_WAVES * LOOK_SLOT_BYTES + 2 * LOOK * 4;
-// ACC64 kernels keep two buffers of per-chunk row sums behind the accept table (8-byte aligned)
+// canonical-order kernels keep two buffers of per-super-chunk row sums behind the accept table
 __host__ __device__ constexpr long long dense_canon_offset(long long sbytes, int table_m) {
     return (sbytes + DENSE_LDS_EXTRA + 4ll * (table_m + 1) + 7) & ~7ll;
 }
@@ -195,6 +195,18 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     const float *dvec = a.diag + (long long)model * n;
     const long long kstep = (long long)W * CHUNK_STEP;  // address step between a wave's chunks
     const int8_t *slane = s_lds + lane_off;
+    // Which chunk is this wave's k-th?  Chunk w + k W everywhere -- except in the canonical-order
+    // builds (real-valued J of a wide dynamic range), where a wave owns whole SUPER-CHUNKS of
+    // SC = 4 consecutive chunks (1024 elements), so that one tree serves four chunks: its k-th
+    // chunk is chunk ((k / 4) W + w) 4 + k % 4.  coff(k): that chunk's offset in address steps.
+    constexpr bool SUPER = ACC64 && CANON;
+    constexpr int SC = 4;
+    static_assert(!SUPER || CPW % SC == 0, "canonical order: whole super-chunks per wave");
+    auto coff = [&](unsigned int k) -> unsigned int {
+        if constexpr (SUPER) return (((k / SC) * (unsigned int)W + (unsigned int)w) * SC + (k % SC)) * (unsigned int)CHUNK_STEP;
+        else return ((unsigned int)w + k * (unsigned int)W) * (unsigned int)CHUNK_STEP;
+    };
+    const unsigned int lane_part = (unsigned int)(lane * LANE_STEP);
     const bool arith32 = arith == SGA_ARITH_F32;
 
     // the wave whose chunks hold `site` (chunk c belongs to wave c mod W).  A general modulo costs
@@ -203,14 +215,15 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     const unsigned int w_recip = (65536u + (unsigned int)W - 1u) / (unsigned int)W;
     auto owner_of = [&](int site) -> int {
         if constexpr (SINGLE) return 0;
-        const unsigned int c = (unsigned int)site / (unsigned int)EPC;
+        const unsigned int c = (unsigned int)site / (unsigned int)(SUPER ? SC * EPC : EPC);
         return (int)(c - ((c * w_recip) >> 16) * (unsigned int)W);
     };
 
     constexpr int NBUF = CPW > 0 ? CPW : 1;
     const int cpw_rt = (int)(a.ld / kstride);  // chunks per wave (runtime; = CPW when CPW > 0)
-    const int n_chunks_ld = (int)(a.ld / EPC);       // chunk slots of the layout (W * chunks per wave)
-    const int n_chunks_row = (n + EPC - 1) / EPC;    // chunks that hold elements of a row
+    // canonical order: super-chunk slots of the layout / super-chunks that hold elements of a row
+    const int n_chunks_ld = (int)(a.ld / (4 * EPC));
+    const int n_chunks_row = (n + 4 * EPC - 1) / (4 * EPC);
 
     // The base of row `site`.  Up to 8 chunks per wave it is pinned to SGPRs and the loads take
     // the scalar-base form (one 32-bit offset VGPR per load instead of a 64-bit address pair);
@@ -239,7 +252,7 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
         if constexpr (SCALAR_BASE) {
             // byte offset in 32 bits, opaque to the optimiser (a hoisted 64-bit zero extension of
             // it loses the base + zext(VGPR) address form)
-            unsigned int o32 = (lane_off + (unsigned int)k * (unsigned int)kstep) * (unsigned int)sizeof(JE);
+            unsigned int o32 = (lane_part + coff((unsigned int)k)) * (unsigned int)sizeof(JE);
             in = o32 < (unsigned int)row_step * (unsigned int)sizeof(JE);
             o32 = in ? o32 : 0u;
             asm volatile("" : "+v"(o32));
@@ -271,9 +284,10 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     // the spins under chunk k of this wave, and one chunk's contribution to a row sum
     using spin_t = typename std::conditional<sizeof(JT) == 4, int, int4>::type;
     auto load_spins = [&](long long k) -> spin_t {
-        if constexpr (BITS) return *reinterpret_cast<const int4 *>(slane + k * kstep);
-        else if constexpr (sizeof(JT) == 4) return *reinterpret_cast<const int *>(slane + k * kstride);
-        else return *reinterpret_cast<const int4 *>(slane + k * kstride);
+        const int8_t *sp = SUPER ? s_lds + lane_part + coff((unsigned int)k) : slane + k * kstep;
+        if constexpr (BITS) return *reinterpret_cast<const int4 *>(sp);
+        else if constexpr (sizeof(JT) == 4) return *reinterpret_cast<const int *>(sp);
+        else return *reinterpret_cast<const int4 *>(sp);
     };
     auto accumulate_with = [&](acc_t &acc, const vec_t &x, const spin_t &sv) {
         if constexpr (BITS) {  // count the stored couplings whose product with the spin is -1
@@ -340,48 +354,47 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
         constexpr bool CANON64 = ACC64 && CANON;
         acc_t tot;
         if constexpr (CANON64) {
-            // CANONICAL ORDER for real-valued J: each 256-element chunk c is summed by itself --
-            // lane partial ((e0 + e1) + e2) + e3 from +0, adjacent-pairs tree over the 64 lanes
-            // (wave_sum) -- and the chunk sums are added in chunk order c = 0, 1, 2, ...  Which
-            // wave holds a chunk, and how many chunks a wave holds, does not enter: the fp64 sum,
-            // and with it the fp32 row sum and every decision, is the same for every launch
-            // geometry (the CPU checker forms the same sum).
+            // CANONICAL ORDER for real-valued J: each 1024-element super-chunk is summed by itself --
+            // lane l of 64 adds its 16 products (chunk j = 0..3 of the super-chunk, elements 4l..4l+3
+            // of each, in that order) from +0, then the adjacent-pairs tree over the 64 lanes
+            // (wave_sum) -- and the super-chunk sums are added in order.  Which wave holds a
+            // super-chunk, and how many a wave holds, does not enter: the fp64 sum, and with it the
+            // fp32 row sum and every decision, is the same for every launch geometry (the CPU
+            // checker forms the same sum).
             double *slot = canon + pp * n_chunks_ld;
             if constexpr (CPW == 0) {
                 const JE *p = row_base(site);
-                for (int k0 = 0; k0 < cpw_rt; k0 += 4) {
-                    vec_t t[4];
+                for (int k0 = 0; k0 < cpw_rt; k0 += SC) {
+                    vec_t t[SC];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k0 + j < cpw_rt) t[j] = load_chunk(p, k0 + j);
+                    for (int j = 0; j < SC; ++j) t[j] = load_chunk(p, k0 + j);
+                    acc_t pl = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k0 + j < cpw_rt) {
-                            acc_t pl = 0;
-                            accumulate(pl, t[j], k0 + j);
-                            const acc_t cs = wave_sum(pl);
-                            if (lane == 0) slot[w + (k0 + j) * W] = cs;
-                        }
+                    for (int j = 0; j < SC; ++j) accumulate(pl, t[j], k0 + j);
+                    const acc_t cs = wave_sum(pl);
+                    if (lane == 0) slot[(k0 / SC) * W + w] = cs;
                 }
                 tot = 0;
             } else {
-                acc_t cs[NBUF];
+                constexpr int NS = NBUF / SC > 0 ? NBUF / SC : 1;
+                acc_t cs[NS];
 #pragma unroll
-                for (int k = 0; k < NBUF; ++k) {
+                for (int q = 0; q < NS; ++q) {
                     acc_t pl = 0;
-                    accumulate(pl, buf[k], k);
-                    cs[k] = wave_sum(pl);
+#pragma unroll
+                    for (int j = 0; j < SC; ++j) accumulate(pl, buf[(q * SC + j) % NBUF], q * SC + j);
+                    cs[q] = wave_sum(pl);
                 }
                 if (W > 1) {
                     if (lane == 0) {
 #pragma unroll
-                        for (int k = 0; k < NBUF; ++k) slot[w + k * W] = cs[k];
+                        for (int q = 0; q < NS; ++q) slot[q * W + w] = cs[q];
                     }
                     tot = 0;
                 } else {
                     tot = cs[0];
 #pragma unroll
-                    for (int k = 1; k < NBUF; ++k) tot += cs[k];
+                    for (int q = 1; q < NS; ++q) tot += cs[q];
                 }
             }
         } else {
@@ -724,9 +737,12 @@ constexpr bool has_look_ahead() {  // keep dense_look_ahead() (sweep_dense_i8.hi
 
 template <typename JT, bool ACC64, int CPW, bool CANON = false>
 static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
+    if constexpr (ACC64 && CANON && CPW % 4 != 0) {
+        return hipErrorInvalidValue;  // canonical order: whole 4-chunk super-chunks per wave (engine's geometry)
+    } else {
     constexpr bool BITS = std::is_same<JT, Tern2>::value;
     const size_t lds = CANON ? (size_t)(dense_canon_offset(a.ld, a.table_m) +
-                                        dense_canon_bytes(a.ld, 64 * JTraits<JT>::EPL))
+                                        dense_canon_bytes(a.ld, 4 * 64 * JTraits<JT>::EPL))
                              : (size_t)(BITS ? a.ld / 8 : a.ld) + DENSE_LDS_EXTRA +
                                    sizeof(float) * (size_t)(a.table_m + 1);
     const bool lean = sweep_args_are_lean(a);
@@ -759,6 +775,7 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
     return hipGetLastError();
+    }
 }
 
 template <typename JT, bool ACC64, bool CANON = false>

@@ -65,11 +65,11 @@ __global__ void __launch_bounds__(64) sweep_wolff_kernel(const SweepArgs a, cons
         } else {
             const JT *row = Jm + (long long)i * a.ldj;
             double t = 0.0;
-            for (int c0 = 0; c0 < n; c0 += 256) {
+            for (int c0 = 0; c0 < n; c0 += 1024) {  // 1024-element super-chunks (sweep_dense_impl.h)
                 double p = 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = c0 + 4 * lane + q;
+                for (int q = 0; q < 16; ++q) {
+                    const int j = c0 + 256 * (q >> 2) + 4 * lane + (q & 3);
                     if (j < n) p += (double)((float)row[j] * (float)s[j]);
                 }
                 const double cs = wave_sum(p);

@@ -335,14 +335,14 @@ def test_more_waves_than_chunks_is_clamped(sg, n, waves, integer):
 
 
 def test_forced_waves_up_to_the_chunk_count_are_kept(sg):
-    J = np.triu(np.random.RandomState(3).randn(700, 700), 1).astype(np.float32)
+    J = np.triu(np.random.RandomState(3).randint(-200, 201, (700, 700)), 1).astype(np.float32)
     J = J + J.T
     for waves, expect in ((2, 2), (3, 3), (4, 3), (16, 3)):  # 700 fp32 = 3 chunks of 256
         with sg.AnnealEngine(0) as e:
             e.set_tuning(waves_per_replica=waves)
-            e.set_dense(J, np.zeros(700, np.float32))
+            e.set_dense(J, np.zeros(700, np.float32), storage="f32")
             e.init_replicas(4, seed=1)
-            assert f"waves_per_replica={expect} " in e.describe(), e.describe()
+            assert f"waves_per_replica={expect} " in e.describe() and "acc=f32" in e.describe(), e.describe()
 
 
 @pytest.mark.parametrize("n,geometries", [(700, (1, 2, 3)), (2500, (1, 3, 5, 8, 10)),
@@ -351,7 +351,7 @@ def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
     """Gaussian couplings: the fp64 row sum is formed in one canonical order (256-element chunks,
     adjacent-pairs tree, chunk order) whatever the waves-per-replica, so every decision and every
     dE equals the oracle's bit for bit under each geometry -- including the streaming form (more
-    than 10 chunks per wave: n = 5000 on one wave, n = 6000 on two)."""
+    than two super-chunks per wave: n = 2500 and 5000 on one wave, n = 5000 and 6000 on two)."""
     J = np.triu(np.random.RandomState(n).randn(n, n), 1).astype(np.float32)
     J = J + J.T
     h = np.random.RandomState(n + 1).randn(n).astype(np.float32)
@@ -366,8 +366,12 @@ def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
             e.set_dense(J, h)
             e.init_replicas(R, seed=seed)
             d = e.describe()
-            assert "acc=f64-canonical" in d and f"waves_per_replica={g} " in d, d
-            assert ("(streaming)" in d) == ((n + 255) // 256 > 10 * g), d
+            # canonical-order builds: a wave owns whole 1024-element super-chunks, one or two of them
+            # in registers; a forced wave count is clamped to the super-chunk count
+            supers = (n + 1023) // 1024
+            w_eff = min(g, supers)
+            assert "acc=f64-canonical" in d and f"waves_per_replica={w_eff} " in d, d
+            assert ("(streaming)" in d) == (-(-supers // w_eff) > 2), d
             e.set_temperatures(temps)
             for traced in (True, False):   # general and production variants
                 if not traced:
@@ -404,7 +408,8 @@ def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced
             e.set_dense(J, h)
             e.init_replicas(R, seed=seed)
             d = e.describe()
-            assert ("acc=f64-canonical" if forced else "acc=f64-exact") in d and f"waves_per_replica={g} " in d, d
+            w_eff = min(g, (n + 1023) // 1024) if forced else g   # canonical builds: whole super-chunks
+            assert ("acc=f64-canonical" if forced else "acc=f64-exact") in d and f"waves_per_replica={w_eff} " in d, d
             e.set_temperatures(temps)
             out = e.sweep(ns, trace=True)
             assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
@@ -606,7 +611,7 @@ def test_checkpoint_moves_between_launch_geometries(sg, real):
     blob = a.export_state()
     advance(a, 3)
     seen = set()
-    for waves in (1, 4, 11):
+    for waves in ((1, 2, 3) if real else (1, 4, 11)):  # (Gaussian J: 3 super-chunks of 1024 elements)
         b = fresh(waves)
         seen.add(b.describe())
         b.import_state(blob)
