@@ -245,7 +245,7 @@ long long t2_row_bits(int n) { return ((long long)n + 127) / 128 * 128; }  // 16
 // waves per CU) is best as long as every wave keeps >= 4 KiB of the row in flight and W
 // balances the four SIMDs; row padding is paid on every read, so it dominates the cost.
 bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
-                     int max_cpw = sga::MAX_CPW) {
+                     int max_cpw = sga::MAX_CPW, int unit = 1 /* 1-KiB chunks per counted unit */) {
     const int C = (n + epc - 1) / epc;
     // A wave beyond the row's last chunk would hold nothing but pad lanes (every lane redirected
     // to the row's first granule against zero pad spins): a forced count is clamped to the chunk
@@ -262,11 +262,11 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
         if (w > C && w > 1) continue;
         const double pad = (double)(w * cpw - C) / C;
         double cost = 4.0 * pad + 0.05 * std::fabs(std::log2(w / target));
-        if (cpw < 4 && w > 1) cost += 0.5 * (4 - cpw);   // too little in flight per wave
+        if (cpw * unit < 4 && w > 1) cost += 0.5 * (4 - cpw * unit);   // too little in flight per wave
         if (w > 2 && (w % 4) != 0) cost += 0.03;          // uneven over the 4 SIMDs
         // 9-10 chunks: at the edge of the register file, no look-ahead form (n = 10^4 fp32,
         // 4096 replicas: 4 waves x 10 chunks 1.53e8 attempts/s, 5-16 waves 1.9-2.0e8)
-        if (cpw > 8) cost += 0.2;
+        if (cpw * unit > 8) cost += 0.2;
         if (cost < best_cost) {
             best_cost = cost;
             W = w;
@@ -344,7 +344,7 @@ int ensure_packed(sga_engine *e) {
         // canonical summation order: a wave owns whole super-chunks of 4 chunks (1024 fp32 elements),
         // one or two of them in registers; longer rows take the streaming form on 16 waves
         int S;
-        choose_geometry(e->n, 4 * elems_per_chunk(false), std::max(e->R, 1), e->tune_waves, W, S, 2);
+        choose_geometry(e->n, 4 * elems_per_chunk(false), std::max(e->R, 1), e->tune_waves, W, S, 2, 4);
         CPW = 4 * S;
         ld = (long long)W * CPW * elems_per_chunk(false);
         if (e->waves == W && e->cpw == CPW && e->ld == ld) return SGA_OK;
