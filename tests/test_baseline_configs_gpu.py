@@ -580,6 +580,39 @@ def test_single_site_operators_use_the_canonical_order_dense(sg):
         assert np.array_equal(e.spins(1), s[1])
 
 
+@pytest.mark.parametrize("kind", ["pm1", "int8", "gauss"])
+def test_device_matrix_with_a_row_stride_is_packed_where_it_lies(sg, kind):
+    """sga_set_dense scans and packs a device matrix in place (no engine copy): a strided view
+    (row stride > n) of a larger tensor gives the same chain as its contiguous copy and the oracle."""
+    n, big, R, ns, seed = 1500, 2304, 3, 2, 88
+    rng = np.random.RandomState(2)
+    vals = {"pm1": rng.randint(0, 2, (n, n)) * 2 - 1, "int8": rng.randint(-90, 91, (n, n)),
+            "gauss": rng.randn(n, n)}[kind]
+    J = np.triu(vals, 1).astype(np.float32)
+    J = J + J.T
+    h = rng.randn(n).astype(np.float32) if kind == "gauss" else rng.randint(-2, 3, n).astype(np.float32)
+    canvas = torch.full((big, big), 7.5, device="cuda")      # what lies beside the view must not matter
+    canvas[:n, :n] = torch.from_numpy(J).cuda()
+    view = canvas[:n, :n]
+    assert view.stride(0) == big and not view.is_contiguous()
+    temps = ladder(R, 20.0 if kind == "int8" else 4.0, 0.5)
+    prob = oracle.Problem(J=J, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
+    for src in (view, view.contiguous(), J):
+        with sg.AnnealEngine(0) as e:
+            e.set_dense(src, h)
+            e.init_replicas(R, seed=seed)
+            d = e.describe()
+            assert {"pm1": "storage=i8", "int8": "storage=i8", "gauss": "acc=f64-canonical"}[kind] in d, d
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            assert np.array_equal(e.spins(), s), d
+            if kind != "gauss":
+                assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+    assert float(canvas[n, n]) == 7.5 and float(canvas[0, n]) == 7.5
+
+
 @pytest.mark.parametrize("real", [False, True])
 def test_checkpoint_moves_between_launch_geometries(sg, real):
     """A state exported after sga_autotune / with one waves-per-replica continues bit-exactly
