@@ -179,29 +179,38 @@ def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without torchrun: this process has made no GPU call yet; it
     starts N child processes of the same command line, one rank per GPU, with the rendezvous in
     the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relays rank 0's
-    JSON line and fails if any rank fails.  (Children are started, never exec'ed into.)"""
+    JSON line and fails if any rank fails.  (Children are started, never exec'ed into; a rank that
+    dies takes the others down with it -- exactly those PIDs -- instead of leaving them waiting in a
+    collective.)"""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     procs = []
-    for rank in range(n_ranks):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:  # a rank left behind by a failed peer: stop exactly it
-            p.kill()
-            codes.append(p.wait())
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    with tempfile.TemporaryFile() as out0:
+        for rank in range(n_ranks):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if rank == 0 else sys.stderr))
+        codes = [None] * n_ranks
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):  # one rank failed: stop the rest
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.kill()
+                        codes[r] = p.wait()
+                break
+            time.sleep(0.2)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
