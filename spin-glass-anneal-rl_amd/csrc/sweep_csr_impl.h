@@ -1,25 +1,22 @@
-// sweep_csr_impl.h -- single-spin sweep over CSR couplings (BASELINE config 3: N = 10k, degree
-// ~32, 4096 replicas).
+// sweep_csr_impl.h -- single-spin sweeps over CSR couplings: BASELINE configs[2] (10 000 spins, degree
+// ~32, 4096 replicas), configs[3] (50 000 spins, degree 598) and configs[4] (TSP, up to 10^6 spins).
 //
 // Replaces the same reference functions as the dense kernel (core/spin_dynamics.py:73-94,
 // core/ising_model.py:176-185) for IsingModelConfig(use_sparse=True) models; the reference's
 // own sparse branch (ising_model.py:133-135) raises under the container's torch, so the math
 // is the dense path's with the row restricted to its stored entries.
 //
-// Mapping: one replica per wavefront, up to CSR_WAVES_PER_BLOCK independent replicas per
-// workgroup (as many as fit LDS: 4 up to n = 40k, 2 up to 80k, 1 up to 160k) (no workgroup barrier anywhere: each wave owns a private LDS slice holding its
-// replica's spins).  A row has ~32 entries, i.e. one (colidx, val) wave-load each; the spin
-// gather goes through LDS; the dot is a DPP wave sum.  The structure (2.6 MB at C3) is
-// L2-resident, so the kernel is bound by instruction issue and the dependent-load chain,
-// not by HBM; hence:
-//   * the site sequence is known ahead of time (counter RNG): row extents are loaded one
-//     PAIR of updates ahead and row entries one update ahead, so no update waits on a
-//     rowptr -> colidx dependent load;
-//   * FAST variant (integer-valued J and h, sum_j |J_ij| + |h_i| <= M small): the row sum is
-//     accumulated in fp32 (exact), and the Metropolis probability exp(float32(-dE/T)) of the
-//     M possible uphill moves dE = 2k is tabulated in LDS once per sweep -- the same function
-//     of the same arguments, so decisions are bit-identical to the general path -- which
-//     removes the fp64 divide and the exp from the per-update chain.
+// NARROW forms: one replica per wavefront, up to CSR_WAVES_PER_BLOCK independent replicas per
+// workgroup (as many as fit LDS), no workgroup barrier anywhere: each wave owns a private LDS slice
+// holding its replica's spins (int8, or bits when that keeps more replicas resident).  A row of ~32
+// entries is one (column, value) wave-load; the spin gather goes through LDS; the dot is a DPP wave
+// sum.  The structure (2.6 MB at C3) is L2-resident, so these forms are bound by instruction issue
+// and the dependent-load chain, not by HBM; hence:
+//   * the site sequence is known ahead of time (counter RNG): row extents are loaded one PAIR of
+//     updates ahead and row entries one update ahead, so no update waits on a rowptr -> entry load;
+//   * integer-valued problems accumulate in fp32 (exact) and look the Metropolis probability
+//     exp(float32(-dE/T)) of the M possible uphill moves dE = 2k up in a per-sweep LDS table -- the
+//     same function of the same arguments, so decisions are bit-identical to the general path.
 #pragma once
 #include "sweep_common.h"
 
@@ -31,24 +28,23 @@ constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight toget
 #endif
 constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (16 measured slower)
 
-// WIDE = several waves per replica (long rows, few replicas): one replica per workgroup, the
-// row's entries are dealt to the waves in 64-entry slices, the per-wave sums meet in LDS with
-// one barrier per update (double-buffered slots, as in the dense kernel).  Every wave applies
-// an accepted flip to the shared spin byte itself before its next gather (same value from all
-// waves), so no second barrier is needed.
+// WIDE = one replica per workgroup, its row dealt to NW = 1, 2, 4 or 8 waves in 64-entry SLOTS of
+// the padded row layout (slot w + NW q is wave-uniform: scalar addressing, no per-lane bounds
+// tests), the per-wave sums meet in LDS with one barrier per update (double-buffered slots, as in
+// the dense kernel).  Every wave applies an accepted flip to the shared spin itself before its
+// next gather (same value from all waves), so no second barrier is needed.
 //
-// BIG (a WIDE form) = problems beyond the int8 LDS capacity (n > ~160k; BASELINE config 5 at 1000
-// cities is n = 10^6) or with nnz >= 2^31: the replica's spins sit in LDS as one bit each (1 =
-// spin down; 125 KB at n = 10^6), row extents are 64-bit, flips are idempotent LDS atomics
-// (or / and-not) so that every wave can still apply them itself.
+// BIG = the replica's spins sit in LDS as one bit each (1 = spin down; 125 KB at n = 10^6): problems
+// beyond the int8 LDS capacity, or whose int8 spins would not keep the whole launch resident; flips
+// are idempotent LDS atomics (or / and-not) so that every wave can still apply them itself.
 //
-// Real-valued problems (FAST = false) sum a row in a CANONICAL ORDER that no launch geometry
-// changes: entry e of the row (storage order) belongs to lane e % 64 of virtual wave (e / 64) % 8;
+// The CANONICAL ORDER of the real-valued row sums whose fp64 sum is not provably exact, which no
+// launch geometry changes: entry e of the row (storage order) belongs to lane e % 64 of virtual wave (e / 64) % 8;
 // a virtual lane adds its entries in storage order (fp64), each virtual wave folds its 64 lanes by
 // the adjacent-pairs tree (wave_sum), and the 8 wave sums are added in order.  A replica dealt to
 // NW = 1, 2, 4 or 8 real waves reproduces that exactly with 8 / NW accumulators per lane (NW is a
 // template parameter of the wide real-valued builds, so every accumulator index is a constant);
-// the CPU checker forms the same sum (DESIGN.md 3).
+// the CPU checker forms the same sum (DESIGN.md 2).
 // ACC = how a row sum is formed (CSR_ACC_*, chosen at set time): fp32 where that is exact
 // (integer J), with the accept table if h is integer too and the moves are few; fp64 in any order
 // where THAT is exact (all J within 53 binary places of each other, row length included -- e.g. the
