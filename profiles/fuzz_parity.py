@@ -12,7 +12,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 n_cases = n_fail = 0
+t_note = time.time()
 while time.time() < t_end:
+    if time.time() - t_note > 60.0:  # a long run keeps talking (the GPU pool takes silence for a hang)
+        print(f"... {n_cases} cases, {n_fail} failures so far", flush=True)
+        t_note = time.time()
     kind = rng.choice(["dense", "dense", "csr"])
     sizes = [1, 2, 3, 5, 8, 17, 64, 65, 200, 255, 256, 257, 700, 1023, 1025, 2049, 3000, 5000]
     if os.environ.get("FUZZ_BIG"):
