@@ -31,8 +31,8 @@
  *
  * Pointers: every user buffer may be a host pointer or a device pointer on the engine's device
  * (copies use hipMemcpyDefault); PyTorch-ROCm tensors are passed as tensor.data_ptr().  J / h
- * are repacked into engine-owned HBM at set time, so the caller's tensors are not borrowed
- * after the call returns.  Calls on one handle must be serialised by the caller; different
+ * are packed into engine-owned HBM at set time (device buffers are read in place, never copied
+ * whole), so the caller's tensors are not borrowed after the call returns.  Calls on one handle must be serialised by the caller; different
  * handles are independent.  No call throws; on failure a negative code is returned and
  * sga_last_error() (thread-local) describes it.
  */
@@ -98,8 +98,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 /* CSR couplings (both triangles present), rowptr[n+1], colidx[nnz], val[nnz], h[n]; host or
  * device pointers.  The structure is checked on the device (SGA_ERR_INVALID for extents that are
  * not monotone / do not span [0, nnz], or a column outside [0, n)); rows need not be sorted and
- * duplicates add up.  The arrays are copied (interleaved into (column, value) entries); the
- * caller's buffers are not referenced after the call. */
+ * duplicates add up.  The arrays are read where they lie (device) or through a staging copy (host)
+ * and packed into the engine's layout -- (column, value) entries interleaved, rows of long-row
+ * problems padded to whole 64-entry slots; the caller's buffers are not referenced after the call.
+ * The same pass classifies how a row sum can be formed exactly (integer / fp64-exact / canonical
+ * order, see sga_describe's "path=" and DESIGN.md 2). */
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
                 const float *h, int n, int64_t nnz);
 /* Same with 64-bit row extents, for nnz >= 2^31 (BASELINE config 5 at 1000 cities: n = 10^6,
