@@ -13,6 +13,9 @@ namespace sga {
 struct UpdatePair {
     int sA, sB;
     float uA, uB;
+    // production (Philox) streams: the uniforms' 24 raw bits, u = r * 2^-24 -- a table of integer
+    // thresholds ceil(p * 2^24) decides u < p without converting u (r < ceil(p 2^24) <=> u < p)
+    uint32_t rA = 0, rB = 0;
 };
 
 // Kernels are compiled twice: LEAN = the production configuration (Philox random sites, the
@@ -107,8 +110,10 @@ struct PairSource {
             const int l = b & 63;
             o.sA = __builtin_amdgcn_readlane((int)vsa, l);
             o.sB = __builtin_amdgcn_readlane((int)vsb, l);
-            o.uA = word_to_u((uint32_t)__builtin_amdgcn_readlane((int)vua, l));
-            o.uB = word_to_u((uint32_t)__builtin_amdgcn_readlane((int)vub, l));
+            o.rA = (uint32_t)__builtin_amdgcn_readlane((int)vua, l) >> 8;
+            o.rB = (uint32_t)__builtin_amdgcn_readlane((int)vub, l) >> 8;
+            o.uA = (float)o.rA * 0x1.0p-24f;
+            o.uB = (float)o.rB * 0x1.0p-24f;
             return o;
         }
     }
