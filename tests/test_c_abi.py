@@ -1,0 +1,37 @@
+"""The boundary is a C ABI: include/sga.h compiles as C99 on its own, and a plain-C program
+(tests/c_abi/abi_smoke.c, gcc, no torch, no Python) drives the engine through libsga.so."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+CSRC = os.path.join(ROOT, "spin-glass-anneal-rl_amd", "csrc")
+SRC = os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", INC, SRC, "-o", exe, "-L", CSRC, "-lsga",
+                    "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True)
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                    os.path.join(INC, "sga.h")], check=True, capture_output=True)
+    exe = _build(tmp_path)
+    assert os.path.exists(exe)
+    import torch
+    if torch.cuda.device_count() == 0:   # no GPU here: the program reports the device error code, no fallback
+        p = subprocess.run([exe], capture_output=True, text=True)
+        assert p.returncode == 3 and "NO_DEVICE" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_program_runs_the_engine(tmp_path):
+    p = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith("OK version="), (p.returncode, p.stdout, p.stderr)
