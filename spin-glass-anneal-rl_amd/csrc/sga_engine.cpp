@@ -138,7 +138,7 @@ struct sga_engine {
     int waves = 0, cpw = 0;
     int32_t *rowptr = nullptr, *colidx = nullptr;  // rowptr: only while the layout has < 2^31 entries
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels)
-    int32_t *rowslot = nullptr;  // slotted layout: row extents in 64-entry slots (wide sweep forms)
+    int4 *rowinfo = nullptr;     // slotted layout, per row: first slot, slots, offset of a zero slot, h (wide sweep forms)
     bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
     long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
     long long max_row_len = 0;     // entries of the longest row
@@ -200,7 +200,7 @@ struct sga_engine {
         use_t2 = false;
         dev_free(rowptr);
         dev_free(rowptr64);
-        dev_free(rowslot);
+        dev_free(rowinfo);
         slotted = false;
         dev_free(colidx);
         dev_free(val);
@@ -707,26 +707,52 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 
 // Row extents of the layout the kernels read: dst[i] = prefix sum of the rows' lengths, each rounded
 // up to whole 64-entry slots when `slotted`.  n <= ~1.3e6 rows: done on the host at set time.
+//
+// Slotted layouts also get the wide forms' per-row record (rowinfo: first slot, slot count, slots
+// from the first slot to an all-zero slot, h): a wave asks for a fixed number of slots per row and
+// the ones past the row's end read that zero slot (value 0: nothing to mask when the row is
+// summed).  The zero slot is the 64 zeroed entries behind the array; layouts beyond 2^21 slots
+// (1 GB) get one more inside after every 2^21 slots -- it rides at the end of the row before it,
+// like slot padding -- so that the offset always fits the 32-bit lane offset of a load.
 static int build_layout(sga_engine *e, const std::vector<long long> &src, bool slotted) {
     const int n = e->n;
+    constexpr long long ZERO_SLOT_EVERY = 1ll << 21;
     std::vector<long long> dst((size_t)n + 1);
-    std::vector<int32_t> slots(slotted ? (size_t)n + 1 : 0), narrow;
-    long long at = 0;
+    std::vector<int4> info(slotted ? (size_t)n : 0);
+    std::vector<int32_t> narrow;
+    std::vector<std::pair<int, long long>> zero_after;  // (row, slot number) of the zero slots inside
+    long long at = 0, since = 0;
     for (int i = 0; i < n; ++i) {
         dst[(size_t)i] = at;
-        if (slotted) slots[(size_t)i] = (int32_t)(at >> 6);
         const long long len = src[(size_t)i + 1] - src[(size_t)i];
         // (src may be a padded layout being re-padded: slot padding never adds a slot)
         e->max_row_len = i == 0 ? len : std::max(e->max_row_len, len);
-        at += slotted ? (len + 63) / 64 * 64 : len;
+        if (!slotted) {
+            at += len;
+            continue;
+        }
+        const long long slots = (len + 63) / 64;
+        info[(size_t)i] = make_int4((int)(at >> 6), (int)slots, 0, 0);
+        at += slots * 64;
+        since += slots;
+        if (since >= ZERO_SLOT_EVERY && i + 1 < n) {
+            zero_after.emplace_back(i, at >> 6);
+            at += 64;
+            since = 0;
+        }
     }
     dst[(size_t)n] = at;
     if (slotted) {
         if ((at >> 6) >= (long long)INT32_MAX) return fail(SGA_ERR_UNSUPPORTED, "CSR problem too large");
-        slots[(size_t)n] = (int32_t)(at >> 6);
+        zero_after.emplace_back(n - 1, at >> 6);  // the zeroed entries behind the array
+        size_t z = 0;
+        for (int i = 0; i < n; ++i) {
+            while (zero_after[z].first < i) ++z;
+            info[(size_t)i].z = (int)(zero_after[z].second - info[(size_t)i].x);
+        }
     }
     dev_free(e->rowptr);
-    dev_free(e->rowslot);
+    dev_free(e->rowinfo);
     const size_t np1 = (size_t)n + 1;
     HIPCHK(hipMemcpyAsync(e->rowptr64, dst.data(), sizeof(long long) * np1, hipMemcpyHostToDevice, e->stream));
     if (at < (long long)INT32_MAX) {
@@ -735,8 +761,9 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
         HIPCHK(hipMemcpyAsync(e->rowptr, narrow.data(), sizeof(int32_t) * np1, hipMemcpyHostToDevice, e->stream));
     }
     if (slotted) {
-        HIPCHK(hipMalloc(&e->rowslot, sizeof(int32_t) * np1));
-        HIPCHK(hipMemcpyAsync(e->rowslot, slots.data(), sizeof(int32_t) * np1, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMalloc(&e->rowinfo, sizeof(int4) * (size_t)n));
+        HIPCHK(hipMemcpyAsync(e->rowinfo, info.data(), sizeof(int4) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(sga::launch_rowinfo_fields(e->rowinfo, e->h, n, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));  // the host vectors go out of scope
     e->slotted = slotted;
@@ -1276,7 +1303,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.J = e->J_packed;
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
-        a.rowslot = e->rowslot;
+        a.rowinfo = e->rowinfo;
         a.csr_acc = e->csr_acc;  // (the table form needs its table: set below once table_m is final)
         {   // head slots per wave that the longest row needs (the wide bit forms are built per count)
             const long long slots = (e->max_row_len + 63) / 64;

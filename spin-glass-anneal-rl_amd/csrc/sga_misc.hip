@@ -260,6 +260,16 @@ hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_pt
     return hipGetLastError();
 }
 
+// the wide forms' per-row record carries the row's field (one 16-byte load per extent)
+__global__ void rowinfo_fields_kernel(int4 *rowinfo, const float *h, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rowinfo[i].w = __float_as_int(h[i]);
+}
+hipError_t launch_rowinfo_fields(int4 *rowinfo, const float *h, int n, hipStream_t st) {
+    hipLaunchKernelGGL(rowinfo_fields_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowinfo, h, n);
+    return hipGetLastError();
+}
+
 __global__ void widen_rowptr_kernel(const int32_t *src, long long *dst, long long count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i];

@@ -55,11 +55,11 @@ hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream
             if (wpb < 1) return hipErrorInvalidValue;
             return launch_csr_narrow<true>(a, wpb, st);
         }
-        if (!a.rowslot) return hipErrorInvalidValue;  // wide forms read the slotted layout
+        if (!a.rowinfo) return hipErrorInvalidValue;  // wide forms read the slotted layout
         return launch_csr_wide_bits(a, waves_per_replica, a.csr_head, st);
     }
     if (waves_per_replica > 1) {
-        if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1 || !a.rowslot)
+        if (waves_per_replica > CSR_MAX_WIDE || csr_waves_per_block(a.sstride, a.table_m) < 1 || !a.rowinfo)
             return hipErrorInvalidValue;
         return launch_csr_wide_bytes(a, waves_per_replica, st);
     }

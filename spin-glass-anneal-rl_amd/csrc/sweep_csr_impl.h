@@ -63,12 +63,14 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     // (the production wide builds are made per wave count as well: with the slot arithmetic and
     // the cross-wave sum on constants the 1000-city instance runs 12 % faster)
     // Row extents: the narrow forms (one wave per replica) index entries (a.rowptr, 32 bit); the
-    // wide forms address a row by its 64-entry SLOTS (a.rowslot: rows are padded to whole slots,
-    // pad entries carry the value 0), so a slot number is wave-uniform: the address arithmetic is
-    // scalar and no lane tests a bound.  32-bit slot numbers cover nnz >= 2^31 (config 5 at 1000
-    // cities: 63 M slots).
+    // wide forms address a row by its 64-entry SLOTS (a.rowinfo: rows are padded to whole slots,
+    // pad entries carry the value 0), so a slot number is wave-uniform: no lane tests a bound.
+    // 32-bit slot numbers cover nnz >= 2^31 (config 5 at 1000 cities: 63 M slots).  A wave asks
+    // for a fixed number of slots per row; the ones past the row's end are redirected to an
+    // all-zero slot (rowinfo.z slots from the row's first), so nothing is masked when the row is
+    // summed: per slot one scalar select, one VALU op for the lane offset and the load.
     using rp_t = int;
-    const rp_t *rowptr = WIDE ? a.rowslot : a.rowptr;
+    const rp_t *rowptr = a.rowptr;
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;  // (a run-time rule costs C3 12 %: issue bound)
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,7 +131,8 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     unsigned long long nacc = 0;
 
     struct Extent {  // what is indexed by the site alone
-        rp_t beg, end;
+        rp_t beg, end;  // entries [beg, end) | wide forms: first slot, slot count
+        int zrel;       // wide forms: slots from the first slot to an all-zero slot
         float h, d;
     };
     // The entries of a row requested one update ahead: its first 64 (one per lane) in the narrow
@@ -140,47 +143,55 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     struct Head {
         int col[HEAD];
         float val[HEAD];
-        int len;                  // wide forms: the row's slot count (wave-uniform)
+        int len, zrel;            // wide forms: the row's slot count, its zero slot (wave-uniform)
         const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer)
     };
     // wave-uniform value -> SGPR
     auto uniform = [&](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
-    // this lane's entry of slot `slot` (wave-uniform) of the row starting at `row` (wave-uniform):
-    // scalar base + one constant 32-bit lane offset = the scalar-base load form
+    // this lane's entry of slot `slot` (wave-uniform, < 2^23) of the row starting at `row`
+    // (wave-uniform): scalar base + 32-bit lane offset (slot * 512 + lane * 8, one VALU op) = the
+    // scalar-base load form
     const unsigned int lane8 = (unsigned int)lane * 8u;
     auto slot_entry = [&](const int2 *row, int slot) -> int2 {
-        const unsigned char *p = reinterpret_cast<const unsigned char *>(row) +
-                                 ((unsigned long long)(unsigned int)slot << 9);
-        // the lane offset stays a 32-bit value opaque to the optimiser (a hoisted 64-bit
-        // zero extension of it loses the base + zext(VGPR) address form)
-        unsigned int off = lane8;
+        // the offset stays a 32-bit value opaque to the optimiser (a 64-bit zero extension of
+        // it folded into the pointer arithmetic loses the base + zext(VGPR) address form)
+        unsigned int off = ((unsigned int)slot << 9) + lane8;
         asm volatile("" : "+v"(off));
-        return *reinterpret_cast<const int2 *>(p + off);
+        return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
     };
     const int nwc = (WIDE && NW > 0) ? NW : nw;  // waves of this replica (a constant in the real-valued wide builds)
     auto load_extent = [&](int site) {
         Extent o;
-        o.beg = rowptr[site];
-        o.end = rowptr[site + 1];
-        o.h = a.h[site];
+        if constexpr (WIDE) {
+            const int4 ri = a.rowinfo[site];  // one 16-byte load
+            o.beg = ri.x;
+            o.end = ri.y;
+            o.zrel = ri.z;
+            o.h = __int_as_float(ri.w);
+        } else {
+            o.beg = rowptr[site];
+            o.end = rowptr[site + 1];
+            o.zrel = 0;
+            o.h = a.h[site];
+        }
         o.d = arith32 ? a.diag[site] : 0.0f;
         return o;
     };
     auto load_head = [&](const Extent &x) {
         Head o;
         o.len = 0;
+        o.zrel = 0;
         o.row = nullptr;
         if constexpr (WIDE) {
             // HEAD slots per wave: slot w + nw q of the row, q = 0..HEAD-1.  The extent arrived
-            // updates ago: pin it to SGPRs.  A slot past the row's end re-reads slot 0 (no extra
-            // traffic) and its values are zeroed by a wave-uniform select when used.
-            const int beg = uniform(x.beg);
-            o.len = uniform(x.end) - beg;
-            o.row = a.cv + ((long long)beg << 6);
+            // updates ago: pin it to SGPRs.  A slot past the row's end reads the zero slot.
+            o.len = uniform(x.end);
+            o.zrel = uniform(x.zrel);
+            o.row = a.cv + ((long long)uniform(x.beg) << 6);
 #pragma unroll
             for (int q = 0; q < HEAD; ++q) {
                 const int sq = w + nwc * q;
-                const int2 ent = slot_entry(o.row, sq < o.len ? sq : 0);
+                const int2 ent = slot_entry(o.row, sq < o.len ? sq : o.zrel);
                 o.col[q] = ent.x;
                 o.val[q] = __int_as_float(ent.y);
             }
@@ -212,15 +223,14 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
 #pragma unroll
             for (int j = 0; j < NVA; ++j) acc[j] = 0;
             if constexpr (WIDE) {
-                // Every head slot is computed; the values of a slot past the row's end are zeroed by a
-                // wave-uniform select.  Measured against one wave-uniform branch per slot and against a
+                // Every head slot is computed; a slot past the row's end holds the zero slot's entries
+                // (value 0).  Measured against one wave-uniform branch per slot and against a
                 // straight-line block per valid-slot count (same box, profiles/r02_experiments.md): the
                 // branch-free form wins on both graded instances -- C4 49.3 vs 57.8 / 55.4 ms per sweep,
                 // C5 at 1000 cities 1478 vs 1699 / 1597 ms -- because the LDS gathers of all eight
                 // slots stay in flight together.  Virtual wave of slot q: (w + nw q) % 8 -> q % NVA.
 #pragma unroll
-                for (int q = 0; q < HEAD; ++q)
-                    acc[q % NVA] += (acc_t)term((w + nwc * q) < hd.len ? hd.val[q] : 0.0f, hd.col[q]);
+                for (int q = 0; q < HEAD; ++q) acc[q % NVA] += (acc_t)term(hd.val[q], hd.col[q]);
                 // rows beyond HEAD slots per wave (degree > 4096 at 8 waves): eight more slots per pass
                 for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
@@ -228,9 +238,9 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) {
                         const int sq = s0 + w + nwc * q;
-                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : 0);
+                        const int2 ent = slot_entry(hd.row, sq < hd.len ? sq : hd.zrel);
                         c[q] = ent.x;
-                        v[q] = sq < hd.len ? __int_as_float(ent.y) : 0.0f;
+                        v[q] = __int_as_float(ent.y);
                     }
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NVA] += (acc_t)term(v[q], c[q]);
@@ -396,22 +406,30 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         for (int j = 0; j + 1 < NB; ++j) request_extent(er[j]);
 #pragma unroll
         for (int j = 0; j + 1 < NH; ++j) hr[j] = load_head(er[j].x);
-        const long long total = (long long)a.n_sweeps * n;
-        int k = 0, t = 0;
-        for (long long g0 = 0; g0 < total; g0 += NB) {
+        // A sweep = whole groups of NB updates (every ring index a constant), then the < NB left
+        // over one at a time with the rings shifted back into phase (register moves, a few per
+        // sweep), so that the per-sweep work stays outside the unrolled body.
+        for (int k = 0; k < a.n_sweeps; ++k) {
+            sweep_start(k);
+            int t = 0;
+            for (; t + NB <= n; t += NB) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (g0 + j >= total) break;  // workgroup-uniform
-                if (t == 0) sweep_start(k);
-                request_extent(er[(j + NB - 1) % NB]);
-                hr[(j + NH - 1) % NH] = load_head(er[(j + NH - 1) % NB].x);
-                update(er[j].site, er[j].u, er[j].ru, er[j].x, hr[j % NH], g0 + j);
-                if (++t == n) {
-                    sweep_end(k);
-                    t = 0;
-                    ++k;
+                for (int j = 0; j < NB; ++j) {
+                    request_extent(er[(j + NB - 1) % NB]);
+                    hr[(j + NH - 1) % NH] = load_head(er[(j + NH - 1) % NB].x);
+                    update(er[j].site, er[j].u, er[j].ru, er[j].x, hr[j % NH], (long long)k * n + t + j);
                 }
             }
+            for (; t < n; ++t) {
+                request_extent(er[NB - 1]);
+                hr[NH - 1] = load_head(er[NH - 1].x);
+                update(er[0].site, er[0].u, er[0].ru, er[0].x, hr[0], (long long)k * n + t);
+#pragma unroll
+                for (int j = 0; j + 1 < NB; ++j) er[j] = er[j + 1];
+#pragma unroll
+                for (int j = 0; j + 1 < NH; ++j) hr[j] = hr[j + 1];
+            }
+            sweep_end(k);
         }
     } else {
         // Pairs of updates (one Philox block each); the extents of the next pair and the head of its
