@@ -24,7 +24,7 @@ namespace sga {
 
 constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight together
 #ifndef CSR_WIDE_ROWS_AHEAD
-#define CSR_WIDE_ROWS_AHEAD 2    // wide forms: rows requested this many updates before their reduction
+#define CSR_WIDE_ROWS_AHEAD 1    // wide forms: rows requested this many updates before their reduction
 #endif
 constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (16 measured slower)
 
@@ -366,13 +366,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
 
     PairSource<LEAN> rng;
     if constexpr (BIG && WIDE && LEAN) {
-        // HBM-resident structures (C5 at 500 / 1000 cities: 4 / 32 GB): an update lasts ~2 us
-        // (row gather + reduce + barrier), about one loaded HBM round trip, so rows are requested
-        // NH - 1 = 2 updates ahead and their extents NB - 1 updates ahead (two rings, NB a
-        // multiple of NH so that every index is a compile-time constant after unrolling).  The
-        // extent of a row has to be back before its entries can be requested; vmcnt retires in
-        // order, so the gap NB - NH keeps that wait from draining the rows requested in between.
-        // +7 % there.  (A two-update look-ahead -- both rows reduced together, one barrier, the second
+        // Rows are requested CSR_WIDE_ROWS_AHEAD updates before they are reduced and their extents
+        // NB - 1 updates before (two rings, NB a multiple of NH so that every index is a
+        // compile-time constant after unrolling).  The extent of a row has to be back before its
+        // entries can be requested; vmcnt retires in order, so the gap NB - NH keeps that wait from
+        // draining the rows requested in between.  Same-box A/B of 1 / 2 / 3 rows ahead after the
+        // zero-slot change (profiles/ab_wide_r02.sh): C4 34.7 / 35.6 / 35.6 ms per sweep, C5 at
+        // 1000 cities (32 GB, HBM resident) 1315 / 1315 / 1318 ms: one row ahead is enough -- an
+        // update lasts ~0.7-5 us, several loaded HBM round trips.
+        // (A two-update look-ahead -- both rows reduced together, one barrier, the second
         // row sum corrected by -2 J[B][A] s_A when the first flips -- was built, verified against the
         // oracle and measured in round 2: 25 % SLOWER at C4, 16 % at C5-1000, with 128 or 256 VGPRs;
         // see profiles/r02_experiments.md.  The chain, not the barrier, is what an update costs.)
