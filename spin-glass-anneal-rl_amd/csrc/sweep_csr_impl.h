@@ -26,6 +26,14 @@ constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight toget
 #ifndef CSR_WIDE_ROWS_AHEAD
 #define CSR_WIDE_ROWS_AHEAD 1    // wide forms: rows requested this many updates before their reduction
 #endif
+// Row records of the wide forms through the scalar cache (1) or as a vector load (0).  An LDS wait
+// with scalar loads in flight has to be lgkmcnt(0) (they return out of order), so the record
+// requested at the top of an update is waited for by that update's first spin gather: same-box A/B
+// (profiles/ab3.sh) C4 37.1 vs 34.8 ms per sweep, C5 at 1000 cities 1263-1302 vs 1286-1295 ms ->
+// vector loads (in-order vmcnt).  The narrow forms, 4 waves per SIMD, gain 1-2 % from the scalar loads.
+#ifndef CSR_WIDE_SCALAR_EXTENTS
+#define CSR_WIDE_SCALAR_EXTENTS 0
+#endif
 constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (16 measured slower)
 
 // WIDE = one replica per workgroup, its row dealt to NW = 1, 2, 4 or 8 waves in 64-entry SLOTS of
@@ -148,6 +156,12 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     };
     // wave-uniform value -> SGPR
     auto uniform = [&](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+    // Narrow forms: what is indexed by the (wave-uniform) site comes through the scalar data cache:
+    // s_load into SGPRs -- no address VALU, no vector-memory slot, no readfirstlane when the value
+    // is used as a scalar.  (The arrays are written at set time only; the cast to the constant
+    // address space is what makes the compiler pick the scalar load.)
+    auto sload_i = [&](const int *q) -> int { return *(const __attribute__((address_space(4))) int *)q; };
+    auto sload_f = [&](const float *q) -> float { return *(const __attribute__((address_space(4))) float *)q; };
     // this lane's entry of slot `slot` (wave-uniform, < 2^23) of the row starting at `row`
     // (wave-uniform): scalar base + 32-bit lane offset (slot * 512 + lane * 8, one VALU op) = the
     // scalar-base load form
@@ -162,19 +176,25 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     const int nwc = (WIDE && NW > 0) ? NW : nw;  // waves of this replica (a constant in the real-valued wide builds)
     auto load_extent = [&](int site) {
         Extent o;
+        const int us = uniform(site);
         if constexpr (WIDE) {
-            const int4 ri = a.rowinfo[site];  // one 16-byte load
+#if CSR_WIDE_SCALAR_EXTENTS
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i ri = *(const __attribute__((address_space(4))) v4i *)(a.rowinfo + us);  // one 16-byte load
+#else
+            const int4 ri = a.rowinfo[us];  // one 16-byte load
+#endif
             o.beg = ri.x;
             o.end = ri.y;
             o.zrel = ri.z;
             o.h = __int_as_float(ri.w);
         } else {
-            o.beg = rowptr[site];
-            o.end = rowptr[site + 1];
+            o.beg = sload_i(rowptr + us);
+            o.end = sload_i(rowptr + us + 1);
             o.zrel = 0;
-            o.h = a.h[site];
+            o.h = sload_f(a.h + us);
         }
-        o.d = arith32 ? a.diag[site] : 0.0f;
+        o.d = arith32 ? sload_f(a.diag + us) : 0.0f;
         return o;
     };
     auto load_head = [&](const Extent &x) {
@@ -197,14 +217,16 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             }
             return o;
         }
-#pragma unroll
-        for (int q = 0; q < HEAD; ++q) {
-            const rp_t j = x.beg + first_lane + (rp_t)stride_lanes * q;
-            const bool in = j < x.end;
-            const int2 ent = in ? a.cv[j] : make_int2(0, 0);
-            o.col[q] = ent.x;
-            o.val[q] = __int_as_float(ent.y);
-        }
+        // one wave: the row's first 64 entries, scalar row base + lane offset, no bounds test (the
+        // lanes past the row's end hold entries of the rows behind it -- 64 zeroed entries follow
+        // the array -- and are masked when the row is summed)
+        static_assert(WIDE || HEAD == 1, "narrow forms: one wave-load ahead");
+        const int beg = uniform(x.beg);
+        o.len = uniform(x.end) - beg;
+        o.row = a.cv + beg;
+        const int2 ent = slot_entry(o.row, 0);
+        o.col[0] = ent.x;
+        o.val[0] = __int_as_float(ent.y);
         return o;
     };
 
@@ -219,6 +241,8 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             // of the canonical order (a single one in the exact forms, where the order is free)
             using acc_t = typename std::conditional<FAST, float, double>::type;
             constexpr int NVA = !CANON ? 1 : (WIDE ? 8 / (NW > 0 ? NW : 8) : 8);
+            // (accumulators start from their first term: 0 + x is an instruction the compiler has
+            // to keep for x = -0)
             acc_t acc[NVA];
 #pragma unroll
             for (int j = 0; j < NVA; ++j) acc[j] = 0;
@@ -230,7 +254,10 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 // C5 at 1000 cities 1478 vs 1699 / 1597 ms -- because the LDS gathers of all eight
                 // slots stay in flight together.  Virtual wave of slot q: (w + nw q) % 8 -> q % NVA.
 #pragma unroll
-                for (int q = 0; q < HEAD; ++q) acc[q % NVA] += (acc_t)term(hd.val[q], hd.col[q]);
+                for (int q = 0; q < HEAD; ++q) {
+                    if (q < NVA) acc[q] = (acc_t)term(hd.val[q], hd.col[q]);
+                    else acc[q % NVA] += (acc_t)term(hd.val[q], hd.col[q]);
+                }
                 // rows beyond HEAD slots per wave (degree > 4096 at 8 waves): eight more slots per pass
                 for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
@@ -246,21 +273,21 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                     for (int q = 0; q < TAIL_UNROLL; ++q) acc[q % NVA] += (acc_t)term(v[q], c[q]);
                 }
             } else {
-                // one wave: entry q' = 0 is the head, the tail batch t holds q' = 1 + 8 t + q, i.e.
-                // virtual wave (1 + q) % 8 of the canonical order
+                // one wave: 64-entry chunk q' = 0 of the row is the head, the tail batch t holds the
+                // chunks q' = 1 + 8 t + q, i.e. virtual wave (1 + q) % 8 of the canonical order; chunk
+                // numbers and the entries left are scalars, a lane past the row's end adds 0
                 static_assert(WIDE || (TAIL_UNROLL == 8 && HEAD == 1), "virtual wave of a tail entry = (1 + q) % 8");
-                acc[0] += (acc_t)term(hd.val[0], hd.col[0]);
-                for (rp_t j0 = x.beg + (rp_t)stride_lanes * HEAD + first_lane; j0 < x.end;
-                     j0 += stride_lanes * TAIL_UNROLL) {
+                const int len = hd.len;
+                acc[0] = (acc_t)term(lane < len ? hd.val[0] : 0.0f, hd.col[0]);
+                for (int c0 = 1; 64 * c0 < len; c0 += TAIL_UNROLL) {
                     int c[TAIL_UNROLL];
                     float v[TAIL_UNROLL];
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) {
-                        const rp_t j = j0 + stride_lanes * q;
-                        const bool in = j < x.end;
-                        const int2 ent = in ? a.cv[j] : make_int2(0, 0);
+                        const int left = len - 64 * (c0 + q);  // entries of the row from this chunk on
+                        const int2 ent = slot_entry(hd.row, left > 0 ? c0 + q : 0);
                         c[q] = ent.x;
-                        v[q] = __int_as_float(ent.y);
+                        v[q] = lane < left ? __int_as_float(ent.y) : 0.0f;
                     }
 #pragma unroll
                     for (int q = 0; q < TAIL_UNROLL; ++q) acc[(1 + q) % NVA] += (acc_t)term(v[q], c[q]);
@@ -299,7 +326,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 pp ^= 1;
                 dot = (float)t;
             } else {
-                const int len = (int)(x.end - x.beg);
+                const int len = hd.len;
                 double t = wave_sum(acc[0]);
 #pragma unroll
                 for (int j = 1; j < NVA; ++j)
