@@ -98,32 +98,36 @@ __device__ __forceinline__ double exp_det(double x) {
 
 // ---------------------------------------------------------------------------------------
 // wave64 sum.  Four DPP steps fold each 16-lane row onto every lane of the row
-// (quad_perm xor-1, xor-2, row_half_mirror, row_mirror); the four row totals are then
-// read with v_readlane and added as scalars, so the result is wave-uniform and the
-// association order is fixed: ((r0 + r1) + (r2 + r3)).  Requires EXEC = all ones.
+// (quad_perm xor-1, xor-2, row_half_mirror, row_mirror); two more carry the row totals
+// across: row_bcast:15 into rows 1 and 3 (r0 + r1, r2 + r3), row_bcast:31 into row 3, and lane 63
+// is read back -- the association order is fixed, ((r0 + r1) + (r2 + r3)), the result
+// wave-uniform.  (The rows a masked step does not write hold garbage; nothing reads them.)
+// Requires EXEC = all ones.
 // ---------------------------------------------------------------------------------------
-template <int CTRL>
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, ROWS, 0xf, true);
 }
 constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_BCAST15 = 0x142;     // lane 15 of each row -> the next row
+constexpr int DPP_ROW_BCAST31 = 0x143;     // lane 31 -> rows 2 and 3
 
-template <int CTRL>
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ float dpp_move(float v) {
-    return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+    return __builtin_bit_cast(float, dpp_i<CTRL, ROWS>(__builtin_bit_cast(int, v)));
 }
-template <int CTRL>
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ int dpp_move(int v) {
-    return dpp_i<CTRL>(v);
+    return dpp_i<CTRL, ROWS>(v);
 }
-template <int CTRL>
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ double dpp_move(double v) {
     const uint64_t b = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)dpp_i<CTRL>((int)(uint32_t)b);
-    const uint32_t hi = (uint32_t)dpp_i<CTRL>((int)(uint32_t)(b >> 32));
+    const uint32_t lo = (uint32_t)dpp_i<CTRL, ROWS>((int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)dpp_i<CTRL, ROWS>((int)(uint32_t)(b >> 32));
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ float read_lane(float v, int l) {
@@ -143,9 +147,9 @@ __device__ __forceinline__ T wave_sum(T v) {
     v += dpp_move<DPP_QUAD_XOR2>(v);
     v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_move<DPP_ROW_MIRROR>(v);
-    const T r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32),
-            r3 = read_lane(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    v += dpp_move<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_move<DPP_ROW_BCAST31, 0xc>(v);
+    return read_lane(v, 63);
 }
 
 }  // namespace sga

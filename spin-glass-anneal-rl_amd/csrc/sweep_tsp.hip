@@ -57,8 +57,9 @@ __device__ inline void tsp_store_spins(const unsigned int *bits, int8_t *dst, in
     }
 }
 
-// this lane's four cities of pass k against the columns `pm` (previous position) and `pn` (next)
-template <typename acc_t>
+// this lane's four cities of pass k against the columns `pm` (previous position) and `pn` (next);
+// FIRST: the accumulator starts from its first term (0 + x is an instruction of its own)
+template <bool FIRST = false, typename acc_t>
 __device__ __forceinline__ void tsp_accumulate(acc_t &acc, const float4 &xprev, const float4 &xnext,
                                                const unsigned int *bits, int cw, int pm, int pn, int city0) {
     const unsigned int wp = bits[pm * cw + (city0 >> 5)] >> (city0 & 31);
@@ -66,7 +67,8 @@ __device__ __forceinline__ void tsp_accumulate(acc_t &acc, const float4 &xprev, 
     auto signed_val = [](float v, unsigned int word, int q) -> float {
         return __int_as_float(__float_as_int(v) ^ (int)(((word >> q) & 1u) << 31));
     };
-    acc += (acc_t)signed_val(xprev.x, wp, 0);
+    if constexpr (FIRST) acc = (acc_t)signed_val(xprev.x, wp, 0);
+    else acc += (acc_t)signed_val(xprev.x, wp, 0);
     acc += (acc_t)signed_val(xprev.y, wp, 1);
     acc += (acc_t)signed_val(xprev.z, wp, 2);
     acc += (acc_t)signed_val(xprev.w, wp, 3);
@@ -142,8 +144,9 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_kernel(const Swe
         const int c = sl.c, p = sl.p;
         const int pm = p == 0 ? n - 1 : p - 1, pn = p == n - 1 ? 0 : p + 1;
         acc_t acc = 0;
+        tsp_accumulate<true>(acc, sl.prev[0], sl.next[0], bits, cw, pm, pn, 4 * (lane + 64 * w));
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
+        for (int k = 1; k < NP; ++k)
             tsp_accumulate(acc, sl.prev[k], sl.next[k], bits, cw, pm, pn, 4 * (lane + 64 * (w + W * k)));
         acc_t dist = wave_sum(acc);
         // what the flip needs, read before any wave can have applied THIS update's flip
@@ -183,29 +186,32 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_kernel(const Swe
         }
     };
 
+    // The row of update g + 1 is in flight while update g is reduced (two slots that swap roles);
+    // a sweep is pairs of updates plus, for an odd number of spins, one more that puts the slots
+    // back in phase -- the per-sweep work stays outside the unrolled body.
     Slot ring[2];
     produce(ring[0]);
-    const long long total = (long long)a.n_sweeps * N;
-    int k = 0, tt = 0;
-    for (long long g0 = 0; g0 < total; g0 += 2) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (g0 + j >= total) break;  // workgroup-uniform
-            if (tt == 0) T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-            produce(ring[j ^ 1]);  // the row of update g + 1, in flight while update g is reduced
-            step(ring[j], g0 + j);
-            if (++tt == N) {
-                if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
-                if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
-                    bestE = E;
-                    __syncthreads();  // every wave has applied the last flip
-                    tsp_store_spins(bits, a.best_spins + (long long)r * a.sstride, n, cw, a.sstride, tid,
-                                    (int)blockDim.x);
-                    __syncthreads();
-                }
-                tt = 0;
-                ++k;
-            }
+    for (int k = 0; k < a.n_sweeps; ++k) {
+        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        const long long g0 = (long long)k * N;
+        int tt = 0;
+        for (; tt + 2 <= N; tt += 2) {
+            produce(ring[1]);
+            step(ring[0], g0 + tt);
+            produce(ring[0]);
+            step(ring[1], g0 + tt + 1);
+        }
+        if (tt < N) {
+            produce(ring[1]);
+            step(ring[0], g0 + tt);
+            ring[0] = ring[1];
+        }
+        if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+        if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
+            bestE = E;
+            __syncthreads();  // every wave has applied the last flip
+            tsp_store_spins(bits, a.best_spins + (long long)r * a.sstride, n, cw, a.sstride, tid, (int)blockDim.x);
+            __syncthreads();
         }
     }
     __syncthreads();
