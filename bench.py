@@ -365,10 +365,9 @@ def main():
         copy_gbs = measured_copy_bandwidth(dev)
         read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
     torch.cuda.synchronize()
-    # (round 1 paused 0.3 s here to step around a rare 45-75 ms gap on the short-kernel workloads.  Its
-    # cause was found in round 2 -- the first small device-to-host copy issued while kernels are queued,
-    # profiles/r02_experiments.md 13 -- and removed in the engine; wall_ms_total vs kernel_ms_total
-    # below keeps any such gap visible.)
+    # (round 1 paused 0.3 s here to step around a rare 45-75 ms device-side gap on the short-kernel
+    # workloads; the A/B of profiles/r02_experiments.md shows the set-up's frees are not its cause.
+    # The pause is gone: wall_ms_total vs kernel_ms_total below makes any such gap visible.)
     if os.environ.get("SGA_BENCH_SETTLE"):
         time.sleep(float(os.environ["SGA_BENCH_SETTLE"]))
     for _ in range(a.warmup):

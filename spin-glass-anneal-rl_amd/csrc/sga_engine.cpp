@@ -177,12 +177,6 @@ struct sga_engine {
     int32_t *slot_to_rep = nullptr;
     long long *ex_attempts = nullptr, *ex_accepts = nullptr;
     int *d_count = nullptr;
-    // Small results (exchange counts, energies, counters) leave the GPU by a copy KERNEL that
-    // stores into pinned, device-mapped staging memory; the host copies from there once the stream
-    // has drained.  A small device-to-host hipMemcpyAsync goes through the runtime's copy path,
-    // whose first use while kernels are queued costs 30-40 ms once (profiles/r02_experiments.md 13).
-    static constexpr size_t STAGE_BYTES = 1u << 20;
-    unsigned char *h_stage = nullptr, *h_stage_dev = nullptr;
     float *wolff_u = nullptr;        // recorded uniforms of the Wolff rule [R][wolff_cap] (parity tests)
     long long *wolff_cursor = nullptr;  // [R]
     long long wolff_cap = 0;
@@ -400,40 +394,6 @@ extern "C" {
 const char *sga_last_error(void) { return g_last_error.c_str(); }
 int sga_version(void) { return 200; }  // round 2: + sga_exchange_pairs, sga_set_tsp, sga_set_wolff_replay, state blob v2
 
-// Results for the host, gathered per call: add() queues one array, finish() drains the stream and
-// hands the staged ones over.  Device destinations and anything beyond the staging buffer take
-// hipMemcpyAsync.
-struct HostOut {
-    sga_engine *e;
-    struct Item {
-        void *user;
-        size_t bytes, at;
-    };
-    Item items[4];
-    int n_items = 0;
-    size_t used = 0;
-    explicit HostOut(sga_engine *eng) : e(eng) {}
-    int add(void *user, const void *dev, size_t bytes) {
-        if (!user || bytes == 0) return SGA_OK;
-        const size_t padded = (bytes + 15) & ~(size_t)15;
-        if (is_device_ptr(user) || (bytes & 3) || n_items == 4 || used + padded > sga_engine::STAGE_BYTES) {
-            HIPCHK(hipMemcpyAsync(user, dev, bytes, hipMemcpyDefault, e->stream));
-            return SGA_OK;
-        }
-        HIPCHK(sga::launch_copy_out(dev, e->h_stage_dev + used, bytes, e->stream));
-        items[n_items++] = Item{user, bytes, used};
-        used += padded;
-        return SGA_OK;
-    }
-    int finish() {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        for (int i = 0; i < n_items; ++i) std::memcpy(items[i].user, e->h_stage + items[i].at, items[i].bytes);
-        n_items = 0;
-        used = 0;
-        return SGA_OK;
-    }
-};
-
 int sga_create(int device, sga_engine **out) {
     if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -461,12 +421,7 @@ int sga_create(int device, sga_engine **out) {
     eng->stream = eng->own_stream;
     e = hipMalloc(&eng->d_count, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&eng->d_flags, 16 * sizeof(int));
-    if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void **>(&eng->h_stage), sga_engine::STAGE_BYTES, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&eng->h_stage_dev), eng->h_stage, 0);
     if (e != hipSuccess) {
-        if (eng->h_stage) (void)hipHostFree(eng->h_stage);
-        dev_free(eng->d_flags);
         dev_free(eng->d_count);
         (void)hipStreamDestroy(eng->own_stream);
         delete eng;
@@ -491,7 +446,6 @@ void sga_destroy(sga_engine *e) {
     e->point_out.release();
     dev_free(e->d_count);
     dev_free(e->d_flags);
-    if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1636,11 +1590,8 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
     HIPCHK(sga::launch_exchange_neighbor(a, st));
     e->rounds += 1;
     if (n_accepted) {
-        if (is_device_ptr(n_accepted)) return fail(SGA_ERR_INVALID, "n_accepted must be a host pointer");
-        HostOut out(e);
-        rc = out.add(n_accepted, e->d_count, sizeof(int));
-        if (rc == SGA_OK) rc = out.finish();
-        if (rc != SGA_OK) return rc;
+        HIPCHK(hipMemcpyAsync(n_accepted, e->d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
     } else if (d_e.staged || d_u.staged || d_start.staged) {
         HIPCHK(hipStreamSynchronize(st));  // the host buffers may be reused by the caller
     }
@@ -1690,12 +1641,9 @@ int sga_exchange_pairs(sga_engine *e, const double *energies_global, const int32
     a.round = e->rounds;
     HIPCHK(sga::launch_exchange_pairs(a, d_pairs.ptr, count, st));
     e->rounds += 1;
-    // (the pair list was staged from the host: synchronise in any case)
-    int cnt = 0;
-    HostOut out(e);
-    rc = out.add(&cnt, e->d_count, sizeof(int));
-    if (rc == SGA_OK) rc = out.finish();
-    if (rc != SGA_OK) return rc;
+    int cnt = 0;  // (the pair list was staged from the host: synchronise in any case)
+    HIPCHK(hipMemcpyAsync(&cnt, e->d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     if (n_accepted) *n_accepted = cnt;
     return SGA_OK;
 }
@@ -1768,18 +1716,18 @@ int sga_get_energies(sga_engine *e, double *out) {
     if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
     HIPCHK(hipSetDevice(e->device));
-    HostOut ho(e);
-    int rc = ho.add(out, e->energy, sizeof(double) * e->R);
-    return rc == SGA_OK ? ho.finish() : rc;
+    HIPCHK(hipMemcpyAsync(out, e->energy, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
 }
 
 int sga_get_temperatures(sga_engine *e, double *out) {
     if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
     HIPCHK(hipSetDevice(e->device));
-    HostOut ho(e);
-    int rc = ho.add(out, e->rep_temp, sizeof(double) * e->R);
-    return rc == SGA_OK ? ho.finish() : rc;
+    HIPCHK(hipMemcpyAsync(out, e->rep_temp, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
 }
 
 int sga_get_spins(sga_engine *e, int r, int8_t *out) {
@@ -1850,10 +1798,9 @@ int sga_get_stats(sga_engine *e, int64_t *accepted, int64_t *attempted) {
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
     HIPCHK(hipSetDevice(e->device));
     if (accepted) {
-        HostOut ho(e);
-        int rc = ho.add(accepted, e->n_acc, sizeof(int64_t) * e->R);
-        if (rc == SGA_OK) rc = ho.finish();
-        if (rc != SGA_OK) return rc;
+        HIPCHK(hipMemcpyAsync(accepted, e->n_acc, sizeof(int64_t) * e->R, hipMemcpyDefault,
+                              e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
     }
     if (attempted) {
         if (is_device_ptr(attempted)) return fail(SGA_ERR_INVALID, "attempted must be a host buffer");
@@ -1866,19 +1813,24 @@ int sga_get_slot_map(sga_engine *e, int32_t *slot_to_rep) {
     if (!e || !slot_to_rep) return fail(SGA_ERR_INVALID, "NULL argument");
     if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
     HIPCHK(hipSetDevice(e->device));
-    HostOut ho(e);
-    int rc = ho.add(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg);
-    return rc == SGA_OK ? ho.finish() : rc;
+    HIPCHK(hipMemcpyAsync(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg, hipMemcpyDefault,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
 }
 
 int sga_get_exchange_stats(sga_engine *e, int64_t *attempts, int64_t *accepts) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
     HIPCHK(hipSetDevice(e->device));
-    HostOut ho(e);
-    int rc = ho.add(attempts, e->ex_attempts, sizeof(int64_t) * e->Rg);
-    if (rc == SGA_OK) rc = ho.add(accepts, e->ex_accepts, sizeof(int64_t) * e->Rg);
-    return rc == SGA_OK ? ho.finish() : rc;
+    if (attempts)
+        HIPCHK(hipMemcpyAsync(attempts, e->ex_attempts, sizeof(int64_t) * e->Rg, hipMemcpyDefault,
+                              e->stream));
+    if (accepts)
+        HIPCHK(hipMemcpyAsync(accepts, e->ex_accepts, sizeof(int64_t) * e->Rg, hipMemcpyDefault,
+                              e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
 }
 
 int sga_snapshot(sga_engine *e, double *energies, int64_t *accepted, int32_t *slot_to_rep) {
@@ -1886,11 +1838,14 @@ int sga_snapshot(sga_engine *e, double *energies, int64_t *accepted, int32_t *sl
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
     if (slot_to_rep && e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder");
     HIPCHK(hipSetDevice(e->device));
-    HostOut ho(e);
-    int rc = ho.add(energies, e->energy, sizeof(double) * e->R);
-    if (rc == SGA_OK) rc = ho.add(accepted, e->n_acc, sizeof(int64_t) * e->R);
-    if (rc == SGA_OK) rc = ho.add(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg);
-    return rc == SGA_OK ? ho.finish() : rc;
+    if (energies)
+        HIPCHK(hipMemcpyAsync(energies, e->energy, sizeof(double) * e->R, hipMemcpyDefault, e->stream));
+    if (accepted)
+        HIPCHK(hipMemcpyAsync(accepted, e->n_acc, sizeof(int64_t) * e->R, hipMemcpyDefault, e->stream));
+    if (slot_to_rep)
+        HIPCHK(hipMemcpyAsync(slot_to_rep, e->slot_to_rep, sizeof(int32_t) * e->Rg, hipMemcpyDefault, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGA_OK;
 }
 
 int sga_set_seed(sga_engine *e, uint64_t seed) {

@@ -146,7 +146,6 @@ size_t csr_lds_bytes(int sstride, int table_m, bool bits);  // LDS of one replic
 hipError_t launch_energy_dense(const EnergyArgs &a, bool j_is_i8, hipStream_t st);
 hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st);
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st);
-hipError_t launch_copy_out(const void *src, void *mapped_host, size_t bytes, hipStream_t st);  // bytes % 4 == 0
 // ordered list of slot pairs [count][2], one serial chain (exchange_method="all_pairs")
 hipError_t launch_exchange_pairs(const ExchangeArgs &a, const int32_t *pairs, int count, hipStream_t st);
 hipError_t launch_init_spins(int8_t *spins, int n, int sstride, int R, uint32_t seed_lo,

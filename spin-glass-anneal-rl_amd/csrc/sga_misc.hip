@@ -260,20 +260,6 @@ hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_pt
     return hipGetLastError();
 }
 
-// small results into pinned, device-mapped host memory (the host reads them after the stream has drained)
-__global__ void __launch_bounds__(256) copy_out_kernel(const uint32_t *src, uint32_t *mapped_host, size_t words) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
-        mapped_host[i] = src[i];
-}
-hipError_t launch_copy_out(const void *src, void *mapped_host, size_t bytes, hipStream_t st) {
-    const size_t words = bytes / 4;
-    if (words == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 64);
-    hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint32_t *>(src),
-                       static_cast<uint32_t *>(mapped_host), words);
-    return hipGetLastError();
-}
-
 // the wide forms' per-row record carries the row's field (one 16-byte load per extent)
 __global__ void rowinfo_fields_kernel(int4 *rowinfo, const float *h, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
