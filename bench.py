@@ -365,9 +365,11 @@ def main():
         copy_gbs = measured_copy_bandwidth(dev)
         read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
     torch.cuda.synchronize()
-    # (round 1 paused 0.3 s here to step around a rare 45-75 ms device-side gap on the short-kernel
-    # workloads; the A/B of profiles/r02_experiments.md shows the set-up's frees are not its cause.
-    # The pause is gone: wall_ms_total vs kernel_ms_total below makes any such gap visible.)
+    # (round 1 paused 0.3 s here to step around a 42 ms gap that 5-15 % of fresh processes show once, in
+    # the first exchange round that follows >= 7 queued sweeps of a short-kernel workload; profiles/
+    # r02_experiments.md 4 and 13 clear the set-up's frees, the D2H copy path, the host wait mode and
+    # the timing events, and do not explain it.  No pause, no priming: wall_ms_total vs
+    # kernel_ms_total below makes any such gap visible in the line itself.)
     if os.environ.get("SGA_BENCH_SETTLE"):
         time.sleep(float(os.environ["SGA_BENCH_SETTLE"]))
     for _ in range(a.warmup):
