@@ -716,7 +716,9 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 // like slot padding -- so that the offset always fits the 32-bit lane offset of a load.
 static int build_layout(sga_engine *e, const std::vector<long long> &src, bool slotted) {
     const int n = e->n;
-    constexpr long long ZERO_SLOT_EVERY = 1ll << 21;
+    long long ZERO_SLOT_EVERY = 1ll << 21;
+    if (const char *every = std::getenv("SGA_ZERO_SLOT_EVERY"))  // parity tests: zero slots inside small layouts
+        ZERO_SLOT_EVERY = std::max(1ll, std::min(ZERO_SLOT_EVERY, std::atoll(every)));
     std::vector<long long> dst((size_t)n + 1);
     std::vector<int4> info(slotted ? (size_t)n : 0);
     std::vector<int32_t> narrow;
@@ -749,6 +751,7 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
         for (int i = 0; i < n; ++i) {
             while (zero_after[z].first < i) ++z;
             info[(size_t)i].z = (int)(zero_after[z].second - info[(size_t)i].x);
+            if (info[(size_t)i].z >= (1 << 23)) return fail(SGA_ERR_UNSUPPORTED, "CSR row too long for the slot addressing");
         }
     }
     dev_free(e->rowptr);

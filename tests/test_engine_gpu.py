@@ -505,6 +505,40 @@ def test_csr_wide_rows_match_oracle(sg, waves, integer, big, monkeypatch):
         assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
 
 
+@pytest.mark.parametrize("every", [1, 7, 64])
+@pytest.mark.parametrize("waves,integer", [(2, True), (4, False), (8, False)])
+def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, every, monkeypatch):
+    """Head slots past a row's end read an all-zero slot; layouts beyond 1 GB carry such slots INSIDE
+    (one per 2^21 slots).  SGA_ZERO_SLOT_EVERY puts them into a small layout: rows of very different
+    lengths (empty ones too), so that most head slots are redirected, against the oracle."""
+    monkeypatch.setenv("SGA_ZERO_SLOT_EVERY", str(every))
+    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    n, R = 700, 4
+    rng = np.random.RandomState(5 + every)
+    dens = rng.choice([0.0, 0.02, 0.2, 0.9], n)[:, None]
+    mask = np.triu(rng.rand(n, n) < np.minimum(dens, dens.T), 1)
+    vals = (rng.randint(0, 2, (n, n)) * 2 - 1) if integer else np.rint(rng.randn(n, n) * 256.0) / 256.0
+    J = (mask * vals).astype(np.float32)
+    J = J + J.T
+    h = (rng.randint(-2, 3, n) if integer else rng.randn(n)).astype(np.float32)
+    csr = csr_of(J)
+    prob = oracle.Problem(csr=csr, h=h)
+    ns, seed = 4, 8128
+    temps = ladder(R, 20.0, 1.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=waves)
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        assert f"waves_per_replica={waves}" in e.describe() and "spins=lds-bits" in e.describe()
+        assert np.array_equal(e.energies(), oracle.energy(prob, oracle.init_spins(n, R, seed)))
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+
+
 def random_sparse_pm1(n, deg, seed):
     """Symmetric +-1 couplings, ~deg entries per row, canonical CSR (sorted, no duplicates)."""
     import scipy.sparse as sp
