@@ -1311,7 +1311,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         {   // head slots per wave that the longest row needs (the wide bit forms are built per count)
             const long long slots = (e->max_row_len + 63) / 64;
             const long long need = (slots + std::max(e->waves, 1) - 1) / std::max(e->waves, 1);
-            a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 8);
+            a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 10);
         }
         a.big = e->big_form;
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
