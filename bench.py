@@ -26,6 +26,7 @@ reports the energy gap between the two (`energy_gap_vs_gpu`; 0 = bit-identical).
 """
 import argparse
 import json
+import gc
 import os
 import sys
 import time
@@ -365,13 +366,16 @@ def main():
         copy_gbs = measured_copy_bandwidth(dev)
         read_gbs = probe_read_bandwidth(local_rank)  # 4 GiB: beyond the caches
     torch.cuda.synchronize()
-    # (round 1 paused 0.3 s here to step around a 42 ms gap that 5-15 % of fresh processes show once, in
-    # the first exchange round that follows >= 7 queued sweeps of a short-kernel workload; profiles/
-    # r02_experiments.md 4 and 13 clear the set-up's frees, the D2H copy path, the host wait mode and
-    # the timing events, and do not explain it.  No pause, no priming: wall_ms_total vs
-    # kernel_ms_total below makes any such gap visible in the line itself.)
+    # (round 1 paused 0.3 s here to step around a 30-40 ms gap that 5-15 % of fresh processes showed once
+    # on the short-kernel workloads.  profiles/r02_experiments.md 13: it is a full collection of
+    # CPython's garbage collector landing in the timed region -- the GPU idles while the host collects.
+    # The collector is off from the warm-up to the end of timing, as in timeit; wall_ms_total vs
+    # kernel_ms_total below would show any other gap.)
     if os.environ.get("SGA_BENCH_SETTLE"):
         time.sleep(float(os.environ["SGA_BENCH_SETTLE"]))
+    if os.environ.get("SGA_BENCH_GC") is None:  # (SGA_BENCH_GC=1: leave the collector on, the A/B of experiments 13)
+        gc.collect()
+        gc.disable()  # as timeit does: no collector pause of the interpreter inside the timed region
     for _ in range(a.warmup):
         step()
     if a.exchange_interval > 0:
@@ -396,6 +400,7 @@ def main():
               file=sys.stderr, flush=True)
     launches, kernel_ms = eng.kernel_time(reset=True)
     eng.enable_timing(False)
+    gc.enable()
     if debug and rank == 0:
         print(f"kernel events: {launches} launches, {kernel_ms:.1f} ms", file=sys.stderr, flush=True)
 
