@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             dE = (double)(2.0f * fk);
             if (fk <= 0.0f) flip = true;
             else if (fk <= (float)a.table_m) flip = ru < itab[(int)fk];  // u < p, on the uniform's raw bits
-            else flip = (dE > T * 104.0) ? false : (u < expf_det((float)(-dE / T)));  // beyond the table (p == 0 past -104)
+            else  // beyond the table (p == 0 past -104); u from its raw bits here: the table builds never form it otherwise
+                flip = (dE > T * 104.0) ? false : ((float)ru * 0x1.0p-24f < expf_det((float)(-dE / T)));
         } else {
             flip = metropolis_accept(rule, arith, dot, si, x.h, x.d, T, u, dE);
         }
