@@ -26,6 +26,9 @@
 namespace sga {
 
 constexpr int TSP_MAX_WAVES = 8;
+#ifndef TSP_ROWS_AHEAD
+#define TSP_ROWS_AHEAD 2  // distance rows requested this many updates before their reduction
+#endif
 
 // spins of the replica: int8 city-major in HBM -> bits position-major in LDS, plus the 2n sums
 __device__ inline void tsp_load_spins(const int8_t *src, unsigned int *bits, int *sums, int n, int cw,
@@ -58,7 +61,8 @@ __device__ inline void tsp_store_spins(const unsigned int *bits, int8_t *dst, in
 }
 
 // this lane's four cities of pass k against the columns `pm` (previous position) and `pn` (next);
-// FIRST: the accumulator starts from its first term (0 + x is an instruction of its own)
+// FIRST: the accumulator starts from its first term (0 + x is an instruction of its own).  (One chain of
+// adds: two accumulators measured 3-4 % slower, profiles/r02_experiments.md 14.)
 template <bool FIRST = false, typename acc_t>
 __device__ __forceinline__ void tsp_accumulate(acc_t &acc, const float4 &xprev, const float4 &xnext,
                                                const unsigned int *bits, int cw, int pm, int pn, int city0) {
@@ -186,25 +190,30 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_kernel(const Swe
         }
     };
 
-    // The row of update g + 1 is in flight while update g is reduced (two slots that swap roles);
-    // a sweep is pairs of updates plus, for an odd number of spins, one more that puts the slots
-    // back in phase -- the per-sweep work stays outside the unrolled body.
-    Slot ring[2];
-    produce(ring[0]);
+    // The rows of the next TSP_ROWS_AHEAD updates are in flight while update g is reduced (a ring of
+    // slots, every index a constant after unrolling); a sweep is whole groups of ring-size updates
+    // plus a remainder that shifts the ring back into phase -- the per-sweep work stays outside the
+    // unrolled body.
+    constexpr int NB = TSP_ROWS_AHEAD + 1;
+    Slot ring[NB];
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) produce(ring[j]);
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         const long long g0 = (long long)k * N;
         int tt = 0;
-        for (; tt + 2 <= N; tt += 2) {
-            produce(ring[1]);
-            step(ring[0], g0 + tt);
-            produce(ring[0]);
-            step(ring[1], g0 + tt + 1);
+        for (; tt + NB <= N; tt += NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                produce(ring[(j + NB - 1) % NB]);
+                step(ring[j], g0 + tt + j);
+            }
         }
-        if (tt < N) {
-            produce(ring[1]);
+        for (; tt < N; ++tt) {
+            produce(ring[NB - 1]);
             step(ring[0], g0 + tt);
-            ring[0] = ring[1];
+#pragma unroll
+            for (int j = 0; j + 1 < NB; ++j) ring[j] = ring[j + 1];
         }
         if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153

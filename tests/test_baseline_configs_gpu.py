@@ -231,6 +231,36 @@ def test_tsp_implicit_form_equals_stored_couplings_and_oracle(sg, n_cities, inte
                     e.flip(0, 1)
 
 
+@pytest.mark.parametrize("n_cities,splits", [(300, [(1, 2), (2, 1)]), (900, [(2, 2), (1, 4), (4, 1)])])
+def test_tsp_implicit_form_waves_and_passes_give_one_chain(sg, n_cities, splits):
+    """The implicit TSP sweep deals a distance row to waves x passes of 256 cities (default: two passes
+    from four waves up); every split runs one and the same chain -- at 300 cities that of the stored
+    couplings too (the 1000-city default is checked against its 32 GB CSR form above)."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    dist = _tsp_distances(n_cities, 7 + n_cities, False)
+    d32, A, B, h, _ = enc.tsp_structure(dist, 200.0, 120.0)
+    R, seed = 3, 99
+    temps = ladder(R, 150.0, 3.0)
+    out = []
+    forms = [("implicit", w, p) for w, p in splits] + ([("csr", 0, 0)] if n_cities <= 300 else [])
+    for form, waves, passes in forms:
+        with sg.AnnealEngine(0) as e:
+            if form == "implicit":
+                e.set_tuning(waves_per_replica=waves)
+                e.set_tsp(d32, A, B, h)
+            else:
+                e.set_csr(*oracle.tsp_to_csr(d32, A, B), h)
+            e.init_replicas(R, seed=seed)
+            if form == "implicit":
+                assert f"waves_per_replica={waves} passes={passes}" in e.describe(), e.describe()
+            e.set_temperatures(temps)
+            e.sweep(1)
+            out.append((e.spins().copy(), e.energies().copy(), e.stats()[0].copy()))
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][2], o[2])
+        assert np.allclose(out[0][1], o[1], rtol=1e-9, atol=1e-6)
+
+
 def test_tsp_implicit_form_checkpoint_ladders_and_errors(sg):
     from spin_glass_anneal_rl_amd import encoders as enc
     d32, A, B, h, _ = enc.tsp_structure(_tsp_distances(30, 3, False), 200.0, 200.0)
