@@ -256,6 +256,16 @@ int sga_describe(sga_engine *e, char *buf, int buflen);
 /* Measurement aid: GB/s of a plain streaming read (16 bytes per lane) of a fresh `bytes`-byte
  * device buffer, `reps` passes -- the practical bandwidth of this device beside its spec figure. */
 int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per_s);
+/* Storage of CSR entries in the one-replica-per-workgroup bit-spin sweep forms (long rows; call before
+ * sga_init_replicas).  AUTO: integer-valued problems with |J| <= 127 and n < 2^24 keep a second layout
+ * with one dword per entry (24-bit column | 8-bit value) -- half the bytes per row, identical chains;
+ * F32: always the (column int32, value fp32) entries; PACKED: fail (SGA_ERR_UNSUPPORTED, at
+ * sga_init_replicas) when the packed layout cannot be used.  (No reference counterpart: the
+ * reference stores torch COO / dense fp32, core/ising_model.py:56-63.) */
+#define SGA_CSR_STORAGE_AUTO 0
+#define SGA_CSR_STORAGE_F32 1
+#define SGA_CSR_STORAGE_PACKED 2
+int sga_set_csr_storage(sga_engine *e, int storage);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
 /* Measured choice of the dense launch geometry: times the sweep kernel for every feasible

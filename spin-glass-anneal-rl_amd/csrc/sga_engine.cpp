@@ -140,6 +140,9 @@ struct sga_engine {
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels)
     int4 *rowinfo = nullptr;     // slotted layout, per row: first slot, slots, offset of a zero slot, h (wide sweep forms)
     bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
+    uint32_t *cvp = nullptr;     // slotted layout with packed entries (24-bit column | int8 value << 24), on demand
+    bool cvp_tried = false;      // packing was attempted for this problem (values may not fit)
+    int csr_storage = SGA_CSR_STORAGE_AUTO;
     long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
     long long max_row_len = 0;     // entries of the longest row
     bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
@@ -201,6 +204,8 @@ struct sga_engine {
         dev_free(rowptr);
         dev_free(rowptr64);
         dev_free(rowinfo);
+        dev_free(cvp);
+        cvp_tried = false;
         slotted = false;
         dev_free(colidx);
         dev_free(val);
@@ -455,6 +460,14 @@ int sga_set_stream(sga_engine *e, void *hip_stream) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return SGA_OK;
+}
+
+int sga_set_csr_storage(sga_engine *e, int storage) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (storage != SGA_CSR_STORAGE_AUTO && storage != SGA_CSR_STORAGE_F32 && storage != SGA_CSR_STORAGE_PACKED)
+        return fail(SGA_ERR_INVALID, "bad CSR storage");
+    e->csr_storage = storage;
     return SGA_OK;
 }
 
@@ -798,6 +811,32 @@ static int ensure_slotted(sga_engine *e) {
     }
     dev_free(old_ptr);
     return rc;
+}
+
+// Packed entries for the bit-spin wide forms of integer-valued problems (|J| <= 127, n < 2^24): one
+// dword per entry, the same slots (256 bytes each) -- half the bytes of a row.  Built on demand from the
+// slotted layout; the (column, value) layout stays (energy kernels, traced sweeps).
+static int ensure_packed_entries(sga_engine *e) {
+    if (e->cvp || e->cvp_tried) return SGA_OK;
+    e->cvp_tried = true;
+    if (!e->csr || !e->slotted || e->n >= (1 << 24) ||
+        (e->csr_acc != sga::CSR_ACC_F32 && e->csr_acc != sga::CSR_ACC_F32_TABLE))
+        return SGA_OK;
+    const size_t count = (size_t)e->layout_entries + 64;  // the zero slot behind the array included
+    hipError_t he = hipMalloc(&e->cvp, sizeof(uint32_t) * count);
+    if (he != hipSuccess) {
+        e->cvp = nullptr;
+        (void)hipGetLastError();
+        return SGA_OK;  // no room: the unpacked layout serves
+    }
+    int bad = 0;
+    he = hipMemsetAsync(e->d_flags, 0, sizeof(int), e->stream);
+    if (he == hipSuccess) he = sga::launch_pack_entries(e->cv, e->cvp, (long long)count, e->d_flags, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(&bad, e->d_flags, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess || bad) dev_free(e->cvp);
+    if (he != hipSuccess) return fail(SGA_ERR_DEVICE, hipGetErrorString(he));
+    return SGA_OK;
 }
 
 // CSR problem from 32- or 64-bit row extents (host or device pointers).  The structure is
@@ -1159,6 +1198,13 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             int rc = ensure_slotted(e);
             if (rc != SGA_OK) return rc;
         }
+        if (e->big_form == 1 && e->csr_storage != SGA_CSR_STORAGE_F32) {
+            int rc = ensure_packed_entries(e);
+            if (rc != SGA_OK) return rc;
+        }
+        if (e->csr_storage == SGA_CSR_STORAGE_PACKED && !(e->big_form == 1 && e->cvp))
+            return fail(SGA_ERR_UNSUPPORTED, "packed CSR entries need integer couplings with |J| <= 127, n < 2^24 "
+                                             "and the one-replica-per-workgroup bit-spin form");
     }
     const size_t sb = (size_t)R_local * e->sstride;
     HIPCHK(hipMalloc(&e->spins, sb));
@@ -1320,6 +1366,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
         a.rowinfo = e->rowinfo;
+        a.cvp = (e->big_form == 1 && e->csr_storage != SGA_CSR_STORAGE_F32) ? e->cvp : nullptr;
         a.csr_acc = e->csr_acc;  // (the table form needs its table: set below once table_m is final)
         {   // head slots per wave that the longest row needs (the wide bit forms are built per count)
             const long long slots = (e->max_row_len + 63) / 64;
@@ -2066,6 +2113,8 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       " rows=64-entry-slots(+%.1f%%) longest_row_slots=%lld",
                       e->nnz > 0 ? 100.0 * (double)(e->layout_entries - e->nnz) / (double)e->nnz : 0.0,
                       (e->max_row_len + 63) / 64);
+    if (e->csr && e->big_form == 1 && e->cvp && e->csr_storage != SGA_CSR_STORAGE_F32)
+        std::strncat(tmp, " entries=packed-32bit", sizeof(tmp) - std::strlen(tmp) - 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

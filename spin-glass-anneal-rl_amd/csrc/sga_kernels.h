@@ -21,6 +21,7 @@ struct SweepArgs {
     const void *J;           // dense: [n][ld] of float | int8, zero padded rows
     const int32_t *rowptr;   // CSR, layout entries < 2^31 (null otherwise)
     const long long *rowptr64;  // CSR, always present
+    const uint32_t *cvp;     // CSR, slotted layout, packed entries (24-bit column | int8 value << 24) or null
     const int4 *rowinfo;     // CSR, slotted layout (rows padded to whole 64-entry slots), per row:
                              // first slot, slot count, slots from there to an all-zero slot, h (bits)
                              // in slots; the wide sweep forms address rows by it (null otherwise)
@@ -175,6 +176,7 @@ hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_pt
 // CSR row extents between their 32- and 64-bit forms ([n + 1] entries)
 hipError_t launch_widen_rowptr(const int32_t *src, long long *dst, long long count, hipStream_t st);
 hipError_t launch_rowinfo_fields(int4 *rowinfo, const float *h, int n, hipStream_t st);
+hipError_t launch_pack_entries(const int2 *cv, uint32_t *cvp, long long count, int *bad, hipStream_t st);
 hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long count, hipStream_t st);
 // CSR structure checks on the device.  flags (int[8], zeroed by the caller):
 //  [0] rowptr not monotone / not spanning [0, nnz]   [1] column out of range

@@ -260,6 +260,22 @@ hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_pt
     return hipGetLastError();
 }
 
+// (column, fp32 value) -> column | int8 value << 24; *bad is set when some value is not an integer in [-127, 127]
+// or some column needs more than 24 bits
+__global__ void __launch_bounds__(256) pack_entries_kernel(const int2 *cv, uint32_t *cvp, long long count, int *bad) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const int2 e = cv[i];
+        const float v = __int_as_float(e.y);
+        const int iv = (int)v;
+        if ((float)iv != v || iv < -127 || iv > 127 || (unsigned int)e.x >= (1u << 24)) *bad = 1;
+        cvp[i] = ((uint32_t)iv << 24) | ((uint32_t)e.x & 0xFFFFFFu);
+    }
+}
+hipError_t launch_pack_entries(const int2 *cv, uint32_t *cvp, long long count, int *bad, hipStream_t st) {
+    hipLaunchKernelGGL(pack_entries_kernel, dim3(4096), dim3(256), 0, st, cv, cvp, count, bad);
+    return hipGetLastError();
+}
+
 // the wide forms' per-row record carries the row's field (one 16-byte load per extent)
 __global__ void rowinfo_fields_kernel(int4 *rowinfo, const float *h, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -60,12 +60,17 @@ constexpr int CSR_MAX_WIDE = 8;   // most waves one replica's row is dealt to (1
 // HD = head slots per wave of the wide forms (entries requested ahead and reduced branch-free): the
 // engine picks the smallest build that covers the longest row, ceil(max row slots / NW) -- a slot
 // that can never hold an entry costs as much as one that does (C4: 5 of 8 -> 50.1 vs 45.1 ms).
-template <int ACC, bool LEAN, bool WIDE, bool BIG, int NW = 0, int HD = 8>
+// PK = packed entries (a.cvp: one dword per entry = 24-bit column | 8-bit value << 24; integer-valued
+// problems with |J| <= 127 and n < 2^24 in the bit-spin wide forms): half the bytes per entry, the row
+// sum accumulated as an integer -- the same value, so the same chain (storage variant with its own byte
+// model, B = deg * 4 + 8).
+template <int ACC, bool LEAN, bool WIDE, bool BIG, int NW = 0, int HD = 8, bool PK = false>
 __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOCK))
     sweep_csr_kernel(const SweepArgs a) {
     constexpr bool FAST = ACC == CSR_ACC_F32_TABLE || ACC == CSR_ACC_F32;  // fp32 accumulation
     constexpr bool TABLE = ACC == CSR_ACC_F32_TABLE;
     constexpr bool CANON = ACC == CSR_ACC_F64_CANON;
+    static_assert(!PK || (WIDE && BIG && LEAN && FAST), "packed entries: production bit-spin wide forms of integer problems");
     static_assert(!CANON || !WIDE || NW == 1 || NW == 2 || NW == 4 || NW == 8,
                   "canonical-order wide builds are made per wave count");
     // (the production wide builds are made per wave count as well: with the slot arithmetic and
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         int col[HEAD];
         float val[HEAD];
         int len, zrel;            // wide forms: the row's slot count, its zero slot (wave-uniform)
-        const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer)
+        const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer; packed: of a.cvp)
     };
     // wave-uniform value -> SGPR
     auto uniform = [&](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
@@ -172,6 +177,21 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         unsigned int off = ((unsigned int)slot << 9) + lane8;
         asm volatile("" : "+v"(off));
         return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
+    };
+    // the same for packed entries: 256-byte slots, one dword per lane
+    auto slot_entry_pk = [&](const int2 *row, int slot) -> int {
+        unsigned int off = ((unsigned int)slot << 8) + (lane8 >> 1);
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(row) + off);
+    };
+    // packed entry e times the spin at its column: v * (1 - 2 bit) -- v_bfe_u32, v_lshl_add, [ds_read], v_bfe_i32,
+    // v_or, v_mul_i32_i24 (byte 3, sign extended), half a v_add3
+    auto term_pk = [&](int e) -> int {
+        unsigned int widx = ((unsigned int)e >> 5) & 0x7FFFFu;  // column >> 5: bits 5..23 of the entry (v_bfe_u32)
+        asm("" : "+v"(widx));  // (kept apart from the scaling: the LDS base then folds into v_lshl_add)
+        const unsigned int word = sbits[widx];
+        const int m = __builtin_amdgcn_sbfe(word, (unsigned int)e, 1u);         // -bit (v_bfe_i32 takes offset[4:0])
+        return (e >> 24) * ((m << 1) | 1);
     };
     const int nwc = (WIDE && NW > 0) ? NW : nw;  // waves of this replica (a constant in the real-valued wide builds)
     auto load_extent = [&](int site) {
@@ -207,6 +227,16 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             // updates ago: pin it to SGPRs.  A slot past the row's end reads the zero slot.
             o.len = uniform(x.end);
             o.zrel = uniform(x.zrel);
+            if constexpr (PK) {
+                o.row = reinterpret_cast<const int2 *>(a.cvp + ((long long)uniform(x.beg) << 6));
+#pragma unroll
+                for (int q = 0; q < HEAD; ++q) {
+                    const int sq = w + nwc * q;
+                    o.col[q] = slot_entry_pk(o.row, sq < o.len ? sq : o.zrel);
+                    o.val[q] = 0.0f;
+                }
+                return o;
+            }
             o.row = a.cv + ((long long)uniform(x.beg) << 6);
 #pragma unroll
             for (int q = 0; q < HEAD; ++q) {
@@ -239,14 +269,28 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         {
             // one code path for the four row-sum forms: fp32 | fp64 accumulators, one per virtual wave
             // of the canonical order (a single one in the exact forms, where the order is free)
-            using acc_t = typename std::conditional<FAST, float, double>::type;
+            using acc_t = typename std::conditional<PK, int, typename std::conditional<FAST, float, double>::type>::type;
             constexpr int NVA = !CANON ? 1 : (WIDE ? 8 / (NW > 0 ? NW : 8) : 8);
             // (accumulators start from their first term: 0 + x is an instruction the compiler has
             // to keep for x = -0)
             acc_t acc[NVA];
 #pragma unroll
             for (int j = 0; j < NVA; ++j) acc[j] = 0;
-            if constexpr (WIDE) {
+            if constexpr (PK) {
+                acc[0] = term_pk(hd.col[0]);
+#pragma unroll
+                for (int q = 1; q < HEAD; ++q) acc[0] += term_pk(hd.col[q]);
+                for (int s0 = nwc * HEAD; s0 < hd.len; s0 += nwc * TAIL_UNROLL) {
+                    int ev[TAIL_UNROLL];
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) {
+                        const int sq = s0 + w + nwc * q;
+                        ev[q] = slot_entry_pk(hd.row, sq < hd.len ? sq : hd.zrel);
+                    }
+#pragma unroll
+                    for (int q = 0; q < TAIL_UNROLL; ++q) acc[0] += term_pk(ev[q]);
+                }
+            } else if constexpr (WIDE) {
                 // Every head slot is computed; a slot past the row's end holds the zero slot's entries
                 // (value 0).  Measured against one wave-uniform branch per slot and against a
                 // straight-line block per valid-slot count (same box, profiles/r02_experiments.md): the

@@ -15,6 +15,11 @@ namespace sga {
      : waves == 2 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 2, HD_>                      \
      : waves == 4 ? sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 4, HD_>                      \
                   : sweep_csr_kernel<CSR_ACC_F32_TABLE, true, true, BIG, 8, HD_>)
+#define SGA_WIDE_PACKED(ACC_, HD_)                                                                     \
+    (waves == 1 ? sweep_csr_kernel<ACC_, true, true, true, 1, HD_, true>                              \
+     : waves == 2 ? sweep_csr_kernel<ACC_, true, true, true, 2, HD_, true>                            \
+     : waves == 4 ? sweep_csr_kernel<ACC_, true, true, true, 4, HD_, true>                            \
+                  : sweep_csr_kernel<ACC_, true, true, true, 8, HD_, true>)
 // the production builds and the canonical-order builds are made per wave count (1, 2, 4, 8); the other
 // traced builds take it at run time
 template <bool BIG, int HD>
@@ -22,6 +27,13 @@ static hipError_t launch_wide(const SweepArgs &a, int waves, hipStream_t st) {
     if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return hipErrorInvalidValue;
     const bool lean = csr_args_are_lean(a);
     void (*kern)(const SweepArgs) = nullptr;
+    if constexpr (BIG) {  // packed entries (a.cvp): integer problems, production builds
+        if (lean && a.cvp) {
+            const int acc = csr_effective_acc(a, lean);
+            if (acc == CSR_ACC_F32_TABLE) return launch_csr_kernel(SGA_WIDE_PACKED(CSR_ACC_F32_TABLE, HD), a, true, BIG, waves, st);
+            if (acc == CSR_ACC_F32) return launch_csr_kernel(SGA_WIDE_PACKED(CSR_ACC_F32, HD), a, true, BIG, waves, st);
+        }
+    }
     switch (csr_effective_acc(a, lean)) {
         case CSR_ACC_F32_TABLE: kern = SGA_WIDE_TABLE(HD); break;
         case CSR_ACC_F32: kern = SGA_WIDE_NW(CSR_ACC_F32, HD); break;

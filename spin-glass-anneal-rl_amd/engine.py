@@ -112,6 +112,12 @@ class AnnealEngine:
         N.check(self._lib.sga_set_tuning(self._h, int(waves_per_replica), int(sweeps_per_launch)),
                 "sga_set_tuning")
 
+    def set_csr_storage(self, storage: str = "auto"):
+        """Entry storage of the long-row CSR sweep forms: "auto" (one dword per entry where the problem
+        allows: integer couplings, |J| <= 127, n < 2^24), "f32" (column + fp32 value), "packed" (required)."""
+        code = {"auto": 0, "f32": 1, "packed": 2}[storage]
+        N.check(self._lib.sga_set_csr_storage(self._h, code), "sga_set_csr_storage")
+
     def autotune(self) -> float:
         """Time every feasible waves-per-replica on the current replicas and keep the fastest
         (dense problems; results are unaffected).  Returns the best kernel ms per sweep."""

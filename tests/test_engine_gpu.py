@@ -539,6 +539,63 @@ def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, eve
         assert np.array_equal(e.spins(), s)
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("every", [0, 3])
+def test_csr_packed_entries_run_the_same_chain(sg, waves, every, monkeypatch):
+    """Integer couplings with |J| <= 127: the bit-spin wide forms keep one dword per entry (24-bit column,
+    8-bit value) and accumulate integers -- the chain of the (column, fp32 value) entries and of the
+    oracle; larger values and real values keep the unpacked entries; "packed" demanded for them fails."""
+    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    if every:
+        monkeypatch.setenv("SGA_ZERO_SLOT_EVERY", str(every))
+    n, R = 1200, 4
+    rng = np.random.RandomState(40 + waves)
+    dens = rng.choice([0.0, 0.3, 0.6, 0.95], n)[:, None]   # long rows (mean degree > 192), empty ones too
+    mask = np.triu(rng.rand(n, n) < np.minimum(dens, dens.T), 1)
+    J = (mask * rng.randint(-127, 128, (n, n))).astype(np.float32)
+    J = J + J.T
+    h = (rng.randint(-5, 6, n) + (0.5 if waves & 2 else 0.0)).astype(np.float32)   # half-integer fields: no table
+    csr = csr_of(J)
+    prob = oracle.Problem(csr=csr, h=h)
+    ns, seed = 3, 4242
+    temps = ladder(R, 4000.0, 50.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    for storage in ("auto", "f32", "packed"):
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_csr_storage(storage)
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed)
+            assert ("entries=packed-32bit" in e.describe()) == (storage != "f32"), e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"]), storage
+            assert np.array_equal(e.spins(), s), storage
+            assert np.array_equal(e.stats()[0], ref["n_accepted"]), storage
+            out2 = e.sweep(1, energy_trace=True, trace=True)   # traced build: unpacked entries, same state
+            assert out2["accept_trace"].shape == (R, n)
+    for bad in (J * 2.0, J + np.where(J != 0, 0.25, 0.0).astype(np.float32)):   # |J| up to 254; quarter offsets
+        c2 = csr_of(bad.astype(np.float32))
+        p2 = oracle.Problem(csr=c2, h=h)
+        s2 = oracle.init_spins(n, R, seed)
+        r2 = oracle.sweeps(p2, s2, temps, 1, seed=seed, n_threads=8)
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_csr(*c2, h)
+            e.init_replicas(R, seed=seed)
+            assert "entries=packed-32bit" not in e.describe()
+            e.set_temperatures(temps)
+            e.sweep(1)
+            assert np.array_equal(e.spins(), s2)
+        with sg.AnnealEngine(0) as e:
+            e.set_tuning(waves_per_replica=waves)
+            e.set_csr_storage("packed")
+            e.set_csr(*c2, h)
+            with pytest.raises(sg.AnnealingError):
+                e.init_replicas(R, seed=seed)
+
+
 def random_sparse_pm1(n, deg, seed):
     """Symmetric +-1 couplings, ~deg entries per row, canonical CSR (sorted, no duplicates)."""
     import scipy.sparse as sp
