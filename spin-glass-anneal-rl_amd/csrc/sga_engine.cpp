@@ -143,6 +143,7 @@ struct sga_engine {
     uint32_t *cvp = nullptr;     // slotted layout with packed entries (24-bit column | int8 value << 24), on demand
     bool cvp_tried = false;      // packing was attempted for this problem (values may not fit)
     int csr_storage = SGA_CSR_STORAGE_AUTO;
+    int table_scale = 1;         // CSR accept table: entry q stands for dE = 2 q / table_scale
     long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
     long long max_row_len = 0;     // entries of the longest row
     bool big = false;  // CSR sweeps with bit spins in LDS (decided per replica set)
@@ -926,9 +927,17 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     // integer-valued problem?  then dE takes at most M = max_i(sum_j |J_ij| + |h_i|) even values
     float m;
     std::memcpy(&m, &flags[sga::CSR_ROW_ABS_MAX], sizeof(m));
+    // (J integer, h a multiple of 1/2 -- penalty encodings of 0/1 variables: dE takes integer values,
+    // tabulated at twice the resolution)
     e->table_m = 0;
-    if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f)
+    e->table_scale = 1;
+    if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f) {
         e->table_m = (int)std::min(m, 2048.0f);
+    } else if ((flags[sga::CSR_NOT_INTEGRAL] & 5) == 0 && m >= 1.0f && m < 8388608.0f &&
+               std::getenv("SGA_NO_HALF_TABLE") == nullptr) {
+        e->table_m = (int)std::min(2.0f * m, 2048.0f);
+        e->table_scale = 2;
+    }
     HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, ci, vv, n, e->diag, e->stream));
     std::vector<long long> src(np1);
     HIPCHK(hipMemcpyAsync(src.data(), e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToHost, e->stream));
@@ -1405,6 +1414,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.arith = arith;
         a.rule = e->rule;
         a.table_m = exact_mode ? 0 : e->table_m;
+        a.table_scale = e->csr ? e->table_scale : 1;
         if (a.csr_acc == sga::CSR_ACC_F32_TABLE && a.table_m == 0) a.csr_acc = sga::CSR_ACC_F32;
         a.no_best = exact_mode ? 1 : 0;
         a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;
@@ -2087,7 +2097,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->big_form == 2 ? sga::csr_bits_waves_per_block(e->sstride, e->table_m)
                                        : ((e->waves > 1 || e->big) ? 1 : sga::csr_waves_per_block(e->sstride, e->table_m)),
                       e->sstride,
-                      (e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0) ? "integer-fast"
+                      (e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0) ? (e->table_scale == 2 ? "half-integer-fast" : "integer-fast")
                       : e->csr_acc == sga::CSR_ACC_F32_TABLE ? "general acc=f32-exact"
                       : e->csr_acc == sga::CSR_ACC_F32     ? "general acc=f32-exact"
                       : e->csr_acc == sga::CSR_ACC_F64     ? "general acc=f64-exact"

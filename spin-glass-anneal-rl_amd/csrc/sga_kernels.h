@@ -58,6 +58,7 @@ struct SweepArgs {
     long long model_stride_j;
     int no_best;  // 1: leave best tracking to the host-driven pass (asymmetric / diagonal J)
     int table_m;  // > 0: J, h integer valued with max_i(sum_j |J_ij| + |h_i|) = table_m
+    int table_scale;  // CSR: 1 | 2 -- table entry q stands for dE = 2 q / table_scale (2: J integer, h half-integer)
     int big;      // CSR: spins held as bits in LDS; 1 = one replica per workgroup with 64-bit row
                   // extents (n > ~160k, nnz >= 2^31, long rows), 2 = narrow form, several replicas per
                   // workgroup (short rows)

@@ -353,12 +353,13 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
         }
         const float hi = h[i];
         if (hi != rintf(hi)) non_int |= 2;
+        if (2.0f * hi != rintf(2.0f * hi)) non_int |= 4;
         // an upper bound is all the table needs; fp32 rounds it up or down by < 1 ulp
         const float tot = (float)(wave_sum(acc) + (double)fabsf(hi));
         row_max = fmaxf(row_max, tot);
     }
     if (bad_col) flags[CSR_BAD_COLUMN] = 1;
-    if (non_int) atomicOr(&flags[CSR_NOT_INTEGRAL], non_int);  // bit 0: some J, bit 1: some h
+    if (non_int) atomicOr(&flags[CSR_NOT_INTEGRAL], non_int);  // bit 0: some J, bit 1: some h, bit 2: some 2 h
     if (exp_hi) atomicMax(&flags[CSR_EXP_HI], exp_hi);
     if (exp_lo) atomicMax(&flags[CSR_EXP_LO], exp_lo);
     if (unsorted) flags[CSR_UNSORTED] = 1;

@@ -382,10 +382,12 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         bool flip;
         if (TABLE && rule == SGA_RULE_METROPOLIS && arith == SGA_ARITH_F64) {
             // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2k exactly
+            // (half-integer fields: table_scale = 2, the table is indexed by 2 fk = dE)
             const float fk = (float)si * (dot + x.h);
             dE = (double)(2.0f * fk);
+            const float fq = fk * (float)a.table_scale;
             if (fk <= 0.0f) flip = true;
-            else if (fk <= (float)a.table_m) flip = ru < itab[(int)fk];  // u < p, on the uniform's raw bits
+            else if (fq <= (float)a.table_m) flip = ru < itab[(int)fq];  // u < p, on the uniform's raw bits
             else  // beyond the table (p == 0 past -104); u from its raw bits here: the table builds never form it otherwise
                 flip = (dE > T * 104.0) ? false : ((float)ru * 0x1.0p-24f < expf_det((float)(-dE / T)));
         } else {
@@ -421,7 +423,8 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             // as integer thresholds on the uniform's 24 raw bits: u = r 2^-24 < p <=> r < ceil(p 2^24)
             // (p 2^24 is exact, so is its ceiling) -- no int -> float conversion of u per update
             for (int q = first_lane; q <= a.table_m; q += stride_lanes)
-                itab[q] = (unsigned int)__builtin_ceilf(expf_det((float)(-(double)(2 * q) / T)) * 16777216.0f);
+                itab[q] = (unsigned int)__builtin_ceilf(
+                    expf_det((float)(-((double)(2 * q) / (double)a.table_scale) / T)) * 16777216.0f);
             if constexpr (WIDE) __syncthreads();
         }
     };

@@ -85,6 +85,8 @@ def test_c4_scheduling_instance_at_1024_replicas_per_gpu(sg):
             e.init_replicas(R, seed=seed, R_global=Rg, replica0=replica0)
             d = e.describe()
             assert "spins=lds-bits" in d and "waves_per_replica=2" in d and "R=1024" in d, d
+            # integer couplings, half-integer fields: packed entries, the accept table at twice the resolution
+            assert "entries=packed-32bit" in d and "path=half-integer-fast" in d, d
             e.set_ladder(temps_g)
             assert np.array_equal(e.temperatures(), temps_g[replica0:replica0 + R])
             out = e.sweep(1, energy_trace=True)
@@ -511,7 +513,7 @@ def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
     h = rng.randint(-2, 3, n).astype(np.float32) + (0.5 if kind == "half_integer_h" else 0.0)
     if kind in ("fixed_point", "gaussian"):
         h = rng.randn(n).astype(np.float32)
-    expect = {"integer": "path=integer-fast", "half_integer_h": "acc=f32-exact",
+    expect = {"integer": "path=integer-fast", "half_integer_h": "path=half-integer-fast",
               "fixed_point": "acc=f64-exact", "gaussian": "acc=f64-canonical"}[kind]
     csr = csr_of(J)
     prob = oracle.Problem(csr=csr, h=h)
