@@ -33,6 +33,8 @@ while time.time() < t_end:
     J = np.triu(vals * (rng.rand(n, n) < dens), 1).astype(np.float32)
     J = J + J.T
     h = (rng.randint(-2, 3, n) if integer else rng.randn(n)).astype(np.float32)
+    if integer and rng.rand() < 0.3:
+        h = h + np.float32(0.5)   # half-integer fields: the accept table at twice the resolution (CSR)
     if rng.rand() < 0.2:
         h[:] = 0
     storage = "auto"
