@@ -722,8 +722,8 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 // Row extents of the layout the kernels read: dst[i] = prefix sum of the rows' lengths, each rounded
 // up to whole 64-entry slots when `slotted`.  n <= ~1.3e6 rows: done on the host at set time.
 //
-// Slotted layouts also get the wide forms' per-row record (rowinfo: first slot, slot count, slots
-// from the first slot to an all-zero slot, h): a wave asks for a fixed number of slots per row and
+// Slotted layouts also get the wide forms' per-row record (rowinfo: first slot, slot count | entries in
+// the last slot << 24, slots from the first slot to an all-zero slot, h): a wave asks for a fixed number of slots per row and
 // the ones past the row's end read that zero slot (value 0: nothing to mask when the row is
 // summed).  The zero slot is the 64 zeroed entries behind the array; layouts beyond 2^21 slots
 // (1 GB) get one more inside after every 2^21 slots -- it rides at the end of the row before it,
@@ -748,7 +748,11 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
             continue;
         }
         const long long slots = (len + 63) / 64;
-        info[(size_t)i] = make_int4((int)(at >> 6), (int)slots, 0, 0);
+        // .y: slot count | entries in the last slot << 24 (lanes beyond them read the zero slot: no HBM
+        // traffic for the padding's cache lines)
+        if (slots >= (1 << 24)) return fail(SGA_ERR_UNSUPPORTED, "CSR row too long for the slot addressing");
+        info[(size_t)i] = make_int4((int)(at >> 6), (int)(slots | ((len - 64 * (slots - 1)) << 24)), 0, 0);
+        if (slots == 0) info[(size_t)i].y = 0;
         at += slots * 64;
         since += slots;
         if (since >= ZERO_SLOT_EVERY && i + 1 < n) {

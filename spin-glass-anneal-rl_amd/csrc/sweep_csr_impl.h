@@ -31,6 +31,11 @@ constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight toget
 // requested at the top of an update is waited for by that update's first spin gather: same-box A/B
 // (profiles/ab3.sh) C4 37.1 vs 34.8 ms per sweep, C5 at 1000 cities 1263-1302 vs 1286-1295 ms ->
 // vector loads (in-order vmcnt).  The narrow forms, 4 waves per SIMD, gain 1-2 % from the scalar loads.
+// Wide forms with (column, fp32 value) entries: lanes behind the last entry of a row's last slot read the
+// zero slot (1) or the padding (0).
+#ifndef CSR_TRIM_LAST_SLOT
+#define CSR_TRIM_LAST_SLOT 1
+#endif
 #ifndef CSR_WIDE_SCALAR_EXTENTS
 #define CSR_WIDE_SCALAR_EXTENTS 0
 #endif
@@ -146,6 +151,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
     struct Extent {  // what is indexed by the site alone
         rp_t beg, end;  // entries [beg, end) | wide forms: first slot, slot count
         int zrel;       // wide forms: slots from the first slot to an all-zero slot
+        int rem;        // wide forms: entries in the row's last slot (1..64)
         float h, d;
     };
     // The entries of a row requested one update ahead: its first 64 (one per lane) in the narrow
@@ -157,6 +163,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         int col[HEAD];
         float val[HEAD];
         int len, zrel;            // wide forms: the row's slot count, its zero slot (wave-uniform)
+        int rem;                  // wide forms: entries in the row's last slot
         const int2 *row;          // wide forms: the row's first entry (wave-uniform pointer; packed: of a.cvp)
     };
     // wave-uniform value -> SGPR
@@ -176,6 +183,11 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         // it folded into the pointer arithmetic loses the base + zext(VGPR) address form)
         unsigned int off = ((unsigned int)slot << 9) + lane8;
         asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
+    };
+    // (per-lane slot number)
+    auto slot_entry_lanes = [&](const int2 *row, int slot_of_lane) -> int2 {
+        const unsigned int off = ((unsigned int)slot_of_lane << 9) + lane8;  // (varies per load: nothing to hoist)
         return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
     };
     // the same for packed entries: 256-byte slots, one dword per lane
@@ -205,13 +217,15 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             const int4 ri = a.rowinfo[us];  // one 16-byte load
 #endif
             o.beg = ri.x;
-            o.end = ri.y;
+            o.end = ri.y & 0xFFFFFF;
+            o.rem = (int)((unsigned int)ri.y >> 24);
             o.zrel = ri.z;
             o.h = __int_as_float(ri.w);
         } else {
             o.beg = sload_i(rowptr + us);
             o.end = sload_i(rowptr + us + 1);
             o.zrel = 0;
+            o.rem = 0;
             o.h = sload_f(a.h + us);
         }
         o.d = arith32 ? sload_f(a.diag + us) : 0.0f;
@@ -221,6 +235,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         Head o;
         o.len = 0;
         o.zrel = 0;
+        o.rem = 0;
         o.row = nullptr;
         if constexpr (WIDE) {
             // HEAD slots per wave: slot w + nw q of the row, q = 0..HEAD-1.  The extent arrived
@@ -238,10 +253,19 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
                 return o;
             }
             o.row = a.cv + ((long long)uniform(x.beg) << 6);
+            o.rem = uniform(x.rem);
 #pragma unroll
             for (int q = 0; q < HEAD; ++q) {
                 const int sq = w + nwc * q;
+#if CSR_TRIM_LAST_SLOT
+                // the lanes behind the row's last entry read the zero slot as well (cache resident)
+                // instead of the padding: its cache lines are never fetched from HBM
+                const int eff = sq < o.len ? sq : o.zrel;
+                const int remq = sq == o.len - 1 ? o.rem : 64;
+                const int2 ent = slot_entry_lanes(o.row, lane < remq ? eff : o.zrel);
+#else
                 const int2 ent = slot_entry(o.row, sq < o.len ? sq : o.zrel);
+#endif
                 o.col[q] = ent.x;
                 o.val[q] = __int_as_float(ent.y);
             }
