@@ -493,10 +493,15 @@ def main():
         nbytes = float(len(csr[1])) * 8.0
         out["roofline"]["note"] = (
             f"CSR structure = {nbytes / 1e6:.0f} MB: " +
-            ("cache resident (PMC traffic far below the algorithmic bytes), the sweep is bound by "
-             "instruction issue, not by HBM" if nbytes < 2.0e8 else
-             "streamed from HBM; the wide-row forms are instruction bound (~200 VALU instructions per "
-             "wave and update at degree 4000), DESIGN.md 4.2"))
+            ("cache resident (PMC traffic far below the algorithmic bytes): the sweep is paced by the dependent "
+             "chain of one update, not by HBM" if nbytes < 2.0e8 else
+             "streamed from HBM (up to 256 MB partly re-served by the Infinity Cache); bandwidth bound, "
+             "DESIGN.md 4.2"))
+    elif a.workload == "c2a" and not implicit:
+        out["roofline"]["note"] = (
+            f"{n * n * elem / 1e6:.0f} MB of couplings against a 256 MB Infinity Cache: part of every pass is re-served "
+            "on chip, so this algorithmic rate is a fabric figure and can touch the HBM spec number; the HBM-bound "
+            "figure on a matrix beyond every cache is roofline_beyond_cache")
     # the same workload with the couplings held as int8 / as two bit-planes (what
     # coupling_storage="auto" picks for integer / ternary J; exact arithmetic, identical
     # chain): reported beside the fp32 headline
