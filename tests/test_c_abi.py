@@ -35,3 +35,15 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
 def test_plain_c_program_runs_the_engine(tmp_path):
     p = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith("OK version="), (p.returncode, p.stdout, p.stderr)
+
+
+def test_csr_storage_codes_agree_between_header_and_host():
+    """sga_set_csr_storage: the header's constants are what AnnealEngine.set_csr_storage passes."""
+    import inspect
+    import re
+    import spin_glass_anneal_rl_amd as sg
+    text = open(os.path.join(INC, "sga.h")).read()
+    codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define SGA_CSR_STORAGE_(\w+) (\d+)", text)}
+    assert codes == {"auto": 0, "f32": 1, "packed": 2}
+    src = inspect.getsource(sg.AnnealEngine.set_csr_storage)
+    assert '{"auto": 0, "f32": 1, "packed": 2}' in src
