@@ -36,6 +36,9 @@ constexpr int TAIL_UNROLL = 8;  // wave-loads of a long row kept in flight toget
 #ifndef CSR_TRIM_LAST_SLOT
 #define CSR_TRIM_LAST_SLOT 1
 #endif
+#ifndef CSR_NT_LOADS
+#define CSR_NT_LOADS 1  // non-temporal entry loads in the wide builds for very long rows (0: A/B switch)
+#endif
 #ifndef CSR_WIDE_SCALAR_EXTENTS
 #define CSR_WIDE_SCALAR_EXTENTS 0
 #endif
@@ -183,7 +186,19 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
         // it folded into the pointer arithmetic loses the base + zext(VGPR) address form)
         unsigned int off = ((unsigned int)slot << 9) + lane8;
         asm volatile("" : "+v"(off));
-        return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
+        // Rows of 32 slots and more (head slots x waves >= 32: 2000+ entries) belong to structures far
+        // beyond the 256 MB Infinity Cache that are streamed once per update and never re-used:
+        // their entries are loaded non-temporal (C5 at 1000 cities, same box: 1283-1334 -> 1266 ms per
+        // sweep).  Shorter rows keep the default policy -- C4's 239 MB are partly cache served, and
+        // for the dense 400 MB matrix non-temporal loads measured 3-5 % slower.
+        constexpr bool NT = CSR_NT_LOADS && WIDE && NW * HD >= 32;
+        if constexpr (NT) {
+            const long long raw = __builtin_nontemporal_load(
+                reinterpret_cast<const long long *>(reinterpret_cast<const unsigned char *>(row) + off));
+            return make_int2((int)raw, (int)(raw >> 32));
+        } else {
+            return *reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(row) + off);
+        }
     };
     // (per-lane slot number)
     auto slot_entry_lanes = [&](const int2 *row, int slot_of_lane) -> int2 {
