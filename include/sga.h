@@ -132,7 +132,9 @@ int sga_set_tsp(sga_engine *e, const float *dist, int64_t ld, int n_cities, floa
 /* R_local replicas live on this engine; they are replicas [replica0, replica0+R_local) of a
  * global set of R_global (R_global == R_local, replica0 == 0 on one GPU).  s0 == NULL draws
  * the initial spins from the Philox stream (domain 2), else s0 is int8 +-1 [R_local][n].
- * Energies are computed, best = initial, counters zeroed, sweep counter = 0. */
+ * Energies are computed, best = initial, counters zeroed, sweep counter = 0.  A failed call leaves the
+ * engine WITHOUT replicas (the previous set is released first): later sweeps / state calls return
+ * SGA_ERR_INVALID until replicas are initialised again. */
 int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
                       const int8_t *s0);
 /* Temperature of each local replica (used when sga_sweep gets no schedule). */
@@ -260,12 +262,27 @@ int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per
  * sga_init_replicas).  AUTO: integer-valued problems with |J| <= 127 and n < 2^24 keep a second layout
  * with one dword per entry (24-bit column | 8-bit value) -- half the bytes per row, identical chains;
  * F32: always the (column int32, value fp32) entries; PACKED: fail (SGA_ERR_UNSUPPORTED, at
- * sga_init_replicas) when the packed layout cannot be used.  (No reference counterpart: the
+ * sga_init_replicas) when the packed layout cannot be used.  The choice is latched by
+ * sga_init_replicas: a call made while replicas exist takes effect at the next sga_init_replicas
+ * (sga_describe reports what the current replicas run).  (No reference counterpart: the
  * reference stores torch COO / dense fp32, core/ising_model.py:56-63.) */
 #define SGA_CSR_STORAGE_AUTO 0
 #define SGA_CSR_STORAGE_F32 1
 #define SGA_CSR_STORAGE_PACKED 2
 int sga_set_csr_storage(sga_engine *e, int storage);
+/* How sga_sweep evaluates a proposal.  OFF (default): the reference's way -- the local field of the
+ * proposed site is formed from its coupling row (IsingModel.get_local_field, core/ising_model.py:176-185):
+ * one row read per proposal.  ON / AUTO: the local fields of every replica stay resident (int16 / int32
+ * in LDS; seeded by one pass over J on the matrix cores) and a row is read only when a proposal is
+ * ACCEPTED, to update them -- the reference's incremental mode, core/energy_computer.py:166-173,262-265.
+ * Same sites, uniforms and accept rule: the chain equals OFF's bit for bit.  Needs dense couplings of
+ * one model, J and h integer valued, J symmetric with a zero diagonal, max_i(sum_j |J_ij| + |h_i|) < 2^24,
+ * n <= ~75 000 (int16 fields; ~37 000 with int32); any rule but SGA_RULE_WOLFF.  ON: sga_sweep fails with
+ * SGA_ERR_UNSUPPORTED where that does not hold; AUTO: falls back to OFF's kernels there. */
+#define SGA_FIELD_CACHE_OFF 0
+#define SGA_FIELD_CACHE_ON 1
+#define SGA_FIELD_CACHE_AUTO 2
+int sga_set_field_cache(sga_engine *e, int mode);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
 /* Measured choice of the dense launch geometry: times the sweep kernel for every feasible

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("sga_get_kernel_time", _i, [_p, C.POINTER(_i64), C.POINTER(_d), _i]),
     ("sga_describe", _i, [_p, C.c_char_p, _i]),
     ("sga_set_csr_storage", _i, [_p, _i]),
+    ("sga_set_field_cache", _i, [_p, _i]),
     ("sga_set_tuning", _i, [_p, _i, _i]),
     ("sga_autotune", _i, [_p, C.POINTER(_d)]),
     ("sga_probe_read_bandwidth", _i, [_i, _i64, _i, C.POINTER(_d)]),

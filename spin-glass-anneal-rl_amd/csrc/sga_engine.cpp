@@ -142,7 +142,8 @@ struct sga_engine {
     bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
     uint32_t *cvp = nullptr;     // slotted layout with packed entries (24-bit column | int8 value << 24), on demand
     bool cvp_tried = false;      // packing was attempted for this problem (values may not fit)
-    int csr_storage = SGA_CSR_STORAGE_AUTO;
+    int csr_storage = SGA_CSR_STORAGE_AUTO;         // what the caller asked for ...
+    int csr_storage_latched = SGA_CSR_STORAGE_AUTO; // ... and what the current replicas were laid out for
     int table_scale = 1;         // CSR accept table: entry q stands for dE = 2 q / table_scale
     long long layout_entries = 0;  // entries of the layout the kernels read (nnz + padding)
     long long max_row_len = 0;     // entries of the longest row
@@ -163,6 +164,16 @@ struct sga_engine {
     int rule = SGA_RULE_METROPOLIS;
     bool consistent_dE = true;  // J symmetric with zero diagonal: dE of the rule == energy change
     int table_m = 0;  // integer problems: largest possible |dE| / 2 (0 = not integer / too big)
+    // cached-local-field sweep (sweep_clf_impl.h)
+    int field_cache = SGA_FIELD_CACHE_OFF;  // what the caller asked for
+    bool clf_problem = false;  // dense, one model, J and h integer valued, symmetric, zero diagonal, sums < 2^24
+    float row_abs_max = 0.0f;  // max_i(sum_j |J_ij| + |h_i|)
+    int clf_scale = 1, clf_bits = 16;
+    void *fields = nullptr;    // [R][ldf] int16 | int32: clf_scale * (J s + h), valid while fields_valid
+    long long ldf = 0;
+    bool fields_valid = false;
+    void *ybuf = nullptr;      // [count][ldj] int32 | float: scratch of the all-replica field pass
+    size_t ybuf_bytes = 0;
     int csr_acc = sga::CSR_ACC_F64_CANON;  // CSR: how the sweep kernels form a row sum (set time)
 
     // replicas
@@ -218,6 +229,7 @@ struct sga_engine {
         tsp = false;
         dev_free(epart);
         epart_bytes = 0;
+        clf_problem = false;
         n = 0;
         ld = 0;
     }
@@ -235,6 +247,10 @@ struct sga_engine {
         dev_free(wolff_u);
         dev_free(wolff_cursor);
         wolff_cap = 0;
+        dev_free(fields);
+        fields_valid = false;
+        dev_free(ybuf);
+        ybuf_bytes = 0;
         R = Rg = 0;
         n_ladders = 0;
     }
@@ -288,7 +304,71 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
     return true;
 }
 
+// All replicas' local fields in one pass over the couplings on the matrix cores (fields_dense.hip),
+// then energies and / or the resident fields of the cached-field sweep from them.
+bool fields_pass_applies(const sga_engine *e, int count) {
+    static const bool off = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // A/B switch
+    return !off && !e->csr && !e->tsp && e->n_models == 1 && count >= 32 && e->J_packed;
+}
+int fields_pass(sga_engine *e, int r0, int count, double *energy, void *fields) {
+    const size_t need = sizeof(float) * (size_t)count * (size_t)e->ldj;
+    if (need > e->ybuf_bytes) {
+        dev_free(e->ybuf);
+        e->ybuf_bytes = 0;
+        HIPCHK(hipMalloc(&e->ybuf, need));
+        e->ybuf_bytes = need;
+    }
+    sga::FieldsArgs f{};
+    f.J = e->J_packed;
+    f.spins = e->spins + (long long)r0 * e->sstride;
+    f.Y = e->ybuf;
+    f.h = e->h;
+    f.energy = energy;
+    f.fields = fields;
+    f.ldj = e->ldj;
+    f.ldy = e->ldj;
+    f.ldf = e->ldf;
+    f.n = e->n;
+    f.R = count;
+    f.sstride = e->sstride;
+    f.field_bits = fields ? e->clf_bits : 0;
+    f.field_scale = e->clf_scale;
+    const int mode = e->want_i8 ? 0 : (e->acc64 ? 2 : 1);
+    HIPCHK(sga::launch_fields_dense(f, mode, e->stream));
+    HIPCHK(sga::launch_fields_finish(f, mode == 0, e->stream));
+    return SGA_OK;
+}
+
+// The cached-local-field sweep serves: dense integer-valued symmetric problems (one model) whose
+// fields and spin bits fit LDS, any single-site rule.  why: the reason when it does not.
+bool clf_possible(const sga_engine *e, const char **why) {
+    const char *reason = nullptr;
+    if (e->csr || e->tsp) reason = "cached local fields: dense couplings only";
+    else if (!e->clf_problem)
+        reason = "cached local fields need one model with integer-valued symmetric J, zero diagonal, integer h "
+                 "and row sums below 2^24";
+    else if (e->R > 0 && sga::sweep_clf_lds_bytes((e->ldj + 127) / 128 * 128, e->clf_bits, e->sstride, e->table_m) >
+                             160 * 1024)
+        reason = "cached local fields: fields and spins of a replica do not fit LDS";
+    if (why) *why = reason;
+    return reason == nullptr;
+}
+bool clf_active(const sga_engine *e) {
+    return e->field_cache != SGA_FIELD_CACHE_OFF && e->rule != SGA_RULE_WOLFF && clf_possible(e, nullptr);
+}
+// resident fields of every replica, from the all-replica pass (the tracked energies are left alone)
+int ensure_fields(sga_engine *e) {
+    if (e->fields_valid && e->fields) return SGA_OK;
+    e->ldf = (e->ldj + 127) / 128 * 128;
+    if (!e->fields) HIPCHK(hipMalloc(&e->fields, (size_t)e->R * (size_t)e->ldf * (size_t)(e->clf_bits / 8)));
+    int rc = fields_pass(e, 0, e->R, nullptr, e->fields);  // (any replica count: short tiles are clamped)
+    if (rc != SGA_OK) return rc;
+    e->fields_valid = true;
+    return SGA_OK;
+}
+
 int recompute_energy_range(sga_engine *e, int r0, int count) {
+    if (fields_pass_applies(e, count)) return fields_pass(e, r0, count, e->energy + r0, nullptr);
     sga::EnergyArgs a{};
     a.J = e->J_packed;
     a.rowptr = e->rowptr64;
@@ -398,7 +478,7 @@ int pack_dense(sga_engine *e, const float *src, long long ld_src) {
 extern "C" {
 
 const char *sga_last_error(void) { return g_last_error.c_str(); }
-int sga_version(void) { return 200; }  // round 2: + sga_exchange_pairs, sga_set_tsp, sga_set_wolff_replay, state blob v2
+int sga_version(void) { return 300; }  // round 2: + sga_exchange_pairs, sga_set_tsp, sga_set_wolff_replay, state blob v2
 
 int sga_create(int device, sga_engine **out) {
     if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
@@ -481,6 +561,14 @@ int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch) 
     return SGA_OK;
 }
 
+int sga_set_field_cache(sga_engine *e, int mode) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (mode != SGA_FIELD_CACHE_OFF && mode != SGA_FIELD_CACHE_ON && mode != SGA_FIELD_CACHE_AUTO)
+        return fail(SGA_ERR_INVALID, "bad field-cache mode");
+    e->field_cache = mode;
+    return SGA_OK;
+}
+
 // Measured choice of the dense launch geometry.  Every candidate (waves per replica) runs the
 // real sweep kernel on the real replicas for a trial; the chain does not depend on the geometry,
 // and spins / energies / best states / counters are put back afterwards, so the run continues
@@ -528,6 +616,8 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     const long long attempted = e->attempted;
     const int user_waves = e->tune_waves, user_spl = e->tune_spl;
     const bool was_timing = e->timing;
+    const int user_cache = e->field_cache;  // the geometry belongs to the row-per-proposal kernels
+    e->field_cache = SGA_FIELD_CACHE_OFF;
 
     // lay the replicas out for `waves` (0 = heuristic) and put the saved state back
     auto layout = [&](int waves) -> int {
@@ -597,6 +687,9 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     // leave with the winner (or the caller's setting if something failed) and the saved state
     e->timing = was_timing;
     e->tune_spl = user_spl;
+    e->field_cache = user_cache;
+    e->fields_valid = false;
+    dev_free(e->fields);  // (the spin stride may have changed; rebuilt on demand)
     const int final_rc = e->R > 0 ? layout(rc == SGA_OK && best_w >= 0 ? best_w : user_waves) : SGA_ERR_MEMORY;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (rc != SGA_OK) return rc;
@@ -712,6 +805,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     }
     // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
     if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
+    // cached-local-field sweep: exact integer fields, dE of the rule == energy change, one model
+    e->row_abs_max = m;
+    e->clf_problem = nonint == 0u && m < 16777216.0f && e->consistent_dE && n_models == 1;
+    e->clf_scale = 1;
+    e->clf_bits = m < 32768.0f ? 16 : 32;
     int rc = pack_dense(e, src, ld_src);
     if (rc == SGA_OK) rc = ensure_packed(e);
     // the source (the caller's buffer, or the staging copy about to be released) is done with
@@ -815,6 +913,15 @@ static int ensure_slotted(sga_engine *e) {
         dev_free(old_cv);
     }
     dev_free(old_ptr);
+    if (rc != SGA_OK) {
+        // build_layout may already have overwritten the extents while the entries are still the old
+        // ones (or gone): no half-converted layout survives -- the engine is back to "no couplings set"
+        const std::string msg = g_last_error;
+        (void)hipStreamSynchronize(e->stream);
+        e->free_replicas();
+        e->free_problem();
+        return fail(rc, msg + " (re-padding the CSR layout failed: set the couplings again)");
+    }
     return rc;
 }
 
@@ -1092,9 +1199,24 @@ int sga_set_tsp(sga_engine *e, const float *dist, int64_t ld, int n_cities, floa
     return SGA_OK;
 }
 
+static int init_replicas_body(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
+                              const int8_t *s0);
+
 int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
                       const int8_t *s0) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    // whatever fails in there, the engine is left with NO replicas (R == 0): a later sweep / snapshot /
+    // export then reports SGA_ERR_INVALID instead of launching kernels on half-allocated buffers
+    const int rc = init_replicas_body(e, R_local, R_global, replica0, seed, s0);
+    if (rc != SGA_OK) {
+        (void)hipStreamSynchronize(e->stream);
+        e->free_replicas();
+    }
+    return rc;
+}
+
+static int init_replicas_body(sga_engine *e, int R_local, int R_global, int replica0, uint64_t seed,
+                              const int8_t *s0) {
     if (e->n <= 0) return fail(SGA_ERR_INVALID, "set the couplings before the replicas");
     if (R_local <= 0 || R_global < R_local || replica0 < 0 || replica0 + R_local > R_global)
         return fail(SGA_ERR_INVALID, "bad replica partition");
@@ -1211,6 +1333,7 @@ int sga_init_replicas(sga_engine *e, int R_local, int R_global, int replica0, ui
             int rc = ensure_slotted(e);
             if (rc != SGA_OK) return rc;
         }
+        e->csr_storage_latched = e->csr_storage;
         if (e->big_form == 1 && e->csr_storage != SGA_CSR_STORAGE_F32) {
             int rc = ensure_packed_entries(e);
             if (rc != SGA_OK) return rc;
@@ -1371,6 +1494,20 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     }
     const bool exact_mode = !e->consistent_dE || wolff;
     if (exact_mode) spl = 1;
+    // cached local fields (sga_set_field_cache): a row is read only when a proposal is accepted
+    bool clf = false;
+    if (e->field_cache != SGA_FIELD_CACHE_OFF && !wolff) {
+        const char *why = nullptr;
+        clf = clf_possible(e, &why);
+        if (!clf && e->field_cache == SGA_FIELD_CACHE_ON) return fail(SGA_ERR_UNSUPPORTED, why);
+    }
+    if (clf) {
+        rc = ensure_fields(e);
+        if (rc != SGA_OK) return rc;
+        if (e->tune_spl <= 0) spl = n_sweeps;  // no row streaming to bound: one launch
+    } else {
+        e->fields_valid = false;  // the row-per-proposal kernels move the spins only
+    }
 
     for (int k0 = 0; k0 < n_sweeps; k0 += spl) {
         const int ks = std::min(spl, n_sweeps - k0);
@@ -1379,7 +1516,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.rowptr = e->rowptr;
         a.rowptr64 = e->rowptr64;
         a.rowinfo = e->rowinfo;
-        a.cvp = (e->big_form == 1 && e->csr_storage != SGA_CSR_STORAGE_F32) ? e->cvp : nullptr;
+        a.cvp = (e->big_form == 1 && e->csr_storage_latched != SGA_CSR_STORAGE_F32) ? e->cvp : nullptr;
         a.csr_acc = e->csr_acc;  // (the table form needs its table: set below once table_m is final)
         {   // head slots per wave that the longest row needs (the wide bit forms are built per count)
             const long long slots = (e->max_row_len + 63) / 64;
@@ -1438,7 +1575,13 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         const bool lean = !force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
                           e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
         hipError_t le;
-        if (wolff) {
+        if (clf) {
+            a.fields = e->fields;
+            a.ldf = e->ldf;
+            a.field_bits = e->clf_bits;
+            a.field_scale = e->clf_scale;
+            le = sga::launch_sweep_clf(a, e->want_i8, sga::sweep_clf_waves(e->ldj, e->want_i8), st);
+        } else if (wolff) {
             const sga::WolffArgs wa{e->wolff_u, e->wolff_cap, e->wolff_cursor};
             le = sga::launch_sweep_wolff(a, wa, e->csr, e->want_i8, st);
         } else if (e->tsp) {
@@ -1587,6 +1730,7 @@ static int point_op(sga_engine *e, int r, const int32_t *sites, int count, int o
         he = hipMemcpyAsync(out_host, d_out, sizeof(double) * (size_t)out_count, hipMemcpyDeviceToHost, st);
     if (he == hipSuccess) he = hipStreamSynchronize(st);
     HIPCHK(he);
+    if (op != 0) e->fields_valid = false;
     if (op != 0 && !e->consistent_dE) {  // the rule's dE is not the energy change here
         int rc = recompute_energy_range(e, r, 1);
         if (rc != SGA_OK) return rc;
@@ -1829,6 +1973,7 @@ int sga_set_spins(sga_engine *e, int r, const int8_t *s) {
     HIPCHK(hipMemsetAsync(e->spins + (long long)r * e->sstride, 0, (size_t)e->sstride, e->stream));
     HIPCHK(hipMemcpyAsync(e->spins + (long long)r * e->sstride, s, (size_t)e->n, hipMemcpyDefault,
                           e->stream));
+    e->fields_valid = false;
     int rc = recompute_energy_range(e, r, 1);
     if (rc != SGA_OK) return rc;
     HIPCHK(sga::launch_copy_best(e->energy + r, e->spins + (long long)r * e->sstride,
@@ -2050,6 +2195,7 @@ int sga_import_state(sga_engine *e, const void *buf, uint64_t size) {
     e->rounds = h.rounds;
     e->seed = h.seed;
     e->attempted = h.attempted;
+    e->fields_valid = false;
     return SGA_OK;
 }
 
@@ -2127,9 +2273,13 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       " rows=64-entry-slots(+%.1f%%) longest_row_slots=%lld",
                       e->nnz > 0 ? 100.0 * (double)(e->layout_entries - e->nnz) / (double)e->nnz : 0.0,
                       (e->max_row_len + 63) / 64);
-    if (e->csr && e->big_form == 1 && e->cvp && e->csr_storage != SGA_CSR_STORAGE_F32)
+    if (e->csr && e->big_form == 1 && e->cvp && e->csr_storage_latched != SGA_CSR_STORAGE_F32)
         std::strncat(tmp, " entries=packed-32bit", sizeof(tmp) - std::strlen(tmp) - 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
+    if (clf_active(e))
+        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                      " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
+                      e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8));
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;
 }

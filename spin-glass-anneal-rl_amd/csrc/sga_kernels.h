@@ -66,6 +66,11 @@ struct SweepArgs {
     int csr_head;        // CSR wide bit forms: head slots per wave the longest row needs (0: eight)
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
+    // cached-local-field sweep (sweep_clf_impl.h): resident fields F = field_scale * (J s + h)
+    void *fields;        // [R][ldf] int16 | int32
+    long long ldf;
+    int field_bits;      // 16 | 32
+    int field_scale;     // 1 | 2 (J integer, h a multiple of 1/2)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -108,6 +113,26 @@ struct EnergyArgs {
 };
 hipError_t launch_energy_finish(const double *partial, int slices, double *energy, int R,
                                 hipStream_t st);
+
+// Local fields of all replicas in one pass over the couplings (fields_dense.hip, matrix cores)
+struct FieldsArgs {
+    const void *J;         // dense [n][ldj] int8 | float
+    const int8_t *spins;   // [R][sstride]
+    void *Y;               // [R][ldy] int32 (int8 J) | float: Y[r][i] = sum_j J[i][j] s[r][j]
+    const float *h;        // [n]
+    double *energy;        // [R] or null (finish pass)
+    void *fields;          // [R][ldf] int16 | int32 or null (finish pass): field_scale * (Y + h)
+    long long ldj, ldy, ldf;
+    int n, R, sstride;
+    int field_bits, field_scale;
+};
+// mode 0: int8 J (i8 MFMA) | 1: fp32 J with exact fp32 sums (f32 MFMA) | 2: fp32 J, real valued (f64 MFMA)
+hipError_t launch_fields_dense(const FieldsArgs &a, int mode, hipStream_t st);
+hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t st);
+// cached-local-field sweep: dense integer-valued symmetric problems
+hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
+size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
+int sweep_clf_waves(long long ldj, bool j_is_i8);
 
 struct ExchangeArgs {
     const double *energies;   // [R_global] by global replica id

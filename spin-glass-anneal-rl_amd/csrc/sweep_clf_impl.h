@@ -1,0 +1,284 @@
+// sweep_clf_impl.h -- the CACHED-LOCAL-FIELD sweep: the same single-spin chain as the dense sweep
+// kernel (sweep_dense_impl.h), with a coupling row read only when a proposal is ACCEPTED.
+//
+// Replaces the same reference code as the dense sweep -- SpinDynamics.sweep /
+// _metropolis_update (core/spin_dynamics.py:73-94,131-152) batched over replicas -- in the way
+// the reference's own incremental mode evaluates moves (core/energy_computer.py:166-173,
+// 262-265: dE from a maintained field, the field updated on a flip).
+//
+// For integer-valued symmetric couplings with a zero diagonal every replica keeps its local fields
+//     F_i = scale * (sum_j J_ij s_j + h_i)        (int16 | int32, exact; scale = 2 for half-integer h)
+// resident in LDS next to its spins (one bit each).  A proposal at site i needs F_i and s_i only:
+// dE = 2 s_i F_i / scale.  The site and the uniform of every update come from the counter RNG, not
+// from the chain's state, and a REJECTED proposal leaves the state untouched -- so a window of 128
+// consecutive updates is evaluated at once, lane l taking updates 2l and 2l + 1 against the spins
+// and fields as they stand; a wave ballot finds the first accepted one, everything before it is
+// rejected for good, the flip is applied (row i of J streamed once:  F_j -= 2 scale J_ij s_i),
+// and the candidates behind it are evaluated again.  Decisions, energies and spins are those of
+// the one-update-at-a-time chain bit for bit (all quantities are integers below 2^24; the accept
+// rule is the same function of the same arguments), for every site mode, rule and arithmetic the
+// dense kernel serves -- the tests run it against the same oracle and reference fixtures.
+//
+// Byte model (its own, reported beside the graded one-row-per-proposal figure, never instead of
+// it): B = acceptance rate x n x sizeof(J element) per attempt, SURVEY.md 8(d) last sentence.
+//
+// Mapping: one workgroup per replica, W waves.  Every wave evaluates the same window redundantly
+// (no communication to agree on the decision); the row of an accepted site is dealt to the waves
+// in 1-KiB chunks (chunk c -> wave c mod W), each wave updating the fields under its chunks.
+// With W > 1 an accept costs two barriers (nobody still evaluates / everybody has applied).
+#pragma once
+#include <type_traits>
+
+#include "sweep_common.h"
+
+namespace sga {
+
+constexpr int CLF_WINDOW = 128;  // updates evaluated together: two per lane
+constexpr int CLF_BATCH = 4;     // row chunks a wave requests together
+
+// The accept rule as a function of the exact local field (sum + h): what metropolis_accept
+// (sweep_common.h) computes from (double)dot + (double)h -- the diagonal term of the fp32 operator
+// arithmetic is zero here (the cached-field form needs a zero diagonal).
+__device__ __forceinline__ bool field_rule_accept(int rule, int arith, double field, int si, double T,
+                                                  float u, double &dE) {
+    if (rule != SGA_RULE_METROPOLIS) {  // core/spin_dynamics.py:154-171, :173-191
+        const float x = (rule == SGA_RULE_GLAUBER) ? (float)(-2.0 * field / T)
+                                                   : (float)((-2.0 * (1.0 / T)) * field);
+        const float prob_up = 1.0f / (1.0f + expf_det(x));
+        const int new_spin = (u < prob_up) ? 1 : -1;
+        dE = 2.0 * (double)si * field;
+        return new_spin != si;
+    }
+    if (arith == SGA_ARITH_F64) {  // core/spin_dynamics.py:131-152
+        dE = 2.0 * (double)si * field;
+        if (dE <= 0.0) return true;
+        if (dE > T * 104.0) return false;
+        return u < expf_det((float)(-dE / T));
+    }
+    // annealing/cuda_kernels.py:383-390, fp32 throughout
+    const float sif = (float)si;
+    const float dEf = (2.0f * sif) * (float)field;
+    dE = (double)dEf;
+    if (dEf <= 0.0f) return true;
+    return u < expf_det(-dEf / (float)T);
+}
+
+// two int16 in a dword, each increased by its own (small) amount, wrapping separately
+__device__ __forceinline__ int add_pair(int pair, int d_lo, int d_hi) {
+    const unsigned int p = (unsigned int)pair;
+    return (int)(((p + (unsigned int)d_lo) & 0xFFFFu) | ((p + ((unsigned int)d_hi << 16)) & 0xFFFF0000u));
+}
+
+// LDS of one replica: fields [ldf] FT | spin bits [sstride / 8 bytes] | accept table [table_m + 1] floats
+__host__ __device__ constexpr long long clf_bits_offset(long long ldf, int fbytes) {
+    return (ldf * fbytes + 15) & ~15ll;
+}
+__host__ __device__ constexpr long long clf_table_offset(long long ldf, int fbytes, int sstride) {
+    return clf_bits_offset(ldf, fbytes) + ((sstride / 8 + 15) & ~15);
+}
+inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {
+    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 1) + 16;
+}
+
+template <typename JT, typename FT, bool LEAN>
+__global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
+    constexpr int EPL = 16 / (int)sizeof(JT), EPC = 64 * EPL;  // elements per lane / per 1-KiB chunk
+    constexpr int FB = (int)sizeof(FT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FT *F = reinterpret_cast<FT *>(smem);
+    unsigned int *bits = reinterpret_cast<unsigned int *>(smem + clf_bits_offset(a.ldf, FB));
+    float *ptab = reinterpret_cast<float *>(smem + clf_table_offset(a.ldf, FB, a.sstride));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = (int)(blockDim.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x, n = a.n;
+    const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
+    const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
+    const int sc = a.field_scale;
+    const double inv_sc = 1.0 / (double)sc;  // 1 | 0.5: exact
+    const bool use_tab = LEAN && a.table_m > 0;
+
+    {   // resident state -> LDS
+        const int4 *src = reinterpret_cast<const int4 *>(reinterpret_cast<const FT *>(a.fields) + (long long)r * a.ldf);
+        int4 *dst = reinterpret_cast<int4 *>(F);
+        for (int i = tid; i < (int)(a.ldf * FB / 16); i += blockDim.x) dst[i] = src[i];
+        spins_to_bits(a.spins + (long long)r * a.sstride, bits, a.sstride, tid, blockDim.x);
+    }
+    __syncthreads();
+
+    const JT *Jbase = reinterpret_cast<const JT *>(a.J);
+    const int n_chunks = (int)((a.ldj + EPC - 1) / EPC);
+    double E = a.energy[r], bestE = a.best_energy[r];
+    unsigned long long nacc = 0;
+    double T = 1.0;
+
+    // F_j -= 2 scale J_ij s_i over this wave's chunks of row i
+    auto apply_row = [&](int site, int mult /* -2 scale s_i(old) */) {
+        const JT *row = Jbase + (long long)site * a.ldj;
+        for (int c0 = w; c0 < n_chunks; c0 += CLF_BATCH * W) {
+            using vec_t = typename std::conditional<sizeof(JT) == 4, float4, int4>::type;
+            vec_t x[CLF_BATCH];
+            bool in[CLF_BATCH];
+#pragma unroll
+            for (int q = 0; q < CLF_BATCH; ++q) {
+                const long long j0 = ((long long)(c0 + q * W) * 64 + lane) * EPL;
+                in[q] = (c0 + q * W) < n_chunks && j0 < a.ldj;
+                if (in[q]) x[q] = *reinterpret_cast<const vec_t *>(row + j0);
+            }
+#pragma unroll
+            for (int q = 0; q < CLF_BATCH; ++q) {
+                if (!in[q]) continue;
+                const long long j0 = ((long long)(c0 + q * W) * 64 + lane) * EPL;
+                if constexpr (sizeof(JT) == 4) {
+                    const int d0 = mult * (int)x[q].x, d1 = mult * (int)x[q].y, d2 = mult * (int)x[q].z,
+                              d3 = mult * (int)x[q].w;
+                    if constexpr (FB == 2) {
+                        int2 f = *reinterpret_cast<int2 *>(F + j0);
+                        f.x = add_pair(f.x, d0, d1);
+                        f.y = add_pair(f.y, d2, d3);
+                        *reinterpret_cast<int2 *>(F + j0) = f;
+                    } else {
+                        int4 f = *reinterpret_cast<int4 *>(F + j0);
+                        f.x += d0, f.y += d1, f.z += d2, f.w += d3;
+                        *reinterpret_cast<int4 *>(F + j0) = f;
+                    }
+                } else {
+                    const int wds[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
+                    if constexpr (FB == 2) {
+                        int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
+                        int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {  // four couplings per dword -> two dwords of int16 pairs
+                            const int b0 = (int)(int8_t)(wds[d]), b1 = (int)(int8_t)(wds[d] >> 8),
+                                      b2 = (int)(int8_t)(wds[d] >> 16), b3 = wds[d] >> 24;
+                            int &lo = *fp[2 * d], &hi = *fp[2 * d + 1];
+                            lo = add_pair(lo, mult * b0, mult * b1);
+                            hi = add_pair(hi, mult * b2, mult * b3);
+                        }
+                        *reinterpret_cast<int4 *>(F + j0) = f0;
+                        *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
+                            f.x += mult * (int)(int8_t)(wds[d]);
+                            f.y += mult * (int)(int8_t)(wds[d] >> 8);
+                            f.z += mult * (int)(int8_t)(wds[d] >> 16);
+                            f.w += mult * (wds[d] >> 24);
+                            *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // one candidate against the current state: flips?  dE of the flip
+    auto decide = [&](int site, float u, double &dE) -> bool {
+        const int f = (int)F[site];
+        const int si = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
+        if constexpr (LEAN) {
+            const int k = si * f;  // dE = 2 k / scale
+            dE = (double)(2 * k) * inv_sc;
+            if (k <= 0) return true;
+            if (use_tab && k <= a.table_m) return u < ptab[k];
+            if (dE > T * 104.0) return false;  // p == 0 past -104 (sweep_common.h)
+            return u < expf_det((float)(-dE / T));
+        } else {
+            return field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, dE);
+        }
+    };
+
+    for (int k = 0; k < a.n_sweeps; ++k) {
+        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        if (use_tab) {  // exp(float32(-dE/T)) of the moves dE = 2 q / scale, q <= table_m
+            __syncthreads();
+            for (int q = tid; q <= a.table_m; q += blockDim.x)
+                ptab[q] = expf_det((float)(-((double)(2 * q) * inv_sc) / T));
+            __syncthreads();
+        }
+        const long long base = (long long)r * a.replay_stride + (long long)k * n;
+        for (int t0 = 0; t0 < n; t0 += CLF_WINDOW) {
+            // this lane's two candidates: updates t0 + 2 lane and t0 + 2 lane + 1 of sweep k
+            const int tA = t0 + 2 * lane, tB = tA + 1;
+            const bool vA = tA < n, vB = tB < n;
+            int sA = 0, sB = 0;
+            float uA = 2.0f, uB = 2.0f;
+            if (LEAN || a.site_mode != SGA_SITE_REPLAY) {
+                const u32x4 x = philox4x32_10((uint32_t)(tA >> 1), a.sweep0 + (uint32_t)k, a.replica0 + (uint32_t)r,
+                                              DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+                sA = (int)word_to_site(x.x, (uint32_t)n);
+                sB = (int)word_to_site(x.z, (uint32_t)n);
+                uA = word_to_u(x.y);
+                uB = word_to_u(x.w);
+            }
+            if constexpr (!LEAN) {
+                if (a.site_mode == SGA_SITE_REPLAY) {  // recorded stream of the reference (sweep_common.h)
+                    if (vA) sA = a.replay_site[base + tA], uA = a.replay_u[base + tA];
+                    if (vB) sB = a.replay_site[base + tB], uB = a.replay_u[base + tB];
+                    sA = min(max(sA, 0), n - 1);
+                    sB = min(max(sB, 0), n - 1);
+                } else if (a.site_mode == SGA_SITE_SEQUENTIAL) {  // annealing/cuda_kernels.py:381
+                    sA = vA ? tA : 0;
+                    sB = vB ? tB : 0;
+                    if (a.replay_u) {
+                        if (vA) uA = a.replay_u[base + tA];
+                        if (vB) uB = a.replay_u[base + tB];
+                    }
+                }
+            }
+            int pos = 0;  // window positions below pos are decided
+            for (;;) {
+                double dEA = 0.0, dEB = 0.0;
+                const bool fA = vA && 2 * lane >= pos && decide(sA, uA, dEA);
+                const bool fB = vB && 2 * lane + 1 >= pos && decide(sB, uB, dEB);
+                const unsigned long long mA = __ballot(fA), mB = __ballot(fB);
+                if ((mA | mB) == 0ull) break;  // the rest of the window is rejected
+                const int pA = mA ? 2 * (int)__builtin_ctzll(mA) : 1 << 20;
+                const int pB = mB ? 2 * (int)__builtin_ctzll(mB) + 1 : 1 << 20;
+                const int p = min(pA, pB);  // first accepted update of the window
+                const int src = p >> 1;
+                const int site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, src);
+                const double dE = read_lane((p & 1) ? dEB : dEA, src);
+                const int s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
+                if (W > 1) __syncthreads();  // every wave has evaluated against the old state
+                E += dE;
+                ++nacc;
+                apply_row(site, -2 * sc * s_old);
+                if (tid == 0) {
+                    bits[site >> 5] ^= 1u << (site & 31);
+                    if constexpr (!LEAN) {
+                        const long long upd = base + t0 + p;  // (trace buffers arrive zeroed: rejected = 0)
+                        if (a.accept_trace) a.accept_trace[upd] = 1;
+                        if (a.dE_trace) a.dE_trace[upd] = rule == SGA_RULE_HEAT_BATH ? -dE : dE;
+                    }
+                }
+                pos = p + 1;
+                __syncthreads();  // fields and spin of the new state are visible
+                if (pos >= CLF_WINDOW) break;
+            }
+        }
+        // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)
+        if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+        if (E < bestE && !a.no_best) {
+            bestE = E;
+            bits_to_spins(bits, a.best_spins + (long long)r * a.sstride, a.sstride, n, tid, blockDim.x);
+        }
+    }
+
+    __syncthreads();
+    {
+        int4 *dst = reinterpret_cast<int4 *>(reinterpret_cast<FT *>(a.fields) + (long long)r * a.ldf);
+        const int4 *src = reinterpret_cast<const int4 *>(F);
+        for (int i = tid; i < (int)(a.ldf * FB / 16); i += blockDim.x) dst[i] = src[i];
+        bits_to_spins(bits, a.spins + (long long)r * a.sstride, a.sstride, n, tid, blockDim.x);
+    }
+    if (tid == 0) {
+        a.energy[r] = E;
+        a.best_energy[r] = bestE;
+        a.n_accepted[r] += nacc;
+    }
+}
+
+}  // namespace sga

@@ -118,6 +118,13 @@ class AnnealEngine:
         code = {"auto": 0, "f32": 1, "packed": 2}[storage]
         N.check(self._lib.sga_set_csr_storage(self._h, code), "sga_set_csr_storage")
 
+    def set_field_cache(self, mode="on"):
+        """How sweeps evaluate a proposal (sga_set_field_cache): "off" = one coupling-row read per
+        proposal (the reference's get_local_field), "on" / "auto" = resident local fields, a row read
+        only on accept (the reference's incremental mode); identical chains."""
+        code = {"off": 0, False: 0, "on": 1, True: 1, "auto": 2}[mode]
+        N.check(self._lib.sga_set_field_cache(self._h, code), "sga_set_field_cache")
+
     def autotune(self) -> float:
         """Time every feasible waves-per-replica on the current replicas and keep the fastest
         (dense problems; results are unaffected).  Returns the best kernel ms per sweep."""
@@ -230,6 +237,7 @@ class AnnealEngine:
             cnt = keep.numel() if _is_tensor(keep) else keep.size
             if cnt != R * self.n:
                 raise AnnealingError("s0 must be [R, n] int8")
+        self.R = 0  # a failed call leaves the engine without replicas (include/sga.h)
         N.check(self._lib.sga_init_replicas(self._h, int(R), Rg, int(replica0),
                                             int(seed) & 0xFFFFFFFFFFFFFFFF, sp),
                 "sga_init_replicas")

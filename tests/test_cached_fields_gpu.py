@@ -1,0 +1,344 @@
+"""The cached-local-field sweep (sga_set_field_cache, csrc/sweep_clf_impl.h) and the all-replica
+field pass on the matrix cores (csrc/fields_dense.hip), through the C ABI, against the CPU oracle
+and the reference's golden vectors.
+
+The variant reads a coupling row only when a proposal is accepted, but its chain must be the
+one-row-per-proposal chain bit for bit: every test here compares it with the same oracle runs and
+reference fixtures as tests/test_engine_gpu.py does for the row-per-proposal kernels.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import spin_glass_anneal_rl_amd as m
+    return m
+
+
+def pm1(n, seed):
+    rng = np.random.RandomState(seed)
+    J = np.triu(rng.randint(0, 2, (n, n)) * 2 - 1, 1).astype(np.float32)
+    return J + J.T
+
+
+def int_couplings(n, seed, amp, density=1.0):
+    rng = np.random.RandomState(seed)
+    J = np.triu(rng.randint(-amp, amp + 1, (n, n)) * (rng.rand(n, n) < density), 1).astype(np.float32)
+    return J + J.T
+
+
+def ladder(R, tmax=10.0, tmin=0.1):
+    return np.asarray([tmax * (tmin / tmax) ** (i / max(R - 1, 1)) for i in range(R)])
+
+
+def check_against(e, ref, s, out):
+    assert np.array_equal(out["energy_trace"], ref["energy_trace"]), e.describe()
+    assert np.array_equal(e.spins(), s)
+    assert np.array_equal(e.energies(), ref["energy"])
+    assert np.array_equal(e.stats()[0], ref["n_accepted"])
+    for r in range(len(s)):
+        be, bs, _ = e.best(r)
+        assert be == ref["best_energy"][r] and np.array_equal(bs, ref["best_spins"][r])
+    e.recompute_energies()
+    assert np.array_equal(e.energies(), ref["energy"])
+
+
+# ----------------------------------------------------------------------------- Philox streams
+CLF_CASES = [
+    # (n, R, storage, clf waves: 0 = heuristic)
+    (64, 8, "f32", 0), (64, 8, "i8", 0), (63, 5, "f32", 0), (1, 3, "f32", 0), (2, 4, "i8", 0),
+    (129, 33, "i8", 0), (300, 6, "f32", 2), (1000, 40, "f32", 0), (1000, 7, "i8", 3),
+    (1100, 130, "f32", 5), (2500, 6, "f32", 0), (2500, 3, "i8", 2), (4100, 3, "i8", 0),
+    (4000, 4, "f32", 16), (10000, 2, "f32", 0), (10000, 3, "i8", 0), (10000, 2, "i8", 1),
+    (10000, 2, "t2", 0),
+]
+
+
+@pytest.mark.parametrize("n,R,storage,waves", CLF_CASES)
+def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves, monkeypatch):
+    if waves:
+        monkeypatch.setenv("SGA_CLF_WAVES", str(waves))
+    J = pm1(n, 10 + n)
+    h = np.random.RandomState(n).randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    ns = 4 if n >= 2500 else 12
+    temps = ladder(R, 6.0, 0.5)
+    seed = 0xC1F0000 + n
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("on")
+        e.set_dense(J, h, storage=storage)
+        e.init_replicas(R, seed=seed)
+        assert "sweep=cached-local-fields" in e.describe(), e.describe()
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        check_against(e, ref, s, out)
+
+
+@pytest.mark.parametrize("amp,n,bits", [(3, 500, 16), (100, 1000, 32), (127, 2000, 32)])
+@pytest.mark.parametrize("storage", ["f32", "i8"])
+def test_cached_fields_int16_and_int32(sg, amp, n, bits, storage):
+    """Row sums beyond int16 keep the fields as int32; hot and cold replicas; non-zero h."""
+    J = int_couplings(n, amp + n, amp, density=0.7)
+    h = np.random.RandomState(amp).randint(-amp, amp + 1, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    R, ns, seed = 6, 5, 77 + amp
+    temps = ladder(R, 40.0 * amp, 0.5 * amp)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("on")
+        e.set_dense(J, h, storage=storage)
+        e.init_replicas(R, seed=seed)
+        assert f"cached-local-fields(int{bits}" in e.describe(), e.describe()
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        check_against(e, ref, s, out)
+
+
+# ----------------------------------------------------------------------------- golden replay
+SWEEP_CASES = ["sweeps_pm1_n8", "sweeps_pm1_n16", "sweeps_pm1_n64", "sweeps_pm1_n64_cold",
+               "sweeps_field_n64", "sweeps_pm1_n300"]
+
+
+@pytest.mark.parametrize("storage", ["f32", "i8"])
+@pytest.mark.parametrize("name", SWEEP_CASES)
+def test_reference_sweeps_replayed_with_cached_fields(sg, name, storage):
+    """The reference's own recorded streams (sites, uniforms) -> its decisions, dE and energies."""
+    g = load_golden(name)
+    n, ns = g["J"].shape[0], int(g["n_sweeps"])
+    u = np.nan_to_num(g["u"], nan=2.0).astype(np.float32)
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("on")
+        e.set_dense(g["J"], g["h"], storage=storage)
+        e.init_replicas(1, seed=0, s0=g["s0"][None, :])
+        assert e.energies()[0] == float(g["e0"])
+        e.set_temperatures([float(g["T"])])
+        out = e.sweep(ns, site_mode=sg._native.SITE_REPLAY, replay_site=g["site"][None, :],
+                      replay_u=u[None, :], energy_trace=True, trace=True)
+        assert np.array_equal(out["accept_trace"][0].astype(bool), g["accepted"])
+        assert np.array_equal(out["dE_trace"][0], g["dE"])
+        assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+        assert np.array_equal(e.spins(0), g["s_final"])
+        assert e.stats()[0][0] == int(g["n_accepted"])
+
+
+RULE_CASES = [("sweeps_glauber_n64", 1), ("sweeps_heatbath_n64", 2)]
+
+
+@pytest.mark.parametrize("name,rule", RULE_CASES)
+def test_reference_glauber_heatbath_replayed_with_cached_fields(sg, name, rule):
+    g = load_golden(name)
+    n, ns = g["J"].shape[0], int(g["n_sweeps"])
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("on")
+        e.set_dense(g["J"], g["h"])
+        e.init_replicas(1, seed=0, s0=g["s0"][None, :])
+        e.set_temperatures([float(g["T"])])
+        e.set_update_rule(rule)
+        out = e.sweep(ns, site_mode=sg._native.SITE_REPLAY, replay_site=g["site"][None, :],
+                      replay_u=g["u"].astype(np.float32)[None, :], energy_trace=True, trace=True)
+        assert np.array_equal(out["accept_trace"][0].astype(bool), g["accepted"])
+        assert np.array_equal(out["dE_trace"][0], g["dE"])  # heat bath: minus the change
+        assert np.array_equal(out["energy_trace"][:, 0], g["sweep_energy"])
+        assert np.array_equal(e.spins(0), g["s_final"])
+
+
+@pytest.mark.parametrize("rule", [1, 2])
+@pytest.mark.parametrize("n,R,storage", [(64, 6, "f32"), (1100, 4, "i8")])
+def test_cached_fields_glauber_heatbath_match_oracle(sg, n, R, storage, rule):
+    J = pm1(n, 3 + n)
+    h = np.random.RandomState(n).randint(-2, 3, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    ns, seed = 5, 555 + n
+    temps = ladder(R, 30.0, 3.0)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, rule=rule, trace=True, n_threads=4)
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("on")
+        e.set_dense(J, h, storage=storage)
+        e.init_replicas(R, seed=seed)
+        e.set_temperatures(temps)
+        e.set_update_rule(rule)
+        out = e.sweep(ns, energy_trace=True, trace=True)
+        assert np.array_equal(out["accept_trace"], ref["accept_trace"])
+        assert np.array_equal(out["dE_trace"], ref["dE_trace"])
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+        assert np.array_equal(e.spins(), s)
+
+
+def test_cached_fields_sequential_order_and_operator_arithmetic(sg):
+    """The operator fallback's order and fp32 arithmetic (annealing/cuda_kernels.py:381-390)."""
+    n, R, ns = 130, 4, 5
+    J, h = pm1(n, 6), np.random.RandomState(1).randint(-1, 2, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    seed = 31337
+    u = np.random.RandomState(0).rand(R, ns * n).astype(np.float32)
+    for arith in (oracle.ARITH_F64, oracle.ARITH_F32):
+        s = oracle.init_spins(n, R, seed)
+        ref = oracle.sweeps(prob, s, 1.3, ns, site_mode=oracle.SITE_SEQUENTIAL, arith=arith,
+                            replay_u=u, seed=seed, trace=True)
+        with sg.AnnealEngine(0) as e:
+            e.set_field_cache("on")
+            e.set_dense(J, h, storage="f32")
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(np.full(R, 1.3))
+            out = e.sweep(ns, site_mode=sg._native.SITE_SEQUENTIAL, arith=arith, replay_u=u,
+                          energy_trace=True, trace=True)
+            assert np.array_equal(out["accept_trace"], ref["accept_trace"])
+            assert np.array_equal(out["dE_trace"], ref["dE_trace"])
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+            assert np.array_equal(e.spins(), s)
+
+
+# ----------------------------------------------------------------------------- state handling
+def test_cached_fields_survive_everything_that_moves_spins(sg):
+    """Single-site operators, set_spins, exchanges, checkpoints and switching the cache off and on
+    between calls: the chain stays the row-per-proposal chain."""
+    n, R, seed = 700, 5, 2024
+    J = int_couplings(n, 5, 4)
+    h = np.random.RandomState(2).randint(-3, 4, n).astype(np.float32)
+    temps = ladder(R, 60.0, 4.0)
+
+    def run(cache_plan):
+        with sg.AnnealEngine(0) as e:
+            e.set_dense(J, h)
+            e.init_replicas(R, seed=seed)
+            e.set_ladder(temps)
+            log = []
+            e.set_field_cache(cache_plan[0])
+            log.append(e.sweep(3, energy_trace=True)["energy_trace"])
+            e.flip(1, 17)
+            acc, dE = e.update(2, 5, 3.0, 0.25)
+            log.append(np.asarray([float(acc), dE]))
+            snew = -e.spins(3)
+            e.set_spins(3, snew)
+            e.set_field_cache(cache_plan[1])
+            log.append(e.sweep(2, energy_trace=True)["energy_trace"])
+            log.append(np.asarray([e.exchange()], float))
+            blob = e.export_state()
+            e.set_field_cache(cache_plan[2])
+            log.append(e.sweep(2, energy_trace=True)["energy_trace"])
+            after = e.energies().copy()
+            e.import_state(blob)
+            again = e.sweep(2, energy_trace=True)["energy_trace"]
+            assert np.array_equal(again, log[-1]) and np.array_equal(e.energies(), after)
+            tracked = e.energies()
+            e.recompute_energies()
+            assert np.array_equal(e.energies(), tracked)
+            return log, e.spins(), e.stats()[0]
+
+    base = run(("off", "off", "off"))
+    for plan in (("on", "on", "on"), ("on", "off", "on"), ("off", "on", "auto")):
+        got = run(plan)
+        for a, b in zip(base[0], got[0]):
+            assert np.array_equal(a, b), plan
+        assert np.array_equal(base[1], got[1]) and np.array_equal(base[2], got[2])
+
+
+def test_cached_fields_need_an_integer_symmetric_problem(sg):
+    n = 96
+    rng = np.random.RandomState(0)
+    Jg = np.triu(rng.randn(n, n), 1).astype(np.float32)
+    Jg = Jg + Jg.T
+    Ja = pm1(n, 1)
+    Ja[3, 5] += 1.0  # asymmetric
+    Jd = pm1(n, 2)
+    Jd[4, 4] = 2.0   # diagonal
+    hz = np.zeros(n, np.float32)
+    for J, h in ((Jg, hz), (Ja, hz), (Jd, hz), (pm1(n, 3), hz + 0.25)):
+        with sg.AnnealEngine(0) as e:
+            e.set_dense(J, h)
+            e.init_replicas(3, seed=1)
+            e.set_field_cache("on")
+            with pytest.raises(sg.AnnealingError, match="cached local fields"):
+                e.sweep(1)
+            e.set_field_cache("auto")  # falls back to the row-per-proposal kernels
+            assert "cached-local-fields" not in e.describe()
+            a = e.sweep(2, energy_trace=True)["energy_trace"]
+        with sg.AnnealEngine(0) as e:
+            e.set_dense(J, h)
+            e.init_replicas(3, seed=1)
+            assert np.array_equal(e.sweep(2, energy_trace=True)["energy_trace"], a)
+    with sg.AnnealEngine(0) as e:  # the Wolff rule keeps its own kernel
+        e.set_dense(pm1(n, 3), hz)
+        e.init_replicas(2, seed=1)
+        e.set_field_cache("on")
+        e.set_update_rule(3)
+        e.sweep(1)
+    with sg.AnnealEngine(0) as e:
+        with pytest.raises(sg.AnnealingError):
+            sg._native.check(e._lib.sga_set_field_cache(e._h, 7), "sga_set_field_cache")
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[1]
+def test_c2a_at_full_size_with_cached_fields(sg):
+    """10 000-spin dense +-1 SK instance, 1024 replicas (bench.py's variant): the oracle follows
+    replicas 0..2 (Philox streams are keyed by the global replica id); all replicas: tracked
+    energy == energy from scratch, and the row-per-proposal kernels give the same energies."""
+    import torch
+    import bench
+    n, R, seed, ns = 10000, 1024, 42, 3
+    J = bench.make_sk_instance(n, 2, torch.device("cuda", 0))
+    h = torch.zeros(n, device="cuda:0")
+    temps = ladder(R, 10.0, 0.1)
+    res = {}
+    for cache in ("on", "off"):
+        with sg.AnnealEngine(0) as e:
+            e.set_field_cache(cache)
+            e.set_dense(J, h, storage="f32" if cache == "off" else "auto")
+            e.init_replicas(R, seed=seed)
+            e.set_ladder(temps)
+            out = e.sweep(ns, energy_trace=True)
+            tracked = e.energies()
+            e.recompute_energies()
+            assert np.array_equal(e.energies(), tracked)
+            res[cache] = (out["energy_trace"], e.spins()[:4].copy(), e.stats()[0])
+    assert np.array_equal(res["on"][0], res["off"][0])
+    assert np.array_equal(res["on"][1], res["off"][1]) and np.array_equal(res["on"][2], res["off"][2])
+    k = 3
+    prob = oracle.Problem(J=J.cpu().numpy(), h=np.zeros(n, np.float32))
+    oracle.set_exact_f32(True)
+    try:
+        s = oracle.init_spins(n, k, seed)
+        ref = oracle.sweeps(prob, s, temps[:k], ns, seed=seed, n_threads=k)
+    finally:
+        oracle.set_exact_f32(False)
+    assert np.array_equal(res["on"][0][:, :k], ref["energy_trace"])
+    assert np.array_equal(res["on"][1][:k], s)
+
+
+# ----------------------------------------------------------------------------- all-replica field pass
+@pytest.mark.parametrize("kind", ["pm1", "int", "gauss"])
+@pytest.mark.parametrize("n,R", [(257, 32), (1000, 130), (3000, 200), (64, 64)])
+def test_matrix_core_energies_match_oracle(sg, n, R, kind):
+    """Energies of >= 32 replicas come from one pass over J on the matrix cores (i8 / f32 / f64 MFMA)."""
+    if kind == "pm1":
+        J = pm1(n, n)
+    elif kind == "int":
+        J = int_couplings(n, n, 90, density=0.5)
+    else:
+        rng = np.random.RandomState(n)
+        J = np.triu(rng.randn(n, n), 1).astype(np.float32)
+        J = J + J.T
+    h = (np.random.RandomState(5).randn(n) if kind == "gauss"
+         else np.random.RandomState(5).randint(-3, 4, n)).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    s0 = oracle.init_spins(n, R, 99)
+    want = oracle.energy(prob, s0)
+    for storage in (("f32", "i8") if kind != "gauss" else ("f32",)):
+        with sg.AnnealEngine(0) as e:
+            e.set_dense(J, h, storage=storage)
+            e.init_replicas(R, seed=99)
+            got = e.energies()
+            if kind == "gauss":  # fp64 accumulation in another order: equal to the rounding of the last bits
+                assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+            else:
+                assert np.array_equal(got, want)
