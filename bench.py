@@ -252,9 +252,13 @@ def main():
                          "the multi-rank path on one GPU together with --share-device)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="keep torch.distributed in the path at --gpus 1: a one-rank process group (RCCL "
+                         "with --backend nccl), started as a child process like the ranks of --gpus N; the "
+                         "exchange step all-gathers through it.  Results equal the plain run")
     a = ap.parse_args()
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (a.gpus > 1 or a.force_dist) and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus)  # before anything here has touched the GPU
     # stdout carries ONE JSON line and nothing else: whatever libraries print while the process
     # group comes up (gloo's "[Gloo] Rank 0 is connected to ..." goes to fd 1) is sent to stderr
@@ -272,9 +276,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one side stream for everything: torch's work (probes, RCCL collectives) and the engine's kernels
+    # are ordered by it, so an exchange round (energies -> all-gather -> exchange kernel) needs no
+    # host synchronisation
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     comm_dev = dev if a.backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -302,7 +310,10 @@ def main():
             dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
             bld = None
             tsp = None if a.implicit else enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
-            n_ladders, t_hot, t_cold = 32, 200.0, 2.0
+            # BASELINE configs[4]: 32 ladders x 64 temperatures over 8 GPUs = 4 ladders per GPU; a smaller
+            # replica count keeps the 64-temperature ladders (256 replicas on one GPU = one rank's share)
+            n_ladders = (R * world) // 64 if (R * world) % 64 == 0 else 32
+            t_hot, t_cold = 200.0, 2.0
             label = f"C5: {a.cities}-city TSP QUBO ({a.cities ** 2} spins)"
         n = bld.n if bld is not None else a.cities ** 2
     Rg = R * world
@@ -337,13 +348,43 @@ def main():
         del tsp
         torch.cuda.empty_cache()
     ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
-    pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42,
-                          slot_temps=ladder, n_ladders=n_ladders, dist=dist, device=comm_dev)
+    eng.set_field_cache("off")  # the graded figure: one coupling-row read per proposal
+
+    def tempering():
+        return ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42, slot_temps=ladder,
+                                n_ladders=n_ladders, dist=dist, device=comm_dev, force_dist=a.force_dist)
+
+    pt = tempering()
     implicit = a.workload == "c5" and a.implicit
     autotuned = (not a.no_autotune) and csr is None and a.waves == 0 and not implicit
     if autotuned:
-        eng.autotune()  # keeps its winner; sweeps per launch stay as set above
+        if dist is None:
+            eng.autotune()  # keeps its winner; sweeps per launch stay as set above
+        else:
+            # every rank times the SAME geometry: rank 0 measures, its winner is broadcast (results do
+            # not depend on the geometry, the pace of the slowest rank would)
+            w = torch.zeros(1, dtype=torch.int32, device=comm_dev)
+            if rank == 0:
+                eng.autotune()
+                w[0] = eng.geometry()[0]
+            dist.broadcast(w, src=0)
+            eng.set_tuning(waves_per_replica=int(w.item()), sweeps_per_launch=1)
+            pt = tempering()
     geometry = eng.describe()
+    # every rank must hold the same couplings (J is replicated, built per rank from a seeded generator)
+    checksum = eng.problem_checksum()
+    checksum_agree = True
+    if dist is not None:
+        mine = torch.tensor([checksum - (1 << 64) if checksum >= (1 << 63) else checksum], dtype=torch.int64,
+                            device=comm_dev)
+        every = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+        if a.backend == "nccl":
+            dist.all_gather_into_tensor(every, mine)
+        else:
+            dist.all_gather(list(every.chunk(world)), mine)
+        checksum_agree = bool((every == every[0]).all().item())
+        if not checksum_agree:
+            raise SystemExit(f"bench.py: ranks hold different couplings (checksums {every.tolist()})")
 
     def barrier():
         if dist is not None:
@@ -357,7 +398,7 @@ def main():
         pt.sweep(1)
         step_no += 1
         if a.exchange_interval > 0 and step_no % a.exchange_interval == 0:
-            pt.exchange()
+            pt.exchange(count=False)  # no read-back: the round stays on the stream
 
     # Bandwidth probes (the two practical denominators) before the warm-up, on every rank, so that
     # nothing but the steps and the final barrier lies between the warm-up and the end of timing.
@@ -423,6 +464,8 @@ def main():
         bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
     achieved = per_launch_attempts * bytes_per_attempt / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    kernel_inst = last_kernel()  # template arguments of what the timed steps launched
     # the committed PMC passes were taken on exactly these configurations
     pmc_tag = None
     if a.workload == "c2a" and (n, R) == (10000, 1024):
@@ -454,6 +497,7 @@ def main():
         "data": "synthetic",
         "ranks_seen": dist.get_world_size() if dist is not None else 1,
         "backend": (dist.get_backend() if dist is not None else None),
+        "couplings_checksum_agree": checksum_agree, "couplings_checksum": f"{checksum:016x}",
         "exchange": {"rounds_timed": pt.gather_calls, "allgather_ms_per_round":
                      (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
                      "bytes_per_rank": 8 * R},
@@ -478,7 +522,7 @@ def main():
                                      "WRITE_SIZE, separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": per_launch_attempts * bytes_per_attempt,
-                     "kernel": kernel_name,
+                     "kernel": kernel_name, "kernel_instantiation": kernel_inst,
                      "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "algorithmic_bytes_per_attempt": bytes_per_attempt},
     }
@@ -534,6 +578,68 @@ def main():
                 "note": "exact arithmetic, bit-identical chain to the fp32 layout" +
                         ("" if st == "i8" else "; 2 bits per coupling, popcount row sums "
                                                "(latency bound, not HBM bound)")}
+    # The cached-local-field sweep (sga_set_field_cache): the same chain bit for bit, a coupling row read
+    # only when a proposal is ACCEPTED.  A variant with its own byte model -- B = acceptance rate x row
+    # bytes per attempt (last sentence) -- reported beside the graded one-row-per-proposal
+    # figure, never instead of it.  Storage = what the engine picks by itself for these couplings.
+    if a.workload == "c2a" and world == 1 and not a.no_variants:
+        eng.set_tuning(waves_per_replica=0, sweeps_per_launch=1)
+        eng.set_dense(J, h, storage="auto")
+        eng.set_field_cache("on")
+        pt3 = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=1,
+                               dist=None, device=comm_dev)
+        row_bytes = float(n if "storage=f32" not in eng.describe() else 4 * n)
+        done = 0
+
+        def clf_steps(k):
+            nonlocal done
+            for _ in range(k):
+                pt3.sweep(1)
+                done += 1
+                if a.exchange_interval > 0 and done % a.exchange_interval == 0:
+                    pt3.exchange(count=False)
+
+        def clf_timed(k):
+            torch.cuda.synchronize()
+            acc0 = int(eng.stats()[0].sum())
+            eng.enable_timing(True)
+            eng.kernel_time(reset=True)
+            t1 = time.perf_counter()
+            clf_steps(k)
+            torch.cuda.synchronize()
+            dtv = time.perf_counter() - t1
+            lv, msv = eng.kernel_time(reset=True)
+            eng.enable_timing(False)
+            rate = (int(eng.stats()[0].sum()) - acc0) / (float(R) * n * k)
+            val = float(R) * n * k / dtv
+            return {"value": val, "unit": "attempts/s", "ms_per_step": dtv / k * 1e3,
+                    "kernel_ms_per_step": msv / max(lv, 1), "acceptance_rate": rate,
+                    "algorithmic_bytes_per_attempt": rate * row_bytes,
+                    "achieved_GBs": val * rate * row_bytes / 1e9}
+
+        clf_steps(a.warmup)
+        first = clf_timed(a.steps)          # the same sweeps the headline times
+        clf_steps(max(0, 100 - done))
+        later = clf_timed(a.steps)          # after 100 sweeps of the same ladder
+        tracked = eng.energies()
+        eng.recompute_energies()
+        exact = bool(np.array_equal(tracked, eng.energies()))
+        out.setdefault("variants", {})["cached_local_fields"] = {
+            **first, "sweeps": f"{a.warmup}..{a.warmup + a.steps} (the headline's)",
+            "after_100_sweeps": later,
+            "tracked_energy_equals_recomputed": exact,
+            "kernel_instantiation": last_kernel(), "geometry": eng.describe(),
+            "roofline": {"bound": "latency (one serial chain per replica: evaluation rounds + one row fetch per "
+                                  "accept)", "byte_model": "B = acceptance rate x row bytes per attempt",
+                         "row_bytes": row_bytes, "achieved": first["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": first["achieved_GBs"] / HBM_PEAK_GBS},
+            "note": "bit-identical chain to the headline kernel (same Philox sites and uniforms, same accept rule; "
+                    "tests/test_cached_fields_gpu.py): local fields resident in LDS, seeded by one MFMA pass over J; "
+                    "speed-up over the headline = value / headline value"}
+        eng.set_field_cache("off")
+        eng.set_dense(J, h, storage=a.storage)
+        pt = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=1,
+                              dist=None, device=comm_dev)
     # C4's couplings are small integers: what the engine picks by itself there is one dword per entry
     # (24-bit column | 8-bit value), half the bytes of a row, the same chain -- a storage variant
     # with its own byte model, reported beside the fp32-value figure

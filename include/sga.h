@@ -213,6 +213,10 @@ int sga_op_pt_exchange(int device, float *spins, float *energies, const float *t
 
 /* ---- state access --------------------------------------------------------------------- */
 int sga_get_energies(sga_engine *e, double *out /* [R_local] */);
+/* Stream-ordered form for a DEVICE destination: the copy is enqueued on the engine's stream and the
+ * call returns at once -- for consumers ordered behind that stream (sga_set_stream with the caller's
+ * stream: an RCCL all-gather of the energies followed by sga_exchange needs no host synchronisation). */
+int sga_get_energies_async(sga_engine *e, double *out_device /* [R_local] */);
 int sga_get_temperatures(sga_engine *e, double *out /* [R_local] */);
 int sga_get_spins(sga_engine *e, int r, int8_t *out /* [n]; r<0: all, [R_local][n] */);
 int sga_set_spins(sga_engine *e, int r, const int8_t *s /* recomputes that energy */);
@@ -255,6 +259,15 @@ int sga_get_kernel_time(sga_engine *e, int64_t *n_launches, double *total_ms, in
 /* Describes the launch geometry chosen for the current problem (for DESIGN/bench output):
  * writes a NUL-terminated string into buf. */
 int sga_describe(sga_engine *e, char *buf, int buflen);
+/* 64-bit checksum of the problem as the sweep kernels read it (packed couplings / entry layout /
+ * distance tables, and h).  Ranks of a sharded run compare it after set-up: every rank must hold the
+ * same couplings (the reference replicates the model per device, annealing/multi_gpu.py:110-132). */
+int sga_problem_checksum(sga_engine *e, uint64_t *out);
+/* Launch geometry of the dense sweep kernels (sga_set_tuning / sga_autotune / heuristic). */
+int sga_get_geometry(sga_engine *e, int *waves_per_replica, int *chunks_per_wave);
+/* Measurement aid: the kernel instantiation (template arguments, waves per replica) that the calling
+ * thread's last sga_sweep launched -- what a rocprofv3 trace of the same command must show. */
+int sga_last_kernel(char *buf, int buflen);
 /* Measurement aid: GB/s of a plain streaming read (16 bytes per lane) of a fresh `bytes`-byte
  * device buffer, `reps` passes -- the practical bandwidth of this device beside its spec figure. */
 int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per_s);

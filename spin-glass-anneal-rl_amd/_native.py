@@ -45,6 +45,7 @@ SYMBOLS = [
     ("sga_exchange_pairs", _i, [_p, _p, _p, _p, _i, C.POINTER(_i)]),
     ("sga_op_pt_exchange", _i, [_i, _p, _p, _p, _p, _u64, _u32, _i, _i, C.POINTER(_i)]),
     ("sga_get_energies", _i, [_p, _p]),
+    ("sga_get_energies_async", _i, [_p, _p]),
     ("sga_get_temperatures", _i, [_p, _p]),
     ("sga_get_spins", _i, [_p, _i, _p]),
     ("sga_set_spins", _i, [_p, _i, _p]),
@@ -62,6 +63,9 @@ SYMBOLS = [
     ("sga_enable_timing", _i, [_p, _i]),
     ("sga_get_kernel_time", _i, [_p, C.POINTER(_i64), C.POINTER(_d), _i]),
     ("sga_describe", _i, [_p, C.c_char_p, _i]),
+    ("sga_problem_checksum", _i, [_p, C.POINTER(_u64)]),
+    ("sga_get_geometry", _i, [_p, C.POINTER(_i), C.POINTER(_i)]),
+    ("sga_last_kernel", _i, [C.c_char_p, _i]),
     ("sga_set_csr_storage", _i, [_p, _i]),
     ("sga_set_field_cache", _i, [_p, _i]),
     ("sga_set_tuning", _i, [_p, _i, _i]),

@@ -1580,7 +1580,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             a.ldf = e->ldf;
             a.field_bits = e->clf_bits;
             a.field_scale = e->clf_scale;
-            le = sga::launch_sweep_clf(a, e->want_i8, sga::sweep_clf_waves(e->ldj, e->want_i8), st);
+            le = sga::launch_sweep_clf(a, e->want_i8, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus), st);
         } else if (wolff) {
             const sga::WolffArgs wa{e->wolff_u, e->wolff_cap, e->wolff_cursor};
             le = sga::launch_sweep_wolff(a, wa, e->csr, e->want_i8, st);
@@ -2279,8 +2279,57 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (clf_active(e))
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                       " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
-                      e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8));
+                      e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus));
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
+    return SGA_OK;
+}
+
+int sga_problem_checksum(sga_engine *e, uint64_t *out) {
+    if (!e || !out) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->n <= 0) return fail(SGA_ERR_INVALID, "no couplings set");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(e->point_out.reserve(2 * sizeof(unsigned long long)));
+    unsigned long long *d = static_cast<unsigned long long *>(e->point_out.ptr);
+    HIPCHK(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), e->stream));
+    // what the sweep kernels read: the packed matrix | the entry layout | the distance tables; then h
+    if (e->tsp) {
+        const long long bytes = 4ll * e->tsp_args.n_cities * e->tsp_args.npad;
+        HIPCHK(sga::launch_checksum(e->nd4, bytes, d, e->stream));
+        HIPCHK(sga::launch_checksum(e->nd4t, bytes, d, e->stream));
+    } else if (e->csr) {
+        HIPCHK(sga::launch_checksum(e->cv, 8ll * e->layout_entries, d, e->stream));
+        HIPCHK(sga::launch_checksum(e->rowptr64, 8ll * ((long long)e->n + 1), d, e->stream));
+    } else {
+        HIPCHK(sga::launch_checksum(e->J_packed, (long long)e->n_models * e->n * e->ldj * (e->want_i8 ? 1 : 4), d,
+                                    e->stream));
+    }
+    HIPCHK(sga::launch_checksum(e->h, 4ll * e->n * (e->tsp ? 1 : e->n_models), d + 1, e->stream));
+    unsigned long long host[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = host[0] ^ ((host[1] << 17) | (host[1] >> 47)) ^ ((uint64_t)(uint32_t)e->n << 32);
+    return SGA_OK;
+}
+
+int sga_get_geometry(sga_engine *e, int *waves_per_replica, int *chunks_per_wave) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    if (waves_per_replica) *waves_per_replica = (!e->csr && !e->tsp && e->use_t2) ? e->waves_t2 : e->waves;
+    if (chunks_per_wave) *chunks_per_wave = (!e->csr && !e->tsp && e->use_t2) ? e->cpw_t2 : e->cpw;
+    return SGA_OK;
+}
+
+int sga_get_energies_async(sga_engine *e, double *out_device) {
+    if (!e || !out_device) return fail(SGA_ERR_INVALID, "NULL argument");
+    if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas");
+    if (!is_device_ptr(out_device)) return fail(SGA_ERR_INVALID, "sga_get_energies_async needs a device buffer");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(out_device, e->energy, sizeof(double) * e->R, hipMemcpyDeviceToDevice, e->stream));
+    return SGA_OK;
+}
+
+int sga_last_kernel(char *buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(SGA_ERR_INVALID, "bad arguments");
+    std::snprintf(buf, (size_t)buflen, "%s", sga::last_sweep_kernel());
     return SGA_OK;
 }
 

@@ -6,6 +6,11 @@
 
 namespace sga {
 
+// The instantiation the last sweep launch of this thread ran (measurement: bench.py writes it beside
+// the roofline figure, so that a profile can be matched to the timed kernel).
+void note_sweep_kernel(const char *fmt, ...);
+const char *last_sweep_kernel();
+
 // Raise a kernel's dynamic-LDS limit once per (device, kernel, size), not on every launch.
 hipError_t ensure_lds_limit(const void *kernel, size_t lds_bytes);
 
@@ -132,7 +137,7 @@ hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t 
 // cached-local-field sweep: dense integer-valued symmetric problems
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
-int sweep_clf_waves(long long ldj, bool j_is_i8);
+int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus);
 
 struct ExchangeArgs {
     const double *energies;   // [R_global] by global replica id
@@ -229,6 +234,8 @@ hipError_t launch_csr_symmetry(const long long *rowptr, const int32_t *colidx, c
 hipError_t launch_copy_best(const double *energy, const int8_t *spins, double *best_energy,
                             int8_t *best_spins, int sstride, int R, hipStream_t st);
 
+// *out += position-weighted checksum of the 32-bit words of buf (sga_problem_checksum)
+hipError_t launch_checksum(const void *buf, long long bytes, unsigned long long *out, hipStream_t st);
 // streaming read of `bytes` (a multiple of 16) of device memory, for the bandwidth probe
 hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipStream_t st);
 

@@ -1,6 +1,8 @@
 // sga_misc.hip -- the kernels around the sweep: coupling repack, spin init, full energy
 // evaluation, replica exchange.
 #include <algorithm>
+#include <cstdarg>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -1045,6 +1047,31 @@ __global__ void __launch_bounds__(256) probe_read_kernel(const float4 *__restric
     }
     if (acc == 123456.789f) *sink = acc;  // keeps the loads alive
 }
+// Position-weighted 64-bit checksum of a word array (commutative accumulation: deterministic):
+// sum_i (w_i + 1) * (2 i + 1) * 0x9E3779B97F4A7C15 mod 2^64, added to *out.
+__global__ void __launch_bounds__(256) checksum_kernel(const unsigned int *w, long long count, unsigned long long *out) {
+    unsigned long long acc = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        acc += ((unsigned long long)w[i] + 1ull) * (2ull * (unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull;
+    // wave sum through two 32-bit halves would lose the carries: add lane by lane with readlane
+    unsigned long long tot = 0;
+    for (int l = 0; l < 64; ++l) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)acc, l);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(acc >> 32), l);
+        tot += ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, tot);
+}
+hipError_t launch_checksum(const void *buf, long long bytes, unsigned long long *out, hipStream_t st) {
+    const long long words = bytes / 4;
+    if (words <= 0) return hipSuccess;
+    const int blocks = (int)std::min<long long>(4096, (words + 255) / 256);
+    hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned int *>(buf), words,
+                       out);
+    return hipGetLastError();
+}
+
 hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipStream_t st) {
     hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 32), dim3(256), 0, st,
                        static_cast<const float4 *>(buf), bytes / 16, sink);
@@ -1053,6 +1080,15 @@ hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipS
 }  // namespace sga
 
 namespace sga {
+static thread_local char g_sweep_kernel[192] = "";
+void note_sweep_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_sweep_kernel, sizeof(g_sweep_kernel), fmt, ap);
+    va_end(ap);
+}
+const char *last_sweep_kernel() { return g_sweep_kernel; }
+
 hipError_t ensure_lds_limit(const void *kernel, size_t lds_bytes) {
     if (lds_bytes <= 48 * 1024) return hipSuccess;
     static std::mutex mu;

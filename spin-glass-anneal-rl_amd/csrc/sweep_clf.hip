@@ -7,13 +7,22 @@ size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table
     return clf_lds_bytes(ldf, field_bits / 8, sstride, table_m);
 }
 
-// waves per replica: enough that a wave asks for its share of a row in one batch of loads
-int sweep_clf_waves(long long ldj, bool j_is_i8) {
-    static const int forced = std::getenv("SGA_CLF_WAVES") ? std::atoi(std::getenv("SGA_CLF_WAVES")) : 0;  // A/B switch
-    if (forced >= 1 && forced <= MAX_WAVES) return forced;
+// waves per replica: enough that a wave asks for its share of a row in one batch of loads, as long as
+// every replica stays resident (32 waves per CU)
+int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus) {
+    const char *env = std::getenv("SGA_CLF_WAVES");  // A/B switch, parity tests
+    const int forced = env ? std::atoi(env) : 0;
+    if (forced >= 1) return std::min(forced, CLF_MAX_WAVES);
     const int epc = j_is_i8 ? 1024 : 256;
     const int chunks = (int)((ldj + epc - 1) / epc);
-    return std::max(1, std::min(MAX_WAVES, (chunks + CLF_BATCH - 1) / CLF_BATCH));
+    const int per_cu = std::max(1, (R + std::max(cus, 1) - 1) / std::max(cus, 1));
+    const int cap = std::max(1, std::min(CLF_MAX_WAVES, 32 / per_cu));
+    // about three chunks per wave, from {1, 2, 3, 4, 8} (measured at 10 chunks, 1024 replicas: 1 / 2 / 3 / 4 /
+    // 6 / 8 waves -> 0.28 / 0.19 / 0.175 / 0.167 / 0.173 / 0.165 ms per cold sweep, 9.3 / 6.6 / 7.2 / 7.1 /
+    // 15.0 / 11.4 ms for the first, hot one: profiles/r03_experiments.md)
+    const int want = (chunks + 2) / 3;
+    const int pick = want <= 4 ? std::max(want, 1) : 8;
+    return std::max(1, std::min(cap, pick));
 }
 
 template <typename JT, typename FT>
@@ -25,11 +34,13 @@ static hipError_t launch_clf(const SweepArgs &a, int waves, hipStream_t st) {
     hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
+    note_sweep_kernel("sweep_clf_kernel<%s, %s, %s> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
+                      sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", waves);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st) {
-    if (waves < 1 || waves > MAX_WAVES || !a.fields || (a.field_bits != 16 && a.field_bits != 32) ||
+    if (waves < 1 || waves > CLF_MAX_WAVES || !a.fields || (a.field_bits != 16 && a.field_bits != 32) ||
         (a.ldf * (a.field_bits / 8)) % 16 != 0 || a.sstride % 32 != 0)
         return hipErrorInvalidValue;
     if (j_is_i8)

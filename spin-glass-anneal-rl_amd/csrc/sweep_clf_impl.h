@@ -34,7 +34,8 @@
 namespace sga {
 
 constexpr int CLF_WINDOW = 128;  // updates evaluated together: two per lane
-constexpr int CLF_BATCH = 4;     // row chunks a wave requests together
+constexpr int CLF_BATCH = 5;     // row chunks a wave requests together
+constexpr int CLF_MAX_WAVES = 8; // waves per replica (512 threads: up to 256 VGPRs for the two row buffers)
 
 // The accept rule as a function of the exact local field (sum + h): what metropolis_accept
 // (sweep_common.h) computes from (double)dot + (double)h -- the diagonal term of the fp32 operator
@@ -76,12 +77,12 @@ __host__ __device__ constexpr long long clf_bits_offset(long long ldf, int fbyte
 __host__ __device__ constexpr long long clf_table_offset(long long ldf, int fbytes, int sstride) {
     return clf_bits_offset(ldf, fbytes) + ((sstride / 8 + 15) & ~15);
 }
-inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {
-    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 1) + 16;
+inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {  // + [2][CLF_MAX_WAVES][8] decision slots
+    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 2) + 2 * 32 * CLF_MAX_WAVES + 16;
 }
 
 template <typename JT, typename FT, bool LEAN>
-__global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
+__global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const SweepArgs a) {
     constexpr int EPL = 16 / (int)sizeof(JT), EPC = 64 * EPL;  // elements per lane / per 1-KiB chunk
     constexpr int FB = (int)sizeof(FT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -97,7 +98,6 @@ __global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     const int sc = a.field_scale;
     const double inv_sc = 1.0 / (double)sc;  // 1 | 0.5: exact
-    const bool use_tab = LEAN && a.table_m > 0;
 
     {   // resident state -> LDS
         const int4 *src = reinterpret_cast<const int4 *>(reinterpret_cast<const FT *>(a.fields) + (long long)r * a.ldf);
@@ -113,95 +113,140 @@ __global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
     unsigned long long nacc = 0;
     double T = 1.0;
 
-    // F_j -= 2 scale J_ij s_i over this wave's chunks of row i
-    auto apply_row = [&](int site, int mult /* -2 scale s_i(old) */) {
+    // A row is dealt to the waves in 1-KiB chunks: chunk c -> wave c mod W.  The first CLF_BATCH chunks of
+    // a wave are requested together into registers (row_request: unconditional loads -- a lane past the
+    // row's end reads the row's first granule -- so that requests for a PREDICTED accept can stay in
+    // flight across the evaluation of the next round with counted waits); rows longer than
+    // CLF_BATCH * W chunks stream the rest inside apply_row.
+    using vec_t = typename std::conditional<sizeof(JT) == 4, float4, int4>::type;
+    struct RowRegs {
+        vec_t x[CLF_BATCH];
+    };
+    auto elem0 = [&](int c) -> long long { return ((long long)c * 64 + lane) * EPL; };
+    auto row_request = [&](int site) -> RowRegs {
+        RowRegs o;
         const JT *row = Jbase + (long long)site * a.ldj;
-        for (int c0 = w; c0 < n_chunks; c0 += CLF_BATCH * W) {
-            using vec_t = typename std::conditional<sizeof(JT) == 4, float4, int4>::type;
-            vec_t x[CLF_BATCH];
-            bool in[CLF_BATCH];
 #pragma unroll
-            for (int q = 0; q < CLF_BATCH; ++q) {
-                const long long j0 = ((long long)(c0 + q * W) * 64 + lane) * EPL;
-                in[q] = (c0 + q * W) < n_chunks && j0 < a.ldj;
-                if (in[q]) x[q] = *reinterpret_cast<const vec_t *>(row + j0);
+        for (int q = 0; q < CLF_BATCH; ++q) {
+            const long long j0 = elem0(w + q * W);
+            o.x[q] = *reinterpret_cast<const vec_t *>(row + (j0 < a.ldj ? j0 : 0));
+        }
+        return o;
+    };
+    // F_j -= 2 scale J_ij s_i for the EPL couplings x = J[i][j0 .. j0 + EPL)
+    auto apply_chunk = [&](const vec_t &x, long long j0, int mult /* -2 scale s_i(old) */) {
+        if constexpr (sizeof(JT) == 4) {
+            const int d0 = mult * (int)x.x, d1 = mult * (int)x.y, d2 = mult * (int)x.z, d3 = mult * (int)x.w;
+            if constexpr (FB == 2) {
+                int2 f = *reinterpret_cast<int2 *>(F + j0);
+                f.x = add_pair(f.x, d0, d1);
+                f.y = add_pair(f.y, d2, d3);
+                *reinterpret_cast<int2 *>(F + j0) = f;
+            } else {
+                int4 f = *reinterpret_cast<int4 *>(F + j0);
+                f.x += d0, f.y += d1, f.z += d2, f.w += d3;
+                *reinterpret_cast<int4 *>(F + j0) = f;
             }
+        } else {
+            const int wds[4] = {x.x, x.y, x.z, x.w};
+            if constexpr (FB == 2) {
+                // Four couplings per dword -> two dwords of int16 pairs, in packed 16-bit arithmetic:
+                // v_perm_b32 puts a coupling into the HIGH byte of each half (b << 8), one packed
+                // arithmetic shift right by 8 - log2 |mult| makes it |mult| * b, one packed add or subtract
+                // applies it: 3 instructions per pair.  |mult| = 2 scale is 2 or 4.
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
+                int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
+                const short sh = (short)(sc == 1 ? 7 : 6);
+                const short2v shv = {sh, sh};
 #pragma unroll
-            for (int q = 0; q < CLF_BATCH; ++q) {
-                if (!in[q]) continue;
-                const long long j0 = ((long long)(c0 + q * W) * 64 + lane) * EPL;
-                if constexpr (sizeof(JT) == 4) {
-                    const int d0 = mult * (int)x[q].x, d1 = mult * (int)x[q].y, d2 = mult * (int)x[q].z,
-                              d3 = mult * (int)x[q].w;
-                    if constexpr (FB == 2) {
-                        int2 f = *reinterpret_cast<int2 *>(F + j0);
-                        f.x = add_pair(f.x, d0, d1);
-                        f.y = add_pair(f.y, d2, d3);
-                        *reinterpret_cast<int2 *>(F + j0) = f;
-                    } else {
-                        int4 f = *reinterpret_cast<int4 *>(F + j0);
-                        f.x += d0, f.y += d1, f.z += d2, f.w += d3;
-                        *reinterpret_cast<int4 *>(F + j0) = f;
-                    }
-                } else {
-                    const int wds[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
-                    if constexpr (FB == 2) {
-                        int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
-                        int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned int t01 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x050c040cu);
+                    const unsigned int t23 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x070c060cu);
+                    const short2v v01 = __builtin_bit_cast(short2v, t01) >> shv;
+                    const short2v v23 = __builtin_bit_cast(short2v, t23) >> shv;
+                    short2v lo = __builtin_bit_cast(short2v, *fp[2 * d]), hi = __builtin_bit_cast(short2v, *fp[2 * d + 1]);
+                    if (mult < 0) lo -= v01, hi -= v23;  // wave-uniform
+                    else lo += v01, hi += v23;
+                    *fp[2 * d] = __builtin_bit_cast(int, lo);
+                    *fp[2 * d + 1] = __builtin_bit_cast(int, hi);
+                }
+                *reinterpret_cast<int4 *>(F + j0) = f0;
+                *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
+            } else {
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) {  // four couplings per dword -> two dwords of int16 pairs
-                            const int b0 = (int)(int8_t)(wds[d]), b1 = (int)(int8_t)(wds[d] >> 8),
-                                      b2 = (int)(int8_t)(wds[d] >> 16), b3 = wds[d] >> 24;
-                            int &lo = *fp[2 * d], &hi = *fp[2 * d + 1];
-                            lo = add_pair(lo, mult * b0, mult * b1);
-                            hi = add_pair(hi, mult * b2, mult * b3);
-                        }
-                        *reinterpret_cast<int4 *>(F + j0) = f0;
-                        *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
-                            f.x += mult * (int)(int8_t)(wds[d]);
-                            f.y += mult * (int)(int8_t)(wds[d] >> 8);
-                            f.z += mult * (int)(int8_t)(wds[d] >> 16);
-                            f.w += mult * (wds[d] >> 24);
-                            *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
-                        }
-                    }
+                for (int d = 0; d < 4; ++d) {
+                    int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
+                    f.x += mult * (int)(int8_t)(wds[d]);
+                    f.y += mult * (int)(int8_t)(wds[d] >> 8);
+                    f.z += mult * (int)(int8_t)(wds[d] >> 16);
+                    f.w += mult * (wds[d] >> 24);
+                    *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
                 }
             }
         }
     };
+    auto apply_row = [&](const RowRegs &rr, int site, int mult) {
+#pragma unroll
+        for (int q = 0; q < CLF_BATCH; ++q) {
+            const long long j0 = elem0(w + q * W);
+            if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult);
+        }
+        const JT *row = Jbase + (long long)site * a.ldj;
+        for (int c0 = w + CLF_BATCH * W; c0 < n_chunks; c0 += CLF_BATCH * W) {  // (long rows only)
+            vec_t x[CLF_BATCH];
+#pragma unroll
+            for (int q = 0; q < CLF_BATCH; ++q) {
+                const long long j0 = elem0(c0 + q * W);
+                x[q] = *reinterpret_cast<const vec_t *>(row + (j0 < a.ldj ? j0 : 0));
+            }
+#pragma unroll
+            for (int q = 0; q < CLF_BATCH; ++q) {
+                const long long j0 = elem0(c0 + q * W);
+                if (j0 < a.ldj) apply_chunk(x[q], j0, mult);
+            }
+        }
+    };
 
-    // one candidate against the current state: flips?  dE of the flip
-    auto decide = [&](int site, float u, double &dE) -> bool {
+    // One candidate against the current state: does it flip, and the dE of the flip.
+    // Production build: branch free -- the table covers k <= table_m (entry 0 = 1 serves every downhill
+    // move: u < 1 always), the few moves beyond it are evaluated behind a wave-uniform test.
+    auto decide = [&](int site, float u, bool live, double &dE) -> bool {
         const int f = (int)F[site];
         const int si = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
         if constexpr (LEAN) {
             const int k = si * f;  // dE = 2 k / scale
             dE = (double)(2 * k) * inv_sc;
-            if (k <= 0) return true;
-            if (use_tab && k <= a.table_m) return u < ptab[k];
-            if (dE > T * 104.0) return false;  // p == 0 past -104 (sweep_common.h)
-            return u < expf_det((float)(-dE / T));
+            bool acc = u < ptab[min(max(k, 0), a.table_m)];
+            const bool beyond = live && k > a.table_m;
+            if (__ballot(beyond)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
+                if (beyond) acc = !(dE > T * 104.0) && u < expf_det((float)(-dE / T));
+            }
+            return live && acc;
         } else {
-            return field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, dE);
+            return live && field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, dE);
         }
     };
+    // what a wave found in its window, for the other waves: [2][CLF_MAX_WAVES][8] ints behind the accept
+    // table, the two halves taking turns (a wave may run one round ahead of a wave still reading)
+    int *slots2 = reinterpret_cast<int *>(ptab + ((a.table_m + 2) & ~1));
+    int turn = 0;
+    constexpr int NONE = 1 << 20;
 
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
-        if (use_tab) {  // exp(float32(-dE/T)) of the moves dE = 2 q / scale, q <= table_m
+        if constexpr (LEAN) {  // exp(float32(-dE/T)) of the moves dE = 2 q / scale, q <= table_m
             __syncthreads();
             for (int q = tid; q <= a.table_m; q += blockDim.x)
                 ptab[q] = expf_det((float)(-((double)(2 * q) * inv_sc) / T));
             __syncthreads();
         }
         const long long base = (long long)r * a.replay_stride + (long long)k * n;
-        for (int t0 = 0; t0 < n; t0 += CLF_WINDOW) {
-            // this lane's two candidates: updates t0 + 2 lane and t0 + 2 lane + 1 of sweep k
-            const int tA = t0 + 2 * lane, tB = tA + 1;
+        // W consecutive windows at a time, one per wave: positions [0, 128 W) of the super-window
+        for (int t0 = 0; t0 < n; t0 += CLF_WINDOW * W) {
+            // this lane's two candidates: updates tA and tA + 1 of sweep k
+            const int gA = w * CLF_WINDOW + 2 * lane, gB = gA + 1;  // positions in the super-window
+            const int tA = t0 + gA, tB = tA + 1;
             const bool vA = tA < n, vB = tB < n;
             int sA = 0, sB = 0;
             float uA = 2.0f, uB = 2.0f;
@@ -228,24 +273,79 @@ __global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
                     }
                 }
             }
-            int pos = 0;  // window positions below pos are decided
+            int pos = 0;  // super-window positions below pos are decided
+            // The row of the accept after this one is requested ahead: of the candidates that accept
+            // against the current state, the second is very likely still the next accept once the
+            // first has been applied (one flip moves a field by 2 |J|), so its row travels while
+            // this accept is applied and the rest is evaluated again.
+            RowRegs nxt;
+            int nxt_pos = -1;  // super-window position whose row `nxt` holds (-1: none)
+            auto first_of = [](unsigned long long mA, unsigned long long mB) -> int {
+                const int pA = mA ? 2 * (int)__builtin_ctzll(mA) : NONE;
+                const int pB = mB ? 2 * (int)__builtin_ctzll(mB) + 1 : NONE;
+                return min(pA, pB);
+            };
             for (;;) {
+                // this wave's window: first and second candidate that flip against the current state
                 double dEA = 0.0, dEB = 0.0;
-                const bool fA = vA && 2 * lane >= pos && decide(sA, uA, dEA);
-                const bool fB = vB && 2 * lane + 1 >= pos && decide(sB, uB, dEB);
-                const unsigned long long mA = __ballot(fA), mB = __ballot(fB);
-                if ((mA | mB) == 0ull) break;  // the rest of the window is rejected
-                const int pA = mA ? 2 * (int)__builtin_ctzll(mA) : 1 << 20;
-                const int pB = mB ? 2 * (int)__builtin_ctzll(mB) + 1 : 1 << 20;
-                const int p = min(pA, pB);  // first accepted update of the window
-                const int src = p >> 1;
-                const int site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, src);
-                const double dE = read_lane((p & 1) ? dEB : dEA, src);
+                const bool fA = decide(sA, uA, vA && gA >= pos, dEA);
+                const bool fB = decide(sB, uB, vB && gB >= pos, dEB);
+                unsigned long long mA = __ballot(fA), mB = __ballot(fB);
+                int p = first_of(mA, mB), p2 = NONE, site = 0, site2 = 0;
+                double dE = 0.0;
+                if (p < NONE) {
+                    if (p & 1) mB &= mB - 1;
+                    else mA &= mA - 1;
+                    p2 = first_of(mA, mB);
+                    site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, p >> 1);
+                    dE = read_lane((p & 1) ? dEB : dEA, p >> 1);
+                    if (p2 < NONE) site2 = __builtin_amdgcn_readlane((p2 & 1) ? sB : sA, p2 >> 1);
+                    p += w * CLF_WINDOW;
+                    if (p2 < NONE) p2 += w * CLF_WINDOW;
+                }
+                if (W > 1) {
+                    // the earliest window with an accept decides; the predicted next accept is that wave's
+                    // second, else the first of a later wave
+                    int *slots = slots2 + turn * (8 * CLF_MAX_WAVES);
+                    turn ^= 1;
+                    int *mine = slots + 8 * w;
+                    if (lane == 0) {
+                        mine[0] = p, mine[1] = p2, mine[2] = site, mine[3] = site2;
+                        *reinterpret_cast<double *>(mine + 4) = dE;
+                    }
+                    __syncthreads();  // (A) every wave has evaluated against the old state and published
+                    const int q0 = lane < W ? slots[8 * lane] : NONE;
+                    const unsigned long long have = __ballot(q0 < NONE);
+                    if (have == 0ull) {
+                        p = NONE;
+                    } else {
+                        const int wf = (int)__builtin_ctzll(have);
+                        const int *win = slots + 8 * wf;
+                        p = win[0], p2 = win[1], site = win[2], site2 = win[3];
+                        dE = *reinterpret_cast<const double *>(win + 4);
+                        const unsigned long long later = have & (have - 1);
+                        if (p2 >= NONE && later) {
+                            const int *nx = slots + 8 * (int)__builtin_ctzll(later);
+                            p2 = nx[0], site2 = nx[2];
+                        }
+                        p = __builtin_amdgcn_readfirstlane(p), p2 = __builtin_amdgcn_readfirstlane(p2);
+                        site = __builtin_amdgcn_readfirstlane(site), site2 = __builtin_amdgcn_readfirstlane(site2);
+                    }
+                }
+                if (p >= NONE) break;  // the rest of the super-window is rejected
                 const int s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
-                if (W > 1) __syncthreads();  // every wave has evaluated against the old state
+                RowRegs cur;
+                if (nxt_pos == p) {
+                    cur = nxt;
+                    if (p2 < NONE) nxt = row_request(site2);
+                } else {
+                    cur = row_request(site);
+                    if (p2 < NONE) nxt = row_request(site2);
+                }
+                nxt_pos = p2 < NONE ? p2 : -1;
                 E += dE;
                 ++nacc;
-                apply_row(site, -2 * sc * s_old);
+                apply_row(cur, site, -2 * sc * s_old);
                 if (tid == 0) {
                     bits[site >> 5] ^= 1u << (site & 31);
                     if constexpr (!LEAN) {
@@ -255,8 +355,8 @@ __global__ void __launch_bounds__(1024) sweep_clf_kernel(const SweepArgs a) {
                     }
                 }
                 pos = p + 1;
-                __syncthreads();  // fields and spin of the new state are visible
-                if (pos >= CLF_WINDOW) break;
+                __syncthreads();  // (B) fields and spin of the new state are visible
+                if (pos >= CLF_WINDOW * W) break;
             }
         }
         // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)

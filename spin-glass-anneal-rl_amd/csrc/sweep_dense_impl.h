@@ -747,14 +747,18 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
                                    sizeof(float) * (size_t)(a.table_m + 1);
     const bool lean = sweep_args_are_lean(a);
     void (*kern)(const SweepArgs) = nullptr;
+    bool is_batch = false, is_single = false, is_lean = lean;  // what gets launched (note_sweep_kernel)
     if constexpr (has_look_ahead<JT, ACC64, CPW>()) {
         // the 256-thread builds use up to 170 VGPRs = 3 waves per SIMD: only while the launch does
         // not want more than that (n = 1024 fp32: +31 % at 1024 replicas, -5 % at 8192)
         constexpr bool fat = dense_max_threads<JT, CPW, true>() < 1024;
         if (lean && a.rule == SGA_RULE_METROPOLIS && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
-            (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024)))
+            (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024))) {
             kern = waves == 1 ? sweep_dense_kernel<JT, CPW, ACC64, true, true, true>
                               : sweep_dense_kernel<JT, CPW, ACC64, true, true>;
+            is_batch = true;
+            is_single = waves == 1;
+        }
     }
     if (!kern) {
         if constexpr (BITS) {
@@ -765,7 +769,10 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
                         : sweep_dense_kernel<JT, CPW, ACC64, false, false, false, CANON>;
             // real-valued small problems: the one-wave build of the one-update-at-a-time form
             if constexpr (CPW >= 1 && CPW <= 4) {
-                if (lean && waves == 1) kern = sweep_dense_kernel<JT, CPW, ACC64, true, false, true, CANON>;
+                if (lean && waves == 1) {
+                    kern = sweep_dense_kernel<JT, CPW, ACC64, true, false, true, CANON>;
+                    is_single = true;
+                }
             }
         }
     }
@@ -774,6 +781,9 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
+    note_sweep_kernel("sweep_dense_kernel<%s, CPW=%d, ACC64=%d, LEAN=%d, BATCH=%d, SINGLE=%d, CANON=%d> x %d wave(s)",
+                      BITS ? "Tern2" : (sizeof(JT) == 4 ? "float" : "int8_t"), CPW, (int)ACC64, (int)is_lean,
+                      (int)is_batch, (int)is_single, (int)(CANON && !is_batch), waves);
     return hipGetLastError();
     }
 }

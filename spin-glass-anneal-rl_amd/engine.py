@@ -30,8 +30,9 @@ def _producer_done(t):
         torch.cuda.current_stream(t.device).synchronize()
 
 
-def _buf(x, np_dtype, torch_dtype_name):
-    """Return (pointer, keepalive) for a numpy array / torch tensor / None."""
+def _buf(x, np_dtype, torch_dtype_name, ordered=False):
+    """Return (pointer, keepalive) for a numpy array / torch tensor / None.  ordered: the consumer runs
+    on the stream that produces the tensor (no wait for the producer)."""
     if x is None:
         return None, None
     if _is_tensor(x):
@@ -39,7 +40,8 @@ def _buf(x, np_dtype, torch_dtype_name):
         t = x.detach()
         if t.dtype != want or not t.is_contiguous():
             t = t.to(want).contiguous()
-        _producer_done(t)
+        if not ordered:
+            _producer_done(t)
         return C.c_void_p(t.data_ptr()), t
     a = np.ascontiguousarray(x, dtype=np_dtype)
     return a.ctypes.data_as(C.c_void_p), a
@@ -80,6 +82,7 @@ class AnnealEngine:
         self._lib = _SerialisedLib(N.lib())
         N.check(self._lib.sga_create(int(device), C.byref(self._h)), "sga_create")
         self.device = int(device)
+        self.stream_handle = 0
         self.n = 0
         self.R = 0
         self.R_global = 0
@@ -107,6 +110,24 @@ class AnnealEngine:
 
     def use_stream(self, stream_handle: Optional[int]):
         N.check(self._lib.sga_set_stream(self._h, C.c_void_p(stream_handle or 0)), "sga_set_stream")
+        self.stream_handle = int(stream_handle or 0)
+
+    def shares_torch_stream(self) -> bool:
+        """True when the engine launches on torch's current stream of its device: torch work (an RCCL
+        collective) and engine kernels are then ordered by the stream, no host synchronisation needed."""
+        return bool(self.stream_handle) and torch is not None and torch.cuda.is_available() and \
+            self.stream_handle == torch.cuda.current_stream(self.device).cuda_stream
+
+    def problem_checksum(self) -> int:
+        out = C.c_uint64(0)
+        N.check(self._lib.sga_problem_checksum(self._h, C.byref(out)), "sga_problem_checksum")
+        return int(out.value)
+
+    def geometry(self):
+        """(waves per replica, chunks per wave) of the dense sweep kernels."""
+        w, c = C.c_int(0), C.c_int(0)
+        N.check(self._lib.sga_get_geometry(self._h, C.byref(w), C.byref(c)), "sga_get_geometry")
+        return int(w.value), int(c.value)
 
     def set_tuning(self, waves_per_replica: int = 0, sweeps_per_launch: int = 0):
         N.check(self._lib.sga_set_tuning(self._h, int(waves_per_replica), int(sweeps_per_launch)),
@@ -329,7 +350,8 @@ class AnnealEngine:
     def exchange(self, energies_global=None, start=None, u=None, count: bool = True):
         """One exchange round.  With count=False the call only enqueues the kernel (no host
         synchronisation) and returns None -- use it inside sweep / exchange loops."""
-        ep, k1 = _buf(energies_global, np.float64, "float64")
+        ep, k1 = _buf(energies_global, np.float64, "float64",
+                      ordered=_is_tensor(energies_global) and energies_global.is_cuda and self.shares_torch_stream())
         stp, k2 = _buf(None if start is None else np.atleast_1d(start), np.int32, "int32")
         up, k3 = _buf(u, np.float64, "float64")
         if not count:
@@ -360,12 +382,17 @@ class AnnealEngine:
                 "sga_get_energies")
         return out
 
-    def energies_into(self, tensor):
-        """Copy the local energies into a float64 torch tensor (device-to-device on the GPU)."""
+    def energies_into(self, tensor, stream_ordered: bool = False):
+        """Copy the local energies into a float64 torch tensor (device-to-device on the GPU).  With
+        stream_ordered=True (device tensors only) the copy is only enqueued on the engine's stream."""
         if tensor.dtype != torch.float64 or tensor.numel() != self.R or not tensor.is_contiguous():
             raise AnnealingError("need a contiguous float64 tensor of R entries")
-        N.check(self._lib.sga_get_energies(self._h, C.c_void_p(tensor.data_ptr())),
-                "sga_get_energies")
+        if stream_ordered and tensor.is_cuda:
+            N.check(self._lib.sga_get_energies_async(self._h, C.c_void_p(tensor.data_ptr())),
+                    "sga_get_energies_async")
+        else:
+            N.check(self._lib.sga_get_energies(self._h, C.c_void_p(tensor.data_ptr())),
+                    "sga_get_energies")
         return tensor
 
     def temperatures(self) -> np.ndarray:
@@ -469,6 +496,13 @@ class AnnealEngine:
         buf = C.create_string_buffer(512)
         N.check(self._lib.sga_describe(self._h, buf, 512))
         return buf.value.decode()
+
+
+def last_kernel() -> str:
+    """The kernel instantiation this thread's last sweep launched (sga_last_kernel)."""
+    buf = C.create_string_buffer(256)
+    N.check(N.lib().sga_last_kernel(buf, 256), "sga_last_kernel")
+    return buf.value.decode()
 
 
 def op_pt_exchange(device: int, spins, energies, temps, u=None, seed: int = 0, round_: int = 0):

@@ -26,12 +26,15 @@ import torch
 
 class ShardedTempering:
     def __init__(self, engine, R_local: int, rank: int = 0, world: int = 1, seed: int = 0,
-                 slot_temps=None, n_ladders: int = 1, dist=None, device=None, s0=None):
+                 slot_temps=None, n_ladders: int = 1, dist=None, device=None, s0=None,
+                 force_dist: bool = False):
+        """force_dist keeps the collectives in the path at world == 1 (a one-rank process group): the
+        RCCL branch can then be exercised on a single GPU; results equal the dist-free run."""
         self.engine = engine
         self.R_local, self.rank, self.world = int(R_local), int(rank), int(world)
         self.R_global = self.R_local * self.world
         self.replica0 = self.rank * self.R_local
-        self.dist = dist if world > 1 else None
+        self.dist = dist if (world > 1 or force_dist) else None
         self.device = device if device is not None else torch.device("cpu")
         engine.init_replicas(self.R_local, seed=seed, s0=s0, R_global=self.R_global,
                              replica0=self.replica0)
@@ -48,33 +51,45 @@ class ShardedTempering:
     def sweep(self, n_sweeps: int = 1, **kw):
         return self.engine.sweep(n_sweeps, **kw)
 
+    def _stream_ordered(self) -> bool:
+        """RCCL on device tensors with the engine on torch's current stream: energies copy, all-gather
+        and exchange kernel are ordered by that one stream -- no host synchronisation in a round."""
+        return (self.dist is not None and self.dist.get_backend() == "nccl" and self._all_E.is_cuda and
+                getattr(self.engine, "shares_torch_stream", lambda: False)())
+
     def gather_energies(self) -> torch.Tensor:
         """All ranks' energies, indexed by global replica id."""
-        self.engine.energies_into(self._local_E)
+        ordered = self._stream_ordered()
+        if ordered:
+            self.engine.energies_into(self._local_E, stream_ordered=True)
+        else:
+            self.engine.energies_into(self._local_E)
         if self.dist is None:
             self._all_E.copy_(self._local_E)
             return self._all_E
         t0 = time.perf_counter()
-        self._all_gather()
+        self._all_gather(ordered)
         self.gather_calls += 1
         self.gather_ms += (time.perf_counter() - t0) * 1e3
         return self._all_E
 
-    def _all_gather(self):
+    def _all_gather(self, ordered: bool = False):
         if self.dist.get_backend() == "nccl":
             self.dist.all_gather_into_tensor(self._all_E, self._local_E)
-            # the engine launches on its own HIP stream: the gathered vector must be complete
-            # before sga_exchange reads it (8 KiB collective -- the wait is microseconds)
-            torch.cuda.current_stream(self._all_E.device).synchronize()
+            if not ordered:
+                # the engine launches on its own HIP stream: the gathered vector must be complete
+                # before sga_exchange reads it (8 KiB collective -- the wait is microseconds)
+                torch.cuda.current_stream(self._all_E.device).synchronize()
         else:
             parts = list(self._all_E.chunk(self.world))
             self.dist.all_gather(parts, self._local_E)
 
-    def exchange(self) -> int:
-        """One replica-exchange round over the global ladder(s); identical on every rank."""
+    def exchange(self, count: bool = True):
+        """One replica-exchange round over the global ladder(s); identical on every rank.  Returns the
+        number of accepted swaps, or None with count=False (no read-back: the round stays asynchronous)."""
         if self.dist is None:
-            return self.engine.exchange()
-        return self.engine.exchange(energies_global=self.gather_energies())
+            return self.engine.exchange(count=count)
+        return self.engine.exchange(energies_global=self.gather_energies(), count=count)
 
     # ------------------------------------------------------------------ results
     def global_best(self):

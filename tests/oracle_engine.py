@@ -58,7 +58,7 @@ class OracleEngine:
         tensor.copy_(tensor.new_tensor(self._energy))
         return tensor
 
-    def exchange(self, energies_global=None, start=None, u=None):
+    def exchange(self, energies_global=None, start=None, u=None, count=True):
         e = self._energy if energies_global is None else \
             np.asarray(energies_global.cpu() if hasattr(energies_global, "cpu") else energies_global,
                        np.float64)

@@ -55,13 +55,15 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert d["exchange"]["rounds_timed"] >= 1 and d["exchange"]["allgather_ms_per_round"] > 0
 
 
-def _rank_main(rank, world, port, backend, share, n_ladders, out_path):
+def _rank_main(rank, world, port, backend, share, n_ladders, out_path, force=False, side_stream=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     import spin_glass_anneal_rl_amd as sg
     dev_index = 0 if share else rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if side_stream:  # engine and torch on one stream: the exchange round runs without host synchronisation
+        torch.cuda.set_stream(torch.cuda.Stream(torch.device("cuda", dev_index)))
+    if world > 1 or force:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", dev_index))
@@ -73,30 +75,41 @@ def _rank_main(rank, world, port, backend, share, n_ladders, out_path):
     L = R_GLOBAL // n_ladders
     ladder = np.asarray([6.0 * (0.3 / 6.0) ** (i / (L - 1)) for i in range(L)] * n_ladders)
     eng = sg.AnnealEngine(dev_index)
+    if side_stream:
+        eng.use_stream(torch.cuda.current_stream().cuda_stream)
+        assert eng.shares_torch_stream()
     eng.set_dense(J, h)
     comm = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
     pt = sg.ShardedTempering(eng, R_GLOBAL // world, rank, world, SEED, ladder, n_ladders,
-                             dist if world > 1 else None, comm)
+                             dist if (world > 1 or force) else None, comm, force_dist=force)
+    assert (pt.dist is not None) == (world > 1 or force)
     swaps = []
-    for _ in range(ROUNDS):
+    for k in range(ROUNDS):
         pt.sweep(2)
-        swaps.append(pt.exchange())
+        if side_stream and k % 2 == 1:  # the asynchronous form: no read-back; the count comes from the statistics
+            before = int(eng.exchange_stats()[1].sum())
+            assert pt.exchange(count=False) is None
+            swaps.append(int(eng.exchange_stats()[1].sum()) - before)
+        else:
+            swaps.append(pt.exchange())
     e, s, idx = pt.global_best()
     np.savez(out_path, swaps=np.asarray(swaps), energies=pt.gather_energies().cpu().numpy(),
              best_e=e, best_s=s, best_idx=idx, spins=eng.spins(), temps=eng.temperatures(),
              slot_map=eng.slot_map())
     eng.close()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _run_ranks(world, backend, share, n_ladders, tmp_path):
+def _run_ranks(world, backend, share, n_ladders, tmp_path, force=False, side_stream=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     port = _free_port()
-    paths = [str(tmp_path / f"w{world}_r{r}.npz") for r in range(world)]
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, backend, share, n_ladders, paths[r]))
+    tag = f"w{world}_{backend}_{int(force)}{int(side_stream)}"
+    paths = [str(tmp_path / f"{tag}_r{r}.npz") for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, backend, share, n_ladders, paths[r], force,
+                                                  side_stream))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -126,3 +139,42 @@ def test_two_ranks_on_real_engines_equal_one_rank(backend, n_ladders, tmp_path):
         assert np.array_equal(o["temps"], single["temps"][sl])
         assert o["best_e"] == single["best_e"] and o["best_idx"] == single["best_idx"]
         assert np.array_equal(o["best_s"], single["best_s"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side_stream", [False, True])
+@pytest.mark.parametrize("n_ladders", [1, 3])
+def test_one_rank_process_group_over_rccl_equals_the_plain_run(n_ladders, side_stream, tmp_path):
+    """The RCCL branch of ShardedTempering on ONE GPU: a one-rank process group (backend "nccl"), started
+    in a fresh child process, with the collectives forced into the path -- sweeps, exchange rounds through
+    all_gather_into_tensor on device tensors, global_best through all_gather + broadcast -- equals the
+    dist-free run bit for bit; with the engine on torch's stream the round needs no host synchronisation."""
+    plain = _run_ranks(1, "gloo", True, n_ladders, tmp_path)[0]
+    assert plain["swaps"].sum() > 0
+    got = _run_ranks(1, "nccl", True, n_ladders, tmp_path, force=True, side_stream=side_stream)[0]
+    for key in ("swaps", "energies", "slot_map", "spins", "temps", "best_s"):
+        assert np.array_equal(got[key], plain[key]), key
+    assert got["best_e"] == plain["best_e"] and got["best_idx"] == plain["best_idx"]
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
+    """`python bench.py --gpus 1 --force-dist`: a one-rank RCCL group in a child process; the line says so
+    and reports that the ranks' couplings agree."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "12",
+           "--warmup", "2", "--spins", "2000", "--replicas", "64", "--no-variants", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["backend"] == "nccl"
+    assert d["couplings_checksum_agree"] is True and len(d["couplings_checksum"]) == 16
+    assert d["exchange"]["rounds_timed"] >= 1 and d["config"]["geometry_autotuned"] is True
+    plain = subprocess.run([c for c in cmd if c != "--force-dist"], capture_output=True, text=True, timeout=900,
+                           env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    q = json.loads(plain.stdout.splitlines()[0])
+    assert q["backend"] is None and q["couplings_checksum"] == d["couplings_checksum"]
+    assert q["config"]["best_energy_rank0"] == d["config"]["best_energy_rank0"]
