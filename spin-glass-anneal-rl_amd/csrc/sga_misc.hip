@@ -150,24 +150,36 @@ hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned in
     return hipGetLastError();
 }
 
-__global__ void check_symmetric_kernel(const float *__restrict__ J, long long ldJ, long long rows,
-                                       int n, int *out) {
-    const long long total = rows * n;
+// J[i][j] == J[j][i] and J[i][i] == 0, per model block of n rows: 64 x 64 tiles, the tile (bi, bj) through
+// LDS against the coalesced rows of tile (bj, bi) -- the matrix is read once (the element-wise form read
+// the transposed operand one cache line per element: 12.6 GB for the 400 MB matrix of n = 10^4, 118 GB and
+// 16 ms at n = 32 768, profiles/r03_experiments.md).
+__global__ void __launch_bounds__(256) check_symmetric_kernel(const float *__restrict__ J, long long ldJ, long long rows,
+                                                              int n, int *out) {
+    __shared__ float tile[64][65];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bi > bj) return;  // the pair (bi, bj) covers both triangles
+    const float *M = J + (long long)blockIdx.z * n * ldJ;  // this model's block
+    const int r0 = bi * 64, c0 = bj * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        tile[i][tx] = (r0 + i < n && c0 + tx < n) ? M[(long long)(r0 + i) * ldJ + c0 + tx] : 0.0f;
+    __syncthreads();
     int bad = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / n, col = i - row * n;
-        const long long base = (row / n) * n;  // first row of this model's block
-        const long long r = row - base;
-        const float a = J[row * ldJ + col], b = J[(base + col) * ldJ + r];
-        if (a != b || (r == col && a != 0.0f)) bad = 1;
+    for (int j = ty; j < 64; j += 4) {  // row c0 + j of the mirrored tile, columns r0 + tx
+        if (c0 + j < n && r0 + tx < n) {
+            const float b = M[(long long)(c0 + j) * ldJ + r0 + tx], a = tile[tx][j];
+            if (a != b || (r0 + tx == c0 + j && b != 0.0f)) bad = 1;
+        }
     }
-    if (bad) atomicOr(out, 1);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(out, 1);
+    (void)rows;
 }
 hipError_t launch_check_symmetric(const float *J, long long ldJ, long long rows, int n, int *out,
                                   hipStream_t st) {
-    hipLaunchKernelGGL(check_symmetric_kernel, dim3(grid_for(rows * n)), dim3(256), 0, st, J, ldJ,
-                       rows, n, out);
+    const int nt = (n + 63) / 64;
+    hipLaunchKernelGGL(check_symmetric_kernel, dim3(nt, nt, (unsigned)(rows / n)), dim3(256), 0, st, J, ldJ, rows, n,
+                       out);
     return hipGetLastError();
 }
 
