@@ -175,7 +175,9 @@ int sga_set_update_rule(sga_engine *e, int rule);
  * always accepted, n_accepted grows by the cluster sizes, the per-update dE record is
  * compute_energy() after minus before, and energies are evaluated from scratch after every sweep
  * (spin_dynamics.py:87).  Needs SGA_ARITH_F64 and n <= ~31 000 (spins, cluster bitmap and queue in
- * LDS); not available for sga_update or sga_set_tsp problems.  One uniform per candidate bond:
+ * LDS), and CSR rows strictly sorted by column (every stored entry is one bond: duplicates, which the
+ * single-site rules add up, are refused with SGA_ERR_UNSUPPORTED); not available for sga_update or
+ * sga_set_tsp problems.  One uniform per candidate bond:
  * Philox (domain 3) or, for the parity tests, the recorded stream given here -- u [R_local][capacity]
  * fp32, consumed in draw order by the following Wolff sweeps (NULL: back to Philox). */
 int sga_set_wolff_replay(sga_engine *e, const float *u, int64_t capacity);

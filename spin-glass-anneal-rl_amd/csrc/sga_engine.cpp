@@ -140,6 +140,7 @@ struct sga_engine {
     long long *rowptr64 = nullptr;                  // always (energy / single-site kernels)
     int4 *rowinfo = nullptr;     // slotted layout, per row: first slot, slots, offset of a zero slot, h (wide sweep forms)
     bool slotted = false;        // rows padded to whole 64-entry slots (value-0 entries behind each row)
+    bool csr_sorted = false;     // rows strictly sorted by column: no duplicate entries
     uint32_t *cvp = nullptr;     // slotted layout with packed entries (24-bit column | int8 value << 24), on demand
     bool cvp_tried = false;      // packing was attempted for this problem (values may not fit)
     int csr_storage = SGA_CSR_STORAGE_AUTO;         // what the caller asked for ...
@@ -1026,6 +1027,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     // compared by linear scans while that stays cheap, else treated as asymmetric (exact-energy
     // mode: slower, never wrong)
     const bool sorted = !flags[sga::CSR_UNSORTED];
+    e->csr_sorted = sorted;
     const double avg_deg = (double)nnz / n;
     if (sorted || (double)nnz * avg_deg <= 4.0e10) {
         he = sga::launch_csr_symmetry(e->rowptr64, ci, vv, n, sorted, d_flags, e->stream);
@@ -1491,6 +1493,11 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             return fail(SGA_ERR_UNSUPPORTED, "the Wolff rule keeps spins, cluster and queue in LDS: n <= ~31 000");
         if (site_mode == SGA_SITE_SEQUENTIAL && !replay_u)
             return fail(SGA_ERR_INVALID, "sequential Wolff sweeps need replay_u (unused values are fine)");
+        // the cluster growth treats every stored entry as one bond: duplicate columns of a row (which the
+        // other rules add up) would be drawn twice and could overrun the cluster queue
+        if (e->csr && !e->csr_sorted)
+            return fail(SGA_ERR_UNSUPPORTED, "the Wolff rule over CSR couplings needs rows strictly sorted by "
+                                             "column (no duplicate entries)");
     }
     const bool exact_mode = !e->consistent_dE || wolff;
     if (exact_mode) spl = 1;

@@ -6,6 +6,15 @@ step, nearest-neighbour exchanges every `exchange_interval` sweeps (skipping swe
 random even/odd start, statistics and best-over-replicas on record sweeps only.  All replicas
 advance in one kernel call between two events; an exchange swaps temperature labels on the
 device instead of moving spin tensors (same Markov chain, no copies).
+
+`exchange_method="all_pairs"` follows the reference's CPU branch (:222-232: every pair i < j behind the
+gate `np.random.rand() < 0.1`, the criterion of `_attempt_single_exchange`, :234-258; pinned to the
+fixture pt_allpairs_n16_r5).  On a CUDA device the reference routes the same setting through
+`_cuda_optimized_exchange` instead (:222-226 -> :260-293: sequential ADJACENT pairs, fp32 probability with
+the inverted sign, spin rows and energies swapped) -- a different exchange rule under the same name.  That
+rule is available here as the stateless operator `CUDAKernelManager.parallel_tempering_exchange_optimized`
+/ `sga_op_pt_exchange` (pinned to operator_n48), not through this class: `ParallelTempering` means the
+CPU branch on every device.
 """
 import time
 from dataclasses import dataclass

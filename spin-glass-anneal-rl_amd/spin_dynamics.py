@@ -135,6 +135,41 @@ class SpinDynamics:
         self.n_rejected = 0
         self.energy_history = []
 
+    # ------------------------------------------------------------------ diagnostics (host side)
+    def get_autocorrelation_time(self, observable: str = "energy") -> float:
+        """Sweeps until the normalised autocorrelation of the recorded history first falls below 1/e
+        (reference core/spin_dynamics.py:361-391): inf with fewer than 10 records, the history's length
+        when it never does (a constant history included)."""
+        histories = {"energy": self.energy_history, "magnetization": self.magnetization_history}
+        if observable not in histories:
+            raise ValueError(f"Unknown observable: {observable}")
+        x = np.asarray(histories[observable], np.float64)
+        if x.size < 10:
+            return float("inf")
+        d = x - x.mean()
+        c = np.correlate(d, d, mode="full")[x.size - 1:]  # lags 0 .. len - 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = c / c[0]
+        below = np.flatnonzero(c < 1.0 / np.e)  # (NaN for a constant history: never below)
+        return float(below[0]) if below.size else float(c.size)
+
+    def thermal_equilibrium_check(self, window_size: int = 100) -> bool:
+        """Are the means of the last two windows of the energy history indistinguishable (two-sample t
+        test, p > 0.05; reference core/spin_dynamics.py:393-421)?  False until 2 windows are recorded."""
+        if len(self.energy_history) < 2 * window_size:
+            return False
+        recent = np.asarray(self.energy_history[-window_size:], np.float64)
+        older = np.asarray(self.energy_history[-2 * window_size:-window_size], np.float64)
+        try:
+            from scipy import stats
+        except ImportError:  # the reference's fallback when scipy is missing
+            return abs(float(np.var(recent)) - float(np.var(older))) < 0.1
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (identical windows: the statistic is 0 / 0)
+            p_value = stats.ttest_ind(recent, older).pvalue
+        return bool(p_value > 0.05)
+
     def __repr__(self) -> str:
         return (f"SpinDynamics(temperature={self.temperature:.4f}, "
                 f"update_rule={self.update_rule.value}, "

@@ -466,6 +466,47 @@ def case_schedules(out):
     print("schedules: ok")
 
 
+def case_diagnostics(out):
+    """SpinDynamics.get_autocorrelation_time / thermal_equilibrium_check (core/spin_dynamics.py:361-421)
+    on recorded histories: a real run's energy / magnetisation series and synthetic ones (AR(1) series of
+    several correlation lengths, a drifting series, short and constant ones)."""
+    model = dense_model(pm1_couplings(48, 12))
+    torch.manual_seed(5)
+    dyn = SpinDynamics(model, temperature=2.5)
+    for _ in range(260):
+        dyn.sweep()
+    series = {"run_energy": np.asarray(dyn.energy_history, np.float64),
+              "run_magnetization": np.asarray(dyn.magnetization_history, np.float64)}
+    rng = np.random.RandomState(17)
+    for name, phi in (("ar_02", 0.2), ("ar_08", 0.8), ("ar_097", 0.97)):
+        x = np.zeros(400)
+        for i in range(1, 400):
+            x[i] = phi * x[i - 1] + rng.randn()
+        series[name] = x
+    series["drift"] = np.linspace(-50.0, -250.0, 300) + rng.randn(300)
+    series["short"] = rng.randn(9)
+    series["ten"] = rng.randn(10)
+    series["constant"] = np.full(250, -17.0)
+    d = {}
+    for name, x in series.items():
+        d[f"{name}__data"] = x
+        for obs in ("energy", "magnetization"):
+            dyn.energy_history = list(x) if obs == "energy" else []
+            dyn.magnetization_history = list(x) if obs == "magnetization" else []
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                d[f"{name}__tau_{obs}"] = np.float64(dyn.get_autocorrelation_time(obs))
+        dyn.energy_history = list(x)
+        for win in (100, 50, 5):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                d[f"{name}__equilibrium_w{win}"] = np.bool_(dyn.thermal_equilibrium_check(win))
+    np.savez_compressed(os.path.join(out, "diagnostics.npz"), kind="diagnostics", **d)
+    print("diagnostics: ok", {k: v for k, v in d.items() if "__data" not in k and "run_" in k})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
@@ -545,6 +586,8 @@ def main():
         case_schedules(a.out)
     if want("encoders"):
         case_encoders(a.out)
+    if want("diagnostics"):
+        case_diagnostics(a.out)
 
 
 if __name__ == "__main__":
