@@ -152,4 +152,28 @@ __device__ __forceinline__ T wave_sum(T v) {
     return read_lane(v, 63);
 }
 
+// Two wave sums with their steps interleaved: a DPP step needs wait states after the instruction that
+// wrote its source, which the other chain's step fills (the compiler schedules two wave_sum calls one
+// after the other, s_nop and all).  Same association order as wave_sum.
+template <typename T>
+__device__ __forceinline__ void wave_sum2(T &a, T &b) {
+#define SGA_STEP2(CTRL, ROWS)                      \
+    {                                              \
+        const T ta = dpp_move<CTRL, ROWS>(a);      \
+        const T tb = dpp_move<CTRL, ROWS>(b);      \
+        asm volatile("" : "+v"(a), "+v"(b));       \
+        a += ta;                                   \
+        b += tb;                                   \
+    }
+    SGA_STEP2(DPP_QUAD_XOR1, 0xf)
+    SGA_STEP2(DPP_QUAD_XOR2, 0xf)
+    SGA_STEP2(DPP_ROW_HALF_MIRROR, 0xf)
+    SGA_STEP2(DPP_ROW_MIRROR, 0xf)
+    SGA_STEP2(DPP_ROW_BCAST15, 0xa)
+    SGA_STEP2(DPP_ROW_BCAST31, 0xc)
+#undef SGA_STEP2
+    a = read_lane(a, 63);
+    b = read_lane(b, 63);
+}
+
 }  // namespace sga

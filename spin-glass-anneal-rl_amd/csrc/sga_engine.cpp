@@ -1531,6 +1531,12 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 10);
         }
         a.big = e->big_form;
+        // Pair look-ahead of the narrow table form: built and verified in round 3, measured -1 ... +3 % on
+        // BASELINE configs[2] (same-box A/B, profiles/r03_experiments.md) -- not the default; kept behind
+        // SGA_CSR_PAIR_AHEAD=1 (2: with the two wave sums interleaved) for the parity test and further A/Bs.
+        a.csr_pair_ahead = 0;
+        if (e->csr && e->max_row_len <= 64 && std::getenv("SGA_CSR_PAIR_AHEAD"))
+            a.csr_pair_ahead = std::max(0, std::min(2, std::atoi(std::getenv("SGA_CSR_PAIR_AHEAD"))));
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
         a.cv = e->cv;

@@ -69,6 +69,7 @@ struct SweepArgs {
                   // workgroup (short rows)
     int csr_acc;         // CSR: one of CSR_ACC_* (how a row sum is formed)
     int csr_head;        // CSR wide bit forms: head slots per wave the longest row needs (0: eight)
+    int csr_pair_ahead;  // CSR narrow table form: every row has <= 64 entries -> the two updates of a pair are reduced together
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     // cached-local-field sweep (sweep_clf_impl.h): resident fields F = field_scale * (J s + h)

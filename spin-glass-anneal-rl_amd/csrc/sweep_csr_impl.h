@@ -551,6 +551,129 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             }
             sweep_end(k);
         }
+    } else if (!WIDE && LEAN && TABLE && a.csr_pair_ahead) {
+        // PAIR LOOK-AHEAD (narrow production form, integer problems, rows of <= 64 entries): the two
+        // updates of a Philox pair are reduced TOGETHER against the spins as they stand before the first
+        // -- two independent gathers, two interleaved wave sums -- and the chain is replayed on scalars:
+        // if A flips, B's row sum is corrected by -2 J[B][A] s_A (the entries of row B at column sA, found
+        // by a ballot over the lanes that hold them) and B's own spin is negated when both sit on one
+        // site.  Every quantity is an integer below 2^24, so decisions, energies and spins equal the
+        // one-at-a-time chain's.  A wave issues dependent instructions several cycles apart and the
+        // degree-32 form is bound by exactly that chain: two chains interleaved fill the
+        // gaps.  Pipeline: row extents two pairs ahead (scalar loads), row entries one pair ahead.
+        struct Stage {
+            UpdatePair p;
+            Extent xA, xB;
+            Head hA, hB;
+        };
+        const int nb = (n + 1) >> 1;
+        auto table_rule = [&](float fk, uint32_t ru, double &dE) -> bool {
+            dE = (double)(2.0f * fk);
+            const float fq = fk * (float)a.table_scale;
+            if (fk <= 0.0f) return true;
+            if (fq <= (float)a.table_m) return ru < itab[(int)fq];
+            return (dE > T * 104.0) ? false : ((float)ru * 0x1.0p-24f < expf_det((float)(-dE / T)));
+        };
+        auto stage_extents = [&](Stage &st, int k, int b) {
+            st.p = rng.get(a, r, k, b, k < a.n_sweeps, lane);  // past the end: site 0
+            st.xA = load_extent(st.p.sA);
+            st.xB = load_extent(st.p.sB);
+        };
+        auto stage_heads = [&](Stage &st) {
+            st.hA = load_head(st.xA);
+            st.hB = load_head(st.xB);
+        };
+        auto reduce_pair = [&](const Stage &c, bool hasB) {
+            const int sA = c.p.sA, sB = c.p.sB;
+            const int siA = spin_i(sA);
+            int siB = spin_i(sB);
+            const float tA = term(lane < c.hA.len ? c.hA.val[0] : 0.0f, c.hA.col[0]);
+            const bool inB = hasB && lane < c.hB.len;
+            const float tB = term(inB ? c.hB.val[0] : 0.0f, c.hB.col[0]);
+            float dotA = tA, dotB = tB;
+            if (a.csr_pair_ahead == 2) {
+                wave_sum2(dotA, dotB);  // the two trees step by step in turn (A/B: SGA_CSR_PAIR_AHEAD=2)
+            } else {
+                dotA = wave_sum(tA);
+                dotB = wave_sum(tB);
+            }
+            double dEA, dEB = 0.0;
+            const bool flipA = table_rule((float)siA * (dotA + c.xA.h), c.p.rA, dEA);
+            if (flipA) {
+                E += dEA;
+                ++nacc;
+                unsigned long long mm = __ballot(inB && c.hB.col[0] == sA);
+                while (mm) {  // (duplicate entries add up; usually no entry at all)
+                    dotB -= 2.0f * read_lane(c.hB.val[0], (int)__builtin_ctzll(mm)) * (float)siA;
+                    mm &= mm - 1;
+                }
+                if (sB == sA) siB = -siB;
+            }
+            bool flipB = false;
+            if (hasB) {
+                flipB = table_rule((float)siB * (dotB + c.xB.h), c.p.rB, dEB);
+                if (flipB) {
+                    E += dEB;
+                    ++nacc;
+                }
+            }
+            if (lane == 0) {  // in chain order
+                if constexpr (BIG) {
+                    if (flipA) {
+                        if (siA > 0) atomicOr(&sbits[sA >> 5], 1u << (sA & 31));
+                        else atomicAnd(&sbits[sA >> 5], ~(1u << (sA & 31)));
+                    }
+                    if (flipB) {
+                        if (siB > 0) atomicOr(&sbits[sB >> 5], 1u << (sB & 31));
+                        else atomicAnd(&sbits[sB >> 5], ~(1u << (sB & 31)));
+                    }
+                } else {
+                    if (flipA) s[sA] = (int8_t)(-siA);
+                    if (flipB) s[sB] = (int8_t)(-siB);
+                }
+            }
+        };
+        // position of the pair `ahead` pairs after (k, b)
+        auto later = [&](int k, int b, int ahead, int &ko, int &bo) {
+            bo = b + ahead;
+            ko = k;
+            while (bo >= nb) {
+                bo -= nb;
+                ++ko;
+            }
+        };
+        Stage S0, S1, S2;
+        stage_extents(S0, 0, 0);
+        {
+            int k1, b1;
+            later(0, 0, 1, k1, b1);
+            stage_extents(S1, k1, b1);
+        }
+        stage_heads(S0);
+        auto pair3 = [&](Stage &c, Stage &n1, Stage &n2, int k, int b) {
+            int k2, b2;
+            later(k, b, 2, k2, b2);
+            stage_extents(n2, k2, b2);  // two pairs ahead
+            stage_heads(n1);            // one pair ahead: its extents were requested a pair ago
+            reduce_pair(c, (2 * b + 1) < n);
+        };
+        for (int k = 0; k < a.n_sweeps; ++k) {
+            sweep_start(k);
+            int b = 0;
+            for (; b + 3 <= nb; b += 3) {
+                pair3(S0, S1, S2, k, b);
+                pair3(S1, S2, S0, k, b + 1);
+                pair3(S2, S0, S1, k, b + 2);
+            }
+            for (; b < nb; ++b) {  // up to two pairs left: one at a time, the stages rotated back into phase
+                pair3(S0, S1, S2, k, b);
+                const Stage t = S0;
+                S0 = S1;
+                S1 = S2;
+                S2 = t;
+            }
+            sweep_end(k);
+        }
     } else {
         // Pairs of updates (one Philox block each); the extents of the next pair and the head of its
         // first row are requested while this pair is reduced.  The loop is unrolled over TWO pairs

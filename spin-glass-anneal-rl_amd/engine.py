@@ -160,6 +160,8 @@ class AnnealEngine:
             return False
         if setting is None and float(self.n) ** 2 * self.R * n_sweeps < 2e13:
             return False
+        if setting is None and "sweep=cached-local-fields" in self.describe():
+            return False  # the measured geometry belongs to the row-per-proposal kernels
         self.autotune()
         return True
 

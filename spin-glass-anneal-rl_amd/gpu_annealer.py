@@ -44,6 +44,9 @@ class GPUAnnealerConfig:
     # build-specific
     site_order: str = "random"            # "random" | "sequential"
     coupling_storage: str = "auto"        # "auto" | "f32" | "i8"
+    field_cache: str = "auto"             # "auto" | "on" | "off": resident local fields, a coupling row read
+    #                                       only on accept where the problem allows (sga_set_field_cache) --
+    #                                       the same chain bit for bit as "off" (one row read per proposal)
     device_index: Optional[int] = None
 
     def __post_init__(self):
@@ -99,6 +102,7 @@ class GPUAnnealer:
         n = model.n_spins
         with AnnealEngine(dev_idx) as eng:
             model.load_into(eng, storage=cfg.coupling_storage)
+            eng.set_field_cache(cfg.field_cache)
             eng.set_update_rule(rule)
             eng.init_replicas(1, seed=fresh_seed(cfg.random_seed), s0=model.spins_int8()[None, :])
             energy_history = [float(eng.energies()[0])]

@@ -47,6 +47,7 @@ class ParallelTemperingConfig:
     random_seed: Optional[int] = None
     # build-specific
     coupling_storage: str = "auto"
+    field_cache: str = "auto"             # resident local fields where the problem allows (identical chain)
     device_index: Optional[int] = None
     autotune: Optional[bool] = None       # measured launch geometry (None: for long runs only)
 
@@ -90,6 +91,7 @@ class ParallelTempering:
         acc_slot, att_slot = np.zeros(R, np.int64), np.zeros(R, np.int64)
         with AnnealEngine(dev_idx) as eng:
             model.load_into(eng, storage=cfg.coupling_storage)
+            eng.set_field_cache(cfg.field_cache)
             eng.set_update_rule(rule)
             eng.init_replicas(R, seed=fresh_seed(cfg.random_seed),
                               s0=None if _replay is None else _replay["s0"])

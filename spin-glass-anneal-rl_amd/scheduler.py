@@ -50,7 +50,10 @@ class SpinGlassScheduler:
                beta_schedule: Union[str, Sequence[float]] = "geometric", beta_min: float = 0.1,
                beta_max: float = 10.0, exchange_interval: int = 10, n_ladders: int = 1,
                coupling_storage: str = "auto", record_interval: int = 10,
-               autotune: Optional[bool] = None) -> AnnealingResult:
+               autotune: Optional[bool] = None, field_cache: str = "auto") -> AnnealingResult:
+        """field_cache: "auto" keeps every replica's local fields resident where the problem allows it
+        (dense integer-valued symmetric couplings) so that a coupling row is read only when a proposal is
+        accepted -- the chain, and with it the result, is the one "off" (a row per proposal) gives."""
         if n_replicas < 1 or n_sweeps < 1 or n_replicas % n_ladders:
             raise ConfigurationError("bad replica / sweep / ladder counts")
         t0 = time.time()
@@ -66,6 +69,7 @@ class SpinGlassScheduler:
         e_hist, t_hist = [], []
         with AnnealEngine(dev) as eng:
             ising_model.load_into(eng, storage=coupling_storage)
+            eng.set_field_cache(field_cache)
             eng.init_replicas(n_replicas, seed=fresh_seed(self.random_seed))
             eng.set_ladder(temps, n_ladders)
             eng.maybe_autotune(n_sweeps, autotune)  # measured launch geometry for long runs

@@ -466,6 +466,69 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
         assert np.array_equal(out2["energy_trace"], ref2["energy_trace"])
 
 
+@pytest.mark.parametrize("bits", [False, True])
+@pytest.mark.parametrize("n,deg,amp,half_h,dups", [
+    (5, 4, 1, False, False),      # tiny: both updates of a pair hit the same site / neighbours all the time
+    (17, 16, 3, False, True),     # every row nearly full, duplicate entries that add up, odd n (last pair has no B)
+    (64, 63, 2, True, False),     # complete graph, rows of 63 entries, half-integer fields
+    (65, 64, 1, False, False),    # rows of exactly 64 entries
+    (1000, 32, 1, False, False),  # the C3 shape
+    (301, 9, 5, True, True),
+])
+def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h, dups, bits, monkeypatch):
+    """Narrow table form (integer problems, rows of <= 64 entries): the two updates of a Philox pair are
+    reduced together and the chain replayed on scalars (fix-up by the entries of row B at site A).  Against
+    the oracle and against the one-update-at-a-time form of the same kernel.  (Opt-in, SGA_CSR_PAIR_AHEAD:
+    measured -1 ... +3 % on BASELINE configs[2], so the default stays one update at a time.)"""
+    if bits:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    rng = np.random.RandomState(7 * n + deg)
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rng.choice(n, min(deg // 2 + 1, n), replace=False):
+            if i != j:
+                J[i, j] = J[j, i] = float(rng.choice([v for v in range(-amp, amp + 1) if v != 0]))
+    J[np.abs(J).sum(1) == 0, :] = 0
+    h = rng.randint(-2, 3, n).astype(np.float32) + (0.5 if half_h else 0.0)
+    rowptr, col, val = csr_of(J)
+    if dups:  # split some entries into two that add up (unsorted rows, duplicate columns)
+        rp, ci, vv = [0], [], []
+        for i in range(n):
+            for e_ in range(rowptr[i], rowptr[i + 1]):
+                if (e_ % 3 == 0) and (rowptr[i + 1] - rowptr[i]) < 40:
+                    ci += [col[e_], col[e_]]
+                    vv += [val[e_] + 2.0, -2.0]
+                else:
+                    ci.append(col[e_])
+                    vv.append(val[e_])
+            rp.append(len(ci))
+        rowptr, col, val = np.asarray(rp, np.int32), np.asarray(ci, np.int32), np.asarray(vv, np.float32)
+    assert np.diff(rowptr).max() <= 64
+    csr = (rowptr, col, val)
+    prob = oracle.Problem(csr=csr, h=h)
+    R, ns, seed = 7, 10, 1717 + n
+    temps = ladder(R, 6.0 * amp, 0.3 * amp)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=7)
+    got = {}
+    for ahead in (1, 2, 0):
+        if ahead:
+            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", str(ahead))
+        else:
+            monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
+        with sg.AnnealEngine(0) as e:
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed)
+            assert "fast" in e.describe(), e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (ahead, e.describe())
+            assert np.array_equal(e.spins(), s)
+            assert np.array_equal(e.stats()[0], ref["n_accepted"])
+            got[ahead] = (out["energy_trace"], e.best()[0])
+    assert np.array_equal(got[1][0], got[0][0]) and got[1][1] == got[0][1] and got[2][1] == got[0][1]
+
+
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("integer", [True, False])
 @pytest.mark.parametrize("big", [False, True])
