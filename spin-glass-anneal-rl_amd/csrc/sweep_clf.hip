@@ -20,9 +20,16 @@ int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus) {
     // about three chunks per wave, from {1, 2, 3, 4, 8} (measured at 10 chunks, 1024 replicas: 1 / 2 / 3 / 4 /
     // 6 / 8 waves -> 0.28 / 0.19 / 0.175 / 0.167 / 0.173 / 0.165 ms per cold sweep, 9.3 / 6.6 / 7.2 / 7.1 /
     // 15.0 / 11.4 ms for the first, hot one: profiles/r03_experiments.md)
-    const int want = (chunks + 2) / 3;
+    const int want = (chunks + 2) / 3;  // (CLF_BATCH_MAX chunks per wave when the cap binds)
     const int pick = want <= 4 ? std::max(want, 1) : 8;
     return std::max(1, std::min(cap, pick));
+}
+
+// chunks a wave requests per row in one batch (the kernel is built for 3 and for 5)
+int sweep_clf_batch(long long ldj, bool j_is_i8, int waves) {
+    const int epc = j_is_i8 ? 1024 : 256;
+    const int chunks = (int)((ldj + epc - 1) / epc);
+    return (chunks + waves - 1) / waves <= 3 ? 3 : CLF_BATCH_MAX;
 }
 
 template <typename JT, typename FT>
@@ -30,12 +37,15 @@ static hipError_t launch_clf(const SweepArgs &a, int waves, hipStream_t st) {
     const size_t lds = clf_lds_bytes(a.ldf, (int)sizeof(FT), a.sstride, a.table_m);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
-    void (*kern)(const SweepArgs) = lean ? sweep_clf_kernel<JT, FT, true> : sweep_clf_kernel<JT, FT, false>;
+    const int batch = sweep_clf_batch(a.ldj, sizeof(JT) == 1, waves);
+    void (*kern)(const SweepArgs) =
+        batch == 3 ? (lean ? sweep_clf_kernel<JT, FT, true, 3> : sweep_clf_kernel<JT, FT, false, 3>)
+                   : (lean ? sweep_clf_kernel<JT, FT, true, CLF_BATCH_MAX> : sweep_clf_kernel<JT, FT, false, CLF_BATCH_MAX>);
     hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
-    note_sweep_kernel("sweep_clf_kernel<%s, %s, %s> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
-                      sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", waves);
+    note_sweep_kernel("sweep_clf_kernel<%s, %s, %s, BATCH=%d> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
+                      sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", batch, waves);
     return hipGetLastError();
 }
 

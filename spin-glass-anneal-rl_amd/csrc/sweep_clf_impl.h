@@ -34,7 +34,8 @@
 namespace sga {
 
 constexpr int CLF_WINDOW = 128;  // updates evaluated together: two per lane
-constexpr int CLF_BATCH = 5;     // row chunks a wave requests together
+constexpr int CLF_BATCH_MAX = 5; // row chunks a wave requests together (kernel builds for 3 and 5)
+constexpr int CLF_SLOT_INTS = 8;  // what a wave publishes per round: 2 positions, 2 sites, dE, the spin at the first site
 constexpr int CLF_MAX_WAVES = 8; // waves per replica (512 threads: up to 256 VGPRs for the two row buffers)
 
 // The accept rule as a function of the exact local field (sum + h): what metropolis_accept
@@ -77,11 +78,11 @@ __host__ __device__ constexpr long long clf_bits_offset(long long ldf, int fbyte
 __host__ __device__ constexpr long long clf_table_offset(long long ldf, int fbytes, int sstride) {
     return clf_bits_offset(ldf, fbytes) + ((sstride / 8 + 15) & ~15);
 }
-inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {  // + [2][CLF_MAX_WAVES][8] decision slots
-    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 2) + 2 * 32 * CLF_MAX_WAVES + 16;
+inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {  // + [2][CLF_MAX_WAVES][CLF_SLOT_INTS] decision slots
+    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 2) + 2 * 4 * CLF_SLOT_INTS * CLF_MAX_WAVES + 16;
 }
 
-template <typename JT, typename FT, bool LEAN>
+template <typename JT, typename FT, bool LEAN, int CLF_BATCH = CLF_BATCH_MAX>
 __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const SweepArgs a) {
     constexpr int EPL = 16 / (int)sizeof(JT), EPC = 64 * EPL;  // elements per lane / per 1-KiB chunk
     constexpr int FB = (int)sizeof(FT);
@@ -133,8 +134,11 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
         }
         return o;
     };
-    // F_j -= 2 scale J_ij s_i for the EPL couplings x = J[i][j0 .. j0 + EPL)
-    auto apply_chunk = [&](const vec_t &x, long long j0, int mult /* -2 scale s_i(old) */) {
+    // F_j -= 2 scale J_ij s_i for the EPL couplings x = J[i][j0 .. j0 + EPL).  NEG = the amount is
+    // subtracted (mult < 0): a compile-time constant here, the caller branches once per accept on the
+    // wave-uniform sign (left to the compiler the select costs two more VALU per int16 pair).
+    auto apply_chunk = [&](const vec_t &x, long long j0, int mult /* -2 scale s_i(old) */, auto neg) {
+        constexpr bool NEG = decltype(neg)::value;
         if constexpr (sizeof(JT) == 4) {
             const int d0 = mult * (int)x.x, d1 = mult * (int)x.y, d2 = mult * (int)x.z, d3 = mult * (int)x.w;
             if constexpr (FB == 2) {
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                     const short2v v01 = __builtin_bit_cast(short2v, t01) >> shv;
                     const short2v v23 = __builtin_bit_cast(short2v, t23) >> shv;
                     short2v lo = __builtin_bit_cast(short2v, *fp[2 * d]), hi = __builtin_bit_cast(short2v, *fp[2 * d + 1]);
-                    if (mult < 0) lo -= v01, hi -= v23;  // wave-uniform
+                    if constexpr (NEG) lo -= v01, hi -= v23;
                     else lo += v01, hi += v23;
                     *fp[2 * d] = __builtin_bit_cast(int, lo);
                     *fp[2 * d + 1] = __builtin_bit_cast(int, hi);
@@ -186,11 +190,11 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             }
         }
     };
-    auto apply_row = [&](const RowRegs &rr, int site, int mult) {
+    auto apply_row_signed = [&](const RowRegs &rr, int site, int mult, auto neg) {
 #pragma unroll
         for (int q = 0; q < CLF_BATCH; ++q) {
             const long long j0 = elem0(w + q * W);
-            if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult);
+            if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult, neg);
         }
         const JT *row = Jbase + (long long)site * a.ldj;
         for (int c0 = w + CLF_BATCH * W; c0 < n_chunks; c0 += CLF_BATCH * W) {  // (long rows only)
@@ -203,31 +207,37 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
 #pragma unroll
             for (int q = 0; q < CLF_BATCH; ++q) {
                 const long long j0 = elem0(c0 + q * W);
-                if (j0 < a.ldj) apply_chunk(x[q], j0, mult);
+                if (j0 < a.ldj) apply_chunk(x[q], j0, mult, neg);
             }
         }
+    };
+    auto apply_row = [&](const RowRegs &rr, int site, int mult) {
+        if (mult < 0) apply_row_signed(rr, site, mult, std::true_type{});  // wave-uniform
+        else apply_row_signed(rr, site, mult, std::false_type{});
     };
 
     // One candidate against the current state: does it flip, and the dE of the flip.
     // Production build: branch free -- the table covers k <= table_m (entry 0 = 1 serves every downhill
     // move: u < 1 always), the few moves beyond it are evaluated behind a wave-uniform test.
+    // (LEAN: dE is returned as the integer k = s_i F_i, dE = 2 k / scale -- formed once, for the accepted one)
     auto decide = [&](int site, float u, bool live, double &dE) -> bool {
         const int f = (int)F[site];
         const int si = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
         if constexpr (LEAN) {
             const int k = si * f;  // dE = 2 k / scale
-            dE = (double)(2 * k) * inv_sc;
+            dE = __builtin_bit_cast(double, (long long)k);
             bool acc = u < ptab[min(max(k, 0), a.table_m)];
             const bool beyond = live && k > a.table_m;
             if (__ballot(beyond)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
-                if (beyond) acc = !(dE > T * 104.0) && u < expf_det((float)(-dE / T));
+                const double dEk = (double)(2 * k) * inv_sc;
+                if (beyond) acc = !(dEk > T * 104.0) && u < expf_det((float)(-dEk / T));
             }
             return live && acc;
         } else {
             return live && field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, dE);
         }
     };
-    // what a wave found in its window, for the other waves: [2][CLF_MAX_WAVES][8] ints behind the accept
+    // what a wave found in its window, for the other waves: [2][CLF_MAX_WAVES][CLF_SLOT_INTS] ints behind the accept
     // table, the two halves taking turns (a wave may run one round ahead of a wave still reading)
     int *slots2 = reinterpret_cast<int *>(ptab + ((a.table_m + 2) & ~1));
     int turn = 0;
@@ -277,8 +287,13 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             // The row of the accept after this one is requested ahead: of the candidates that accept
             // against the current state, the second is very likely still the next accept once the
             // first has been applied (one flip moves a field by 2 |J|), so its row travels while
-            // this accept is applied and the rest is evaluated again.
-            RowRegs nxt;
+            // this accept is applied and the rest is evaluated again.  (Two rows ahead -- three
+            // candidates per wave and round -- measured SLOWER: a round is ~400 issued instructions per
+            // wave, not a memory round trip; profiles/r03_experiments.md 1.)
+            // One row request per round, unconditionally (no predicted accept: the current row again, a
+            // cache hit): the loads in flight at the end of a round are then the same on every path, the
+            // compiler keeps counted waits, and the evaluation of the next round runs while they travel.
+            RowRegs nxt = row_request(0);
             int nxt_pos = -1;  // super-window position whose row `nxt` holds (-1: none)
             auto first_of = [](unsigned long long mA, unsigned long long mB) -> int {
                 const int pA = mA ? 2 * (int)__builtin_ctzll(mA) : NONE;
@@ -292,6 +307,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                 const bool fB = decide(sB, uB, vB && gB >= pos, dEB);
                 unsigned long long mA = __ballot(fA), mB = __ballot(fB);
                 int p = first_of(mA, mB), p2 = NONE, site = 0, site2 = 0;
+                int s_old = 1;  // the spin at the first candidate's site, read while the state is stable
                 double dE = 0.0;
                 if (p < NONE) {
                     if (p & 1) mB &= mB - 1;
@@ -299,6 +315,9 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                     p2 = first_of(mA, mB);
                     site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, p >> 1);
                     dE = read_lane((p & 1) ? dEB : dEA, p >> 1);
+                    if constexpr (LEAN)  // the lanes carried k = s_i F_i: dE = 2 k / scale
+                        dE = (double)(2 * (int)__builtin_bit_cast(long long, dE)) * inv_sc;
+                    s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
                     if (p2 < NONE) site2 = __builtin_amdgcn_readlane((p2 & 1) ? sB : sA, p2 >> 1);
                     p += w * CLF_WINDOW;
                     if (p2 < NONE) p2 += w * CLF_WINDOW;
@@ -306,42 +325,40 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                 if (W > 1) {
                     // the earliest window with an accept decides; the predicted next accept is that wave's
                     // second, else the first of a later wave
-                    int *slots = slots2 + turn * (8 * CLF_MAX_WAVES);
+                    int *slots = slots2 + turn * (CLF_SLOT_INTS * CLF_MAX_WAVES);
                     turn ^= 1;
-                    int *mine = slots + 8 * w;
+                    int *mine = slots + CLF_SLOT_INTS * w;
                     if (lane == 0) {
                         mine[0] = p, mine[1] = p2, mine[2] = site, mine[3] = site2;
                         *reinterpret_cast<double *>(mine + 4) = dE;
+                        mine[6] = s_old;  // (read BEFORE the barrier: wave 0 flips the spin right after its share
+                                          //  of the row, possibly before a slower wave would get to read it)
                     }
                     __syncthreads();  // (A) every wave has evaluated against the old state and published
-                    const int q0 = lane < W ? slots[8 * lane] : NONE;
+                    const int q0 = lane < W ? slots[CLF_SLOT_INTS * lane] : NONE;
                     const unsigned long long have = __ballot(q0 < NONE);
                     if (have == 0ull) {
                         p = NONE;
                     } else {
-                        const int wf = (int)__builtin_ctzll(have);
-                        const int *win = slots + 8 * wf;
+                        const int *win = slots + CLF_SLOT_INTS * (int)__builtin_ctzll(have);
                         p = win[0], p2 = win[1], site = win[2], site2 = win[3];
                         dE = *reinterpret_cast<const double *>(win + 4);
+                        s_old = win[6];
                         const unsigned long long later = have & (have - 1);
                         if (p2 >= NONE && later) {
-                            const int *nx = slots + 8 * (int)__builtin_ctzll(later);
+                            const int *nx = slots + CLF_SLOT_INTS * (int)__builtin_ctzll(later);
                             p2 = nx[0], site2 = nx[2];
                         }
                         p = __builtin_amdgcn_readfirstlane(p), p2 = __builtin_amdgcn_readfirstlane(p2);
                         site = __builtin_amdgcn_readfirstlane(site), site2 = __builtin_amdgcn_readfirstlane(site2);
+                        s_old = __builtin_amdgcn_readfirstlane(s_old);
                     }
                 }
                 if (p >= NONE) break;  // the rest of the super-window is rejected
-                const int s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
                 RowRegs cur;
-                if (nxt_pos == p) {
-                    cur = nxt;
-                    if (p2 < NONE) nxt = row_request(site2);
-                } else {
-                    cur = row_request(site);
-                    if (p2 < NONE) nxt = row_request(site2);
-                }
+                if (nxt_pos == p) cur = nxt;
+                else cur = row_request(site);
+                nxt = row_request(p2 < NONE ? site2 : site);
                 nxt_pos = p2 < NONE ? p2 : -1;
                 E += dE;
                 ++nacc;

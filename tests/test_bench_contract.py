@@ -47,3 +47,24 @@ def test_round2_headline_carries_the_beyond_cache_roofline():
     assert b["frac"] == pytest.approx(b["achieved"] / b["peak"]) and b["frac"] >= 0.6
     assert abs(b["traffic"] / b["algorithmic_bytes_per_launch"] - 1.0) < 0.05      # PMC bytes within 5 %
     assert d["kernel_ms_total"] <= d["wall_ms_total"] and d["ranks_seen"] == 1
+
+
+def test_round3_headline_names_its_kernel_and_carries_the_cached_field_variant():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c2a_f32.json")))
+    r = d["roofline"]
+    # the graded figure is the one-row-per-proposal kernel with B = n x sizeof(J element)
+    assert r["kernel"] == "sweep_dense_kernel" and r["kernel_instantiation"].startswith("sweep_dense_kernel<float")
+    assert r["algorithmic_bytes_per_attempt"] == 40000.0 and "sweep=cached" not in d["config"]["geometry"]
+    assert d["couplings_checksum_agree"] is True
+    v = d["variants"]["cached_local_fields"]
+    assert v["kernel_instantiation"].startswith("sweep_clf_kernel") and v["tracked_energy_equals_recomputed"] is True
+    assert v["value"] > 50 * d["value"] and v["after_100_sweeps"]["value"] > v["value"]
+    assert v["algorithmic_bytes_per_attempt"] == pytest.approx(v["acceptance_rate"] * v["roofline"]["row_bytes"])
+    # the committed profile is of the instantiation the line names (CPW and waves from the geometry)
+    stats = open(os.path.join(ROOT, "profiles", "r03_c2a_f32_kernel_stats.csv")).read()
+    assert "sweep_dense_kernel<float, 5, false, true, true, false, false>" in stats
+    f = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c2a_f32_force_dist.json")))
+    assert f["backend"] == "nccl" and f["ranks_seen"] == 1 and f["couplings_checksum_agree"] is True
+    assert f["couplings_checksum"] == d["couplings_checksum"]
+    c5 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c5_1000_csr.json")))
+    assert "4 geometric ladder(s)" in c5["config"]["workload"] and "substitute_instance" in c5["cpu_baseline"]
