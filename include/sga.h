@@ -291,7 +291,8 @@ int sga_set_csr_storage(sga_engine *e, int storage);
  * in LDS; seeded by one pass over J on the matrix cores) and a row is read only when a proposal is
  * ACCEPTED, to update them -- the reference's incremental mode, core/energy_computer.py:166-173,262-265.
  * Same sites, uniforms and accept rule: the chain equals OFF's bit for bit.  Needs dense couplings of
- * one model, J and h integer valued, J symmetric with a zero diagonal, max_i(sum_j |J_ij| + |h_i|) < 2^24,
+ * one model, J integer valued and symmetric with a zero diagonal, h in multiples of 1/2,
+ * max_i(sum_j |J_ij| + |h_i|) < 2^24 (2^23 with half-integer h),
  * n <= ~75 000 (int16 fields; ~37 000 with int32); any rule but SGA_RULE_WOLFF.  ON: sga_sweep fails with
  * SGA_ERR_UNSUPPORTED where that does not hold; AUTO: falls back to OFF's kernels there. */
 #define SGA_FIELD_CACHE_OFF 0

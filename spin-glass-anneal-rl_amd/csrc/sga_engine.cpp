@@ -346,10 +346,10 @@ bool clf_possible(const sga_engine *e, const char **why) {
     const char *reason = nullptr;
     if (e->csr || e->tsp) reason = "cached local fields: dense couplings only";
     else if (!e->clf_problem)
-        reason = "cached local fields need one model with integer-valued symmetric J, zero diagonal, integer h "
-                 "and row sums below 2^24";
-    else if (e->R > 0 && sga::sweep_clf_lds_bytes((e->ldj + 127) / 128 * 128, e->clf_bits, e->sstride, e->table_m) >
-                             160 * 1024)
+        reason = "cached local fields need one model with integer-valued symmetric J, zero diagonal, h in "
+                 "multiples of 1/2 and row sums below 2^24";
+    else if (e->R > 0 && sga::sweep_clf_lds_bytes((e->ldj + 127) / 128 * 128, e->clf_bits, e->sstride,
+                                                  e->clf_scale == 2 ? 2048 : e->table_m) > 160 * 1024)
         reason = "cached local fields: fields and spins of a replica do not fit LDS";
     if (why) *why = reason;
     return reason == nullptr;
@@ -807,10 +807,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
     if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
     // cached-local-field sweep: exact integer fields, dE of the rule == energy change, one model
+    // (h a multiple of 1/2 -- the penalty encodings of 0/1 variables -- keeps 2 F an integer: scale 2)
     e->row_abs_max = m;
-    e->clf_problem = nonint == 0u && m < 16777216.0f && e->consistent_dE && n_models == 1;
-    e->clf_scale = 1;
-    e->clf_bits = m < 32768.0f ? 16 : 32;
+    e->clf_scale = (nonint & 2u) ? 2 : 1;
+    e->clf_problem = (nonint & 5u) == 0u && (double)m * e->clf_scale < 16777216.0 && e->consistent_dE && n_models == 1;
+    e->clf_bits = (double)m * e->clf_scale < 32768.0 ? 16 : 32;
     int rc = pack_dense(e, src, ld_src);
     if (rc == SGA_OK) rc = ensure_packed(e);
     // the source (the caller's buffer, or the staging copy about to be released) is done with
@@ -1589,6 +1590,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                           e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
         hipError_t le;
         if (clf) {
+            if (e->clf_scale == 2)  // half-integer fields: dE = q for q <= 2 M, tabulated at twice the resolution
+                a.table_m = (int)std::min(2.0 * (double)e->row_abs_max, 2048.0);
             a.fields = e->fields;
             a.ldf = e->ldf;
             a.field_bits = e->clf_bits;

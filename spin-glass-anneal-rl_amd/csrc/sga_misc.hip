@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__r
         atomicMax(&out[0], __builtin_bit_cast(unsigned int, row));  // non-negative: bit order = value order
         if (bad[0] | bad[1] | bad[2] | bad[3]) atomicOr(&out[1], 1u);  // some J not an integer
         if (hi != __builtin_rintf(hi)) atomicOr(&out[1], 2u);           // some h not an integer
+        if (2.0f * hi != __builtin_rintf(2.0f * hi)) atomicOr(&out[1], 4u);  // ... not even a multiple of 1/2
     }
 }
 hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, long long rows,
