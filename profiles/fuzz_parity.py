@@ -24,7 +24,7 @@ while time.time() < t_end:
     n = int(rng.choice(sizes))
     if kind == "csr":
         n = max(n, 2)
-    R = int(rng.choice([1, 2, 3, 7, 16, 33]))
+    R = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))  # (>= 32: energies from the matrix-core pass)
     ns = int(rng.choice([1, 2, 3, 5]))
     integer = rng.rand() < 0.6
     fixed = (not integer) and rng.rand() < 0.5   # real values on a 2^-10 grid: the fp64-exact row-sum forms
@@ -48,6 +48,12 @@ while time.time() < t_end:
         env["SGA_NO_LOOK_AHEAD"] = "1"
     if kind == "csr" and rng.rand() < 0.5:
         env["SGA_FORCE_CSR_BIG"] = "1"
+    # cached-local-field sweep (round 3): "auto" takes it wherever the problem allows, any waves per replica
+    cache = str(rng.choice(["off", "auto", "auto"]))
+    if cache == "auto" and rng.rand() < 0.6:
+        env["SGA_CLF_WAVES"] = str(rng.choice([1, 2, 3, 4, 8]))
+    if kind == "csr" and rng.rand() < 0.3:
+        env["SGA_CSR_PAIR_AHEAD"] = str(rng.choice([1, 2]))
     seed = int(rng.randint(1, 1 << 30))
     temps = np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R) if R > 1 else np.asarray([1.5])
     mode = str(rng.choice(["plain", "plain", "rules", "pt", "batch", "tsp", "wolff"]))
@@ -59,7 +65,7 @@ while time.time() < t_end:
         R = n_lad * int(rng.choice([2, 3, 4, 7]))
         temps = np.tile(np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R // n_lad), n_lad)
     slot_temps = temps.copy()
-    desc = f"{mode} rule={rule} site={site_mode} arith={arith} lad={n_lad} {kind} n={n} R={R} ns={ns} int={integer} fixed={fixed} dens={dens:.3g} storage={storage} waves={waves} env={env} seed={seed}"
+    desc = f"{mode} rule={rule} site={site_mode} arith={arith} lad={n_lad} {kind} n={n} R={R} ns={ns} int={integer} fixed={fixed} dens={dens:.3g} storage={storage} waves={waves} cache={cache} env={env} seed={seed}"
     for k, v in env.items():
         os.environ[k] = v
     if mode == "tsp":   # TSP-structured couplings never stored vs the oracle on the CSR its restatement writes
@@ -195,6 +201,7 @@ while time.time() < t_end:
                     e.set_tuning(waves_per_replica=min(waves, 8 if kind == "csr" else 16))
                 except Exception:
                     pass
+            e.set_field_cache(cache)
             if kind == "csr":
                 e.set_csr(rowptr, col, val, h)
             else:

@@ -35,6 +35,8 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
 def test_plain_c_program_runs_the_engine(tmp_path):
     p = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith("OK version="), (p.returncode, p.stdout, p.stderr)
+    # ... and the same run through sga_set_field_cache(ON): identical energies, the kernel it launched
+    assert "OK cached-fields" in p.stdout and "kernel=sweep_clf_kernel" in p.stdout, p.stdout
 
 
 def test_csr_storage_codes_agree_between_header_and_host():
@@ -47,3 +49,14 @@ def test_csr_storage_codes_agree_between_header_and_host():
     assert codes == {"auto": 0, "f32": 1, "packed": 2}
     src = inspect.getsource(sg.AnnealEngine.set_csr_storage)
     assert '{"auto": 0, "f32": 1, "packed": 2}' in src
+
+
+def test_field_cache_codes_agree_between_header_and_host():
+    import inspect
+    import re
+    import spin_glass_anneal_rl_amd as sg
+    text = open(os.path.join(INC, "sga.h")).read()
+    codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define SGA_FIELD_CACHE_(\w+) (\d+)", text)}
+    assert codes == {"off": 0, "on": 1, "auto": 2}
+    src = inspect.getsource(sg.AnnealEngine.set_field_cache)
+    assert '"off": 0' in src and '"on": 1' in src and '"auto": 2' in src
