@@ -2,7 +2,8 @@
 
 API of the reference's spin_glass_rl/core/energy_computer.py:12-311 (`ComputeMode`,
 `EnergyStats`, `EnergyComputer`).  The O(n^2) work -- total energies, all local fields, batches
-of configurations -- runs in the HIP engine (`energy_*_kernel`, `point_op_kernel`); what is left
+of configurations (32 and more: one pass over J on the matrix cores, `fields_mfma_kernel`) -- runs in
+the HIP engine (`energy_*_kernel`, `point_op_kernel`); what is left
 on the host are O(n) recombinations of GPU-produced local fields for the diagnostic breakdowns.
 The three compute modes of the reference return the same number; they are accepted and ignored.
 """
@@ -78,7 +79,8 @@ class EnergyComputer:
                            field_energy=field, per_spin_energy=per_spin)
 
     def compute_batch_energies(self, spin_configs: torch.Tensor) -> torch.Tensor:
-        """Energies of B configurations [B, n] in one batched kernel (reference :142-158 loops)."""
+        """Energies of B configurations [B, n] in one batched pass (reference :142-158 loops over them):
+        B >= 32 configurations of a dense model read J once, on the matrix cores."""
         cfg = spin_configs.detach().reshape(-1, self.model.n_spins)
         s0 = cfg.cpu().numpy().astype(np.int8)
         with AnnealEngine(_device_index(self.model.device)) as e:
