@@ -16,7 +16,11 @@ int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus) {
     const int epc = j_is_i8 ? 1024 : 256;
     const int chunks = (int)((ldj + epc - 1) / epc);
     const int per_cu = std::max(1, (R + std::max(cus, 1) - 1) / std::max(cus, 1));
-    const int cap = std::max(1, std::min(CLF_MAX_WAVES, 32 / per_cu));
+    // (the kernel holds two row buffers: ~120 VGPRs = 4 waves per SIMD = 16 resident waves per CU -- 6 or 8
+    //  waves x 4 workgroups ran as two rounds of workgroups: 13.3 / 10.3 ms against 6.4 for the hot sweep)
+    //  fp32 rows (4 x the chunks) measured the other way: 8 waves in two rounds 16.7 / 0.195 ms (hot / cold
+    //  sweep) against 19.4 / 0.253 for 4 resident waves that stream their second batch of chunks)
+    const int cap = std::max(1, std::min(CLF_MAX_WAVES, (j_is_i8 ? 16 : 32) / per_cu));
     // about three chunks per wave, from {1, 2, 3, 4, 8} (measured at 10 chunks, 1024 replicas: 1 / 2 / 3 / 4 /
     // 6 / 8 waves -> 0.28 / 0.19 / 0.175 / 0.167 / 0.173 / 0.165 ms per cold sweep, 9.3 / 6.6 / 7.2 / 7.1 /
     // 15.0 / 11.4 ms for the first, hot one: profiles/r03_experiments.md)
