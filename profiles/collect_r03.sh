@@ -22,8 +22,12 @@ passes() {  # tag, note, program args...
 for t in "$@"; do
   case $t in
     headline)
-      python3 bench.py --no-variants --no-cpu-baseline > gpurun_out/r03_pick.json 2> gpurun_out/r03_pick.err || exit 1
-      W=$(python3 -c "import json,re; d=json.load(open('gpurun_out/r03_pick.json')); print(re.search(r'waves_per_replica=(\d+)', d['config']['geometry']).group(1))")
+      # the pick of the committed bench line (collect_r03_all.sh passes it), else of a plain run here
+      if [ -z "$PICK_FROM" ]; then
+        python3 bench.py --no-variants --no-cpu-baseline > gpurun_out/r03_pick.json 2> gpurun_out/r03_pick.err || exit 1
+        PICK_FROM=gpurun_out/r03_pick.json
+      fi
+      W=$(python3 -c "import json,re; d=json.load(open('$PICK_FROM')); print(re.search(r'waves_per_replica=(\d+)', d['config']['geometry']).group(1))")
       echo "autotuner's pick on this box: $W waves per replica"
       passes c2a_f32 "bench.py --waves $W --no-variants --no-cpu-baseline (the autotuner's pick on this box)" \
              python3 bench.py --waves $W --no-variants --no-cpu-baseline ;;

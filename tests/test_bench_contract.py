@@ -61,8 +61,15 @@ def test_round3_headline_names_its_kernel_and_carries_the_cached_field_variant()
     assert v["value"] > 50 * d["value"] and v["after_100_sweeps"]["value"] > v["value"]
     assert v["algorithmic_bytes_per_attempt"] == pytest.approx(v["acceptance_rate"] * v["roofline"]["row_bytes"])
     # the committed profile is of the instantiation the line names (CPW and waves from the geometry)
+    import re
+    m = re.match(r"sweep_dense_kernel<float, CPW=(\d+), ACC64=0, LEAN=1, BATCH=(\d), SINGLE=0, CANON=0> x (\d+) wave", r["kernel_instantiation"])
+    assert m, r["kernel_instantiation"]
     stats = open(os.path.join(ROOT, "profiles", "r03_c2a_f32_kernel_stats.csv")).read()
-    assert "sweep_dense_kernel<float, 5, false, true, true, false, false>" in stats
+    assert f"sweep_dense_kernel<float, {m.group(1)}, false, true, {'true' if m.group(2) == '1' else 'false'}, false, false>" in stats
+    note = json.load(open(os.path.join(ROOT, "profiles", "r03_c2a_f32_pmc.json")))["note"]
+    assert f"--waves {m.group(3)} " in note                      # ... at the same waves per replica
+    avg_ms = [float(l.split(",")[-5]) / 1e6 for l in stats.splitlines() if "sweep_dense_kernel" in l][0]
+    assert abs(avg_ms / r["avg_launch_ms"] - 1.0) < 0.02           # the trace's average agrees with the line's
     f = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_c2a_f32_force_dist.json")))
     assert f["backend"] == "nccl" and f["ranks_seen"] == 1 and f["couplings_checksum_agree"] is True
     assert f["couplings_checksum"] == d["couplings_checksum"]
