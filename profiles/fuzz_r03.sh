@@ -1,4 +1,8 @@
-cd "$GRAFT_REPO_ROOT"
-timeout -k 10 420 python profiles/fuzz_parity.py 380 301 > gpurun_out/fuzz_r03_a.log 2>&1; tail -3 gpurun_out/fuzz_r03_a.log
-FUZZ_BIG=1 timeout -k 10 320 python profiles/fuzz_parity.py 280 302 > gpurun_out/fuzz_r03_b.log 2>&1; tail -3 gpurun_out/fuzz_r03_b.log
-grep -c "MISMATCH\|ERROR" gpurun_out/fuzz_r03_a.log gpurun_out/fuzz_r03_b.log
+#!/bin/bash
+# round-3 fuzz record: fuzz_parity.py with the field cache, the matrix-core energies and the opt-in CSR pair
+# look-ahead in the mix (usage: bash profiles/fuzz_r03.sh <seconds> <seed> [big seconds])
+cd "$GRAFT_REPO_ROOT" || exit 1
+secs=${1:-380}; seed=${2:-301}; big=${3:-280}
+timeout -k 10 $((secs + 60)) python profiles/fuzz_parity.py $secs $seed > gpurun_out/fuzz_r03_a.log 2>&1; tail -1 gpurun_out/fuzz_r03_a.log
+FUZZ_BIG=1 timeout -k 10 $((big + 60)) python profiles/fuzz_parity.py $big $((seed + 1)) > gpurun_out/fuzz_r03_b.log 2>&1; tail -1 gpurun_out/fuzz_r03_b.log
+echo "mismatches / errors: $(cat gpurun_out/fuzz_r03_a.log gpurun_out/fuzz_r03_b.log | grep -c 'MISMATCH\|ERROR')"

@@ -216,16 +216,20 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
         else apply_row_signed(rr, site, mult, std::false_type{});
     };
 
-    // One candidate against the current state: does it flip, and the dE of the flip.
-    // Production build: branch free -- the table covers k <= table_m (entry 0 = 1 serves every downhill
-    // move: u < 1 always), the few moves beyond it are evaluated behind a wave-uniform test.
-    // (LEAN: dE is returned as the integer k = s_i F_i, dE = 2 k / scale -- formed once, for the accepted one)
-    auto decide = [&](int site, float u, bool live, double &dE) -> bool {
+    // One candidate against the current state: does it flip?  The production build returns k = s_i F_i
+    // (dE = 2 k / scale is formed once, for the accepted candidate) and is branch free -- the table covers
+    // k <= table_m (entry 0 = 1 serves every downhill move: u < 1 always), the few moves beyond it are
+    // evaluated behind a wave-uniform test; the general build returns dE from the reference's arithmetic.
+    struct Verdict {
+        int k;      // LEAN
+        double dE;  // !LEAN
+    };
+    auto decide = [&](int site, float u, bool live, Verdict &v) -> bool {
         const int f = (int)F[site];
         const int si = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
         if constexpr (LEAN) {
-            const int k = si * f;  // dE = 2 k / scale
-            dE = __builtin_bit_cast(double, (long long)k);
+            const int k = si * f;
+            v.k = k;
             bool acc = u < ptab[min(max(k, 0), a.table_m)];
             const bool beyond = live && k > a.table_m;
             if (__ballot(beyond)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             }
             return live && acc;
         } else {
-            return live && field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, dE);
+            return live && field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, v.dE);
         }
     };
     // what a wave found in its window, for the other waves: [2][CLF_MAX_WAVES][CLF_SLOT_INTS] ints behind the accept
@@ -302,9 +306,9 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             };
             for (;;) {
                 // this wave's window: first and second candidate that flip against the current state
-                double dEA = 0.0, dEB = 0.0;
-                const bool fA = decide(sA, uA, vA && gA >= pos, dEA);
-                const bool fB = decide(sB, uB, vB && gB >= pos, dEB);
+                Verdict vdA{0, 0.0}, vdB{0, 0.0};
+                const bool fA = decide(sA, uA, vA && gA >= pos, vdA);
+                const bool fB = decide(sB, uB, vB && gB >= pos, vdB);
                 unsigned long long mA = __ballot(fA), mB = __ballot(fB);
                 int p = first_of(mA, mB), p2 = NONE, site = 0, site2 = 0;
                 int s_old = 1;  // the spin at the first candidate's site, read while the state is stable
@@ -314,9 +318,8 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                     else mA &= mA - 1;
                     p2 = first_of(mA, mB);
                     site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, p >> 1);
-                    dE = read_lane((p & 1) ? dEB : dEA, p >> 1);
-                    if constexpr (LEAN)  // the lanes carried k = s_i F_i: dE = 2 k / scale
-                        dE = (double)(2 * (int)__builtin_bit_cast(long long, dE)) * inv_sc;
+                    if constexpr (LEAN) dE = (double)(2 * read_lane((p & 1) ? vdB.k : vdA.k, p >> 1)) * inv_sc;
+                    else dE = read_lane((p & 1) ? vdB.dE : vdA.dE, p >> 1);
                     s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
                     if (p2 < NONE) site2 = __builtin_amdgcn_readlane((p2 & 1) ? sB : sA, p2 >> 1);
                     p += w * CLF_WINDOW;
