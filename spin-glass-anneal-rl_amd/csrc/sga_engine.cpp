@@ -202,6 +202,7 @@ struct sga_engine {
     // 5 dE trace, 6 exchange energies, 7 exchange start, 8 exchange u
     Scratch scratch[9];
     Scratch point_sites, point_out;  // single-site operators
+    Scratch csr_energy;              // transposed spin bits + partial sums of the all-replica CSR energy pass
 
     // timing
     bool timing = false;
@@ -308,7 +309,7 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
 // All replicas' local fields in one pass over the couplings on the matrix cores (fields_dense.hip),
 // then energies and / or the resident fields of the cached-field sweep from them.
 bool fields_pass_applies(const sga_engine *e, int count) {
-    static const bool off = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // A/B switch
+    const bool off = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // A/B switch (read per call: tests flip it)
     return !off && !e->csr && !e->tsp && e->n_models == 1 && count >= 32 && e->J_packed;
 }
 int fields_pass(sga_engine *e, int r0, int count, double *energy, void *fields) {
@@ -370,6 +371,19 @@ int ensure_fields(sga_engine *e) {
 
 int recompute_energy_range(sga_engine *e, int r0, int count) {
     if (fields_pass_applies(e, count)) return fields_pass(e, r0, count, e->energy + r0, nullptr);
+    const bool no_csr_all = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // (one A/B switch for both passes)
+    if (e->csr && !e->tsp && count >= 64 && !no_csr_all) {
+        // all replicas in one pass over the entries: spins transposed to bits, 32 replicas per lane
+        // row groups: enough (group, replica word) threads to fill the chip -- ~4 waves per SIMD -- whatever
+        // the replica count (256 replicas = 8 words: 4096 groups left half the SIMDs without a wave)
+        const int words = (count + 31) / 32;
+        const int groups = std::max(1, std::min(e->n, std::max(1024, 262144 / words)));
+        HIPCHK(e->csr_energy.reserve(sga::csr_energy_scratch_bytes(e->n, count, groups)));
+        const bool exact32 = e->csr_acc == sga::CSR_ACC_F32_TABLE || e->csr_acc == sga::CSR_ACC_F32;
+        HIPCHK(sga::launch_energy_csr_all(e->rowptr64, e->cv, e->h, e->spins + (long long)r0 * e->sstride, e->sstride, e->n,
+                                          count, groups, exact32, e->csr_energy.ptr, e->energy + r0, e->stream));
+        return SGA_OK;
+    }
     sga::EnergyArgs a{};
     a.J = e->J_packed;
     a.rowptr = e->rowptr64;
@@ -531,6 +545,7 @@ void sga_destroy(sga_engine *e) {
     for (auto &sl : e->scratch) sl.release();
     e->point_sites.release();
     e->point_out.release();
+    e->csr_energy.release();
     dev_free(e->d_count);
     dev_free(e->d_flags);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);

@@ -140,6 +140,18 @@ hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStre
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus);
 
+// Energies of all replicas of a CSR problem in one pass over the entries (fields_csr.hip)
+struct CsrEnergyArgs {
+    const long long *rowptr;
+    const int2 *cv;
+    const unsigned int *sb;  // [n][RW] transposed spin bits
+    double *partial;         // [groups][32 RW]
+    int n, R, RW, groups;
+};
+size_t csr_energy_scratch_bytes(int n, int R, int groups);
+hipError_t launch_energy_csr_all(const long long *rowptr, const int2 *cv, const float *h, const int8_t *spins, int sstride,
+                                 int n, int R, int groups, bool exact32, void *scratch, double *energy, hipStream_t st);
+
 struct ExchangeArgs {
     const double *energies;   // [R_global] by global replica id
     const double *slot_temps; // [R_global]

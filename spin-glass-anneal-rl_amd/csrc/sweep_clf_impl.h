@@ -22,10 +22,19 @@
 // Byte model (its own, reported beside the graded one-row-per-proposal figure, never instead of
 // it): B = acceptance rate x n x sizeof(J element) per attempt, SURVEY.md 8(d) last sentence.
 //
-// Mapping: one workgroup per replica, W waves.  Every wave evaluates the same window redundantly
-// (no communication to agree on the decision); the row of an accepted site is dealt to the waves
-// in 1-KiB chunks (chunk c -> wave c mod W), each wave updating the fields under its chunks.
-// With W > 1 an accept costs two barriers (nobody still evaluates / everybody has applied).
+// Mapping: one workgroup per replica, W waves (1 ... 8).  Wave w evaluates the 128 updates of ITS window
+// of a W x 128-update super-window and publishes its first two accepting candidates (position, site, dE,
+// the spin at the first site) in an LDS slot; after one barrier every wave reads the slots and takes the
+// earliest accept -- the decision is the same in all waves without further communication.  The row of the
+// accepted site is dealt to the waves in 1-KiB chunks (chunk c -> wave c mod W), each wave updating the
+// fields under its chunks; a second barrier makes the new state visible and the candidates behind the
+// accept are evaluated again.  One row request per round: the row of the PREDICTED next accept (the second
+// accepting candidate) travels while the current accept is applied and the next round is evaluated.
+// What must hold between the waves: nobody applies before everybody has evaluated (barrier A), nobody
+// evaluates before everybody has applied and wave 0 has flipped the spin (barrier B), and the spin at
+// the accepted site is read BEFORE barrier A (wave 0 flips it right after its own share of the row).
+// Cost: ~260 issued instructions per wave and accept + two barriers ~ 2 us; nothing per rejected
+// proposal beyond its share of an evaluation round (profiles/r03_experiments.md 1).
 #pragma once
 #include <type_traits>
 

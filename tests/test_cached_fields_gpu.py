@@ -398,3 +398,36 @@ def test_matrix_core_energies_match_oracle(sg, n, R, kind):
                 assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
             else:
                 assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["pm1", "int", "gauss"])
+@pytest.mark.parametrize("n,deg,R", [(300, 8, 64), (1000, 40, 130), (2000, 200, 70), (65, 64, 97)])
+def test_csr_energies_of_many_replicas_in_one_pass(sg, n, deg, R, kind, monkeypatch):
+    """64 and more replicas of a CSR problem: spins transposed to a bit matrix, every entry read once for 32
+    replicas per lane (csrc/fields_csr.hip) -- against the oracle and against the per-replica kernel."""
+    rng = np.random.RandomState(n + deg)
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rng.choice(n, min(deg // 2 + 1, n - 1), replace=False):
+            if i != j:
+                v = {"pm1": rng.choice([-1.0, 1.0]), "int": float(rng.randint(-90, 91)), "gauss": rng.randn()}[kind]
+                J[i, j] = J[j, i] = v
+    h = (rng.randn(n) if kind == "gauss" else rng.randint(-3, 4, n)).astype(np.float32)
+    rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
+    col = np.concatenate([np.nonzero(J[i])[0] for i in range(n)]).astype(np.int32)
+    val = np.concatenate([J[i][J[i] != 0] for i in range(n)]).astype(np.float32)
+    prob = oracle.Problem(csr=(rowptr, col, val), h=h)
+    s0 = oracle.init_spins(n, R, 321)
+    want = oracle.energy(prob, s0)
+    got = {}
+    for one_pass in (True, False):
+        if not one_pass:
+            monkeypatch.setenv("SGA_NO_MFMA_ENERGY", "1")
+        with sg.AnnealEngine(0) as e:
+            e.set_csr(rowptr, col, val, h)
+            e.init_replicas(R, seed=321)
+            got[one_pass] = e.energies()
+    if kind == "gauss":  # fp64 accumulation in another order: equal to the rounding of the last bits
+        assert np.allclose(got[True], want, rtol=1e-6, atol=1e-6) and np.allclose(got[True], got[False], rtol=1e-6, atol=1e-6)
+    else:
+        assert np.array_equal(got[True], want) and np.array_equal(got[False], want)
