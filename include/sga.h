@@ -182,7 +182,12 @@ int sga_set_update_rule(sga_engine *e, int rule);
  * fp32, consumed in draw order by the following Wolff sweeps (NULL: back to Philox). */
 int sga_set_wolff_replay(sga_engine *e, const float *u, int64_t capacity);
 
-/* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s */
+/* Recompute every local replica's energy from scratch: -0.5 s.(J s) - h.s.  Batches of replicas share
+ * one pass over the couplings (EnergyComputer.compute_batch_energies, core/energy_computer.py:142-158):
+ * dense problems with >= 32 replicas on the matrix cores, CSR problems with >= 64 replicas through a
+ * transposed spin-bit matrix; fewer replicas take one pass each.  Same values either way (integer
+ * problems: exact; real-valued: the fp64 summation order differs, the fp32-rounded energy does not beyond
+ * its last bit). */
 int sga_recompute_energies(sga_engine *e);
 
 /* One nearest-neighbour replica-exchange round over the ladder(s)
