@@ -71,6 +71,7 @@ class OracleEngine:
                                               round_=self.rounds, ladder=l, attempts=a, accepts=c)
             self.slot_to_rep[sl], self.ex_att[sl], self.ex_acc[sl] = view, a, c
         self.rounds += 1
+        self.last_accepted = n_acc
         for slot, rep in enumerate(self.slot_to_rep):
             if self.replica0 <= rep < self.replica0 + self.R:
                 self._temps[rep - self.replica0] = self.slot_temps[slot]
