@@ -299,7 +299,10 @@ int sga_set_csr_storage(sga_engine *e, int storage);
  * one model, J integer valued and symmetric with a zero diagonal, h in multiples of 1/2,
  * max_i(sum_j |J_ij| + |h_i|) < 2^24 (2^23 with half-integer h),
  * n <= ~75 000 (int16 fields; ~37 000 with int32); any rule but SGA_RULE_WOLFF.  ON: sga_sweep fails with
- * SGA_ERR_UNSUPPORTED where that does not hold; AUTO: falls back to OFF's kernels there.  Cost model: an
+ * SGA_ERR_UNSUPPORTED where that does not hold; AUTO: falls back to OFF's kernels there -- and while the
+ * run is hot: it starts on OFF's kernels, reads the acceptance counters back every 4 ... 32 sweeps and takes
+ * the cached-field sweep while the hottest replica accepts less than ~10 % of its proposals (the chain does
+ * not depend on which kernel runs).  Cost model: an
  * accepted proposal costs ~2 us of its replica's chain, a rejected one next to nothing -- 100-300 x OFF in
  * the glassy regime annealing ends in (acceptance <= 2 %), break-even near 60 % acceptance, up to ~1.5 x
  * slower than OFF when nearly every proposal is accepted. */

@@ -175,6 +175,13 @@ struct sga_engine {
     bool fields_valid = false;
     void *ybuf = nullptr;      // [count][ldj] int32 | float: scratch of the all-replica field pass
     size_t ybuf_bytes = 0;
+    // SGA_FIELD_CACHE_AUTO looks at the acceptance of the last sweeps now and then (host read-back of the
+    // per-replica counters): an accept costs ~2 us of its replica's chain, so the cached-field sweep only
+    // pays while the HOTTEST replica accepts little
+    bool auto_use_clf = false;
+    long long auto_mark_attempted = 0;  // per-replica attempts at the last look
+    int auto_interval = 4;              // sweeps until the next look (doubles up to 32)
+    std::vector<unsigned long long> auto_mark_acc;
     int csr_acc = sga::CSR_ACC_F64_CANON;  // CSR: how the sweep kernels form a row sum (set time)
 
     // replicas
@@ -253,6 +260,10 @@ struct sga_engine {
         fields_valid = false;
         dev_free(ybuf);
         ybuf_bytes = 0;
+        auto_use_clf = false;
+        auto_mark_attempted = 0;
+        auto_interval = 4;
+        auto_mark_acc.clear();
         R = Rg = 0;
         n_ladders = 0;
     }
@@ -1537,6 +1548,34 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         clf = clf_possible(e, &why);
         if (!clf && e->field_cache == SGA_FIELD_CACHE_ON) return fail(SGA_ERR_UNSUPPORTED, why);
     }
+    if (clf && e->field_cache == SGA_FIELD_CACHE_AUTO) {
+        // AUTO: the row-per-proposal kernels until the acceptance is known, then whichever pays.  The
+        // cached-field kernel ends with its hottest replica (~2 us per accept, nothing per reject), the
+        // streaming kernels take 0.1 - 1.4 us per update whatever happens: measured break-even at 12 - 19 %
+        // acceptance of the hottest replica (profiles/clf_crossover.py).  The chain is the same either way.
+        if ((long long)e->auto_mark_acc.size() != e->R) {
+            e->auto_mark_acc.assign((size_t)e->R, 0ull);
+            e->auto_mark_attempted = 0;
+            e->auto_interval = 4;
+            e->auto_use_clf = false;
+        }
+        const long long since = e->attempted - e->auto_mark_attempted;
+        if (since >= (long long)e->auto_interval * n || since < 0) {
+            std::vector<unsigned long long> now((size_t)e->R);
+            HIPCHK(hipMemcpyAsync(now.data(), e->n_acc, sizeof(unsigned long long) * e->R, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (since > 0) {
+                unsigned long long top = 0;
+                for (int r2 = 0; r2 < e->R; ++r2) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
+                const double hottest = (double)top / (double)since;
+                e->auto_use_clf = e->auto_use_clf ? hottest < 0.16 : hottest < 0.10;  // (hysteresis)
+                e->auto_interval = std::min(32, e->auto_interval * 2);
+            }
+            e->auto_mark_acc.swap(now);
+            e->auto_mark_attempted = e->attempted;
+        }
+        clf = e->auto_use_clf;
+    }
     if (clf) {
         rc = ensure_fields(e);
         if (rc != SGA_OK) return rc;
@@ -2322,10 +2361,16 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (e->csr && e->big_form == 1 && e->cvp && e->csr_storage_latched != SGA_CSR_STORAGE_F32)
         std::strncat(tmp, " entries=packed-32bit", sizeof(tmp) - std::strlen(tmp) - 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
-    if (clf_active(e))
-        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
-                      " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
-                      e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus));
+    if (clf_active(e)) {
+        if (e->field_cache == SGA_FIELD_CACHE_ON)
+            std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                          " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
+                          e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus));
+        else
+            std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                          " sweep=auto(cached local fields, int%d in LDS, while the hottest replica accepts < 10 %%; now: %s)",
+                          e->clf_bits, e->auto_use_clf ? "cached" : "one row per proposal");
+    }
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;
 }

@@ -317,6 +317,37 @@ def test_cached_fields_need_an_integer_symmetric_problem(sg):
             sg._native.check(e._lib.sga_set_field_cache(e._h, 7), "sga_set_field_cache")
 
 
+def test_auto_takes_the_cached_field_sweep_only_while_the_run_is_cold(sg):
+    """SGA_FIELD_CACHE_AUTO starts on the row-per-proposal kernels, looks at the acceptance counters every few
+    sweeps and runs the cached-field sweep while the hottest replica accepts less than ~10 % -- with the chain
+    of "off" either way."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    n, R, seed = 1500, 48, 99
+    J = pm1(n, 4)
+    h = np.zeros(n, np.float32)
+    runs = {}
+    for name, temps in (("cold", ladder(R, 0.05 * np.sqrt(n), 0.002 * np.sqrt(n))),
+                        ("hot", ladder(R, 4.0 * np.sqrt(n), 1.0 * np.sqrt(n)))):
+        for cache in ("auto", "off"):
+            with sg.AnnealEngine(0) as e:
+                e.set_field_cache(cache)
+                e.set_dense(J, h)
+                e.init_replicas(R, seed=seed)
+                e.set_ladder(temps)
+                kernels, trace = [], []
+                for _ in range(12):
+                    trace.append(e.sweep(2, energy_trace=True)["energy_trace"])
+                    kernels.append(last_kernel().split("<")[0])
+                    e.exchange(count=False)
+                runs[name, cache] = (np.vstack(trace), e.spins(), kernels, e.describe())
+        assert np.array_equal(runs[name, "auto"][0], runs[name, "off"][0])
+        assert np.array_equal(runs[name, "auto"][1], runs[name, "off"][1])
+        assert set(runs[name, "off"][2]) == {"sweep_dense_kernel"}
+    assert runs["cold", "auto"][2][0] == "sweep_dense_kernel"          # until the acceptance is known
+    assert runs["cold", "auto"][2][-1] == "sweep_clf_kernel" and "now: cached" in runs["cold", "auto"][3]
+    assert set(runs["hot", "auto"][2]) == {"sweep_dense_kernel"} and "now: one row per proposal" in runs["hot", "auto"][3]
+
+
 # ----------------------------------------------------------------------------- BASELINE configs[1]
 def test_c2a_at_full_size_with_cached_fields(sg):
     """10 000-spin dense +-1 SK instance, 1024 replicas (bench.py's variant): the oracle follows
