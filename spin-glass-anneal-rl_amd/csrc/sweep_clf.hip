@@ -42,14 +42,18 @@ static hipError_t launch_clf(const SweepArgs &a, int waves, hipStream_t st) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool lean = sweep_args_are_lean(a) && a.rule == SGA_RULE_METROPOLIS;
     const int batch = sweep_clf_batch(a.ldj, sizeof(JT) == 1, waves);
+    const int epc = sizeof(JT) == 1 ? 1024 : 256;
+    const bool tail = (int)((a.ldj + epc - 1) / epc) > batch * waves;  // (never with 3 chunks per wave)
     void (*kern)(const SweepArgs) =
-        batch == 3 ? (lean ? sweep_clf_kernel<JT, FT, true, 3> : sweep_clf_kernel<JT, FT, false, 3>)
-                   : (lean ? sweep_clf_kernel<JT, FT, true, CLF_BATCH_MAX> : sweep_clf_kernel<JT, FT, false, CLF_BATCH_MAX>);
+        batch == 3 ? (lean ? sweep_clf_kernel<JT, FT, true, 3, false> : sweep_clf_kernel<JT, FT, false, 3, false>)
+        : tail     ? (lean ? sweep_clf_kernel<JT, FT, true, CLF_BATCH_MAX, true> : sweep_clf_kernel<JT, FT, false, CLF_BATCH_MAX, true>)
+                   : (lean ? sweep_clf_kernel<JT, FT, true, CLF_BATCH_MAX, false>
+                           : sweep_clf_kernel<JT, FT, false, CLF_BATCH_MAX, false>);
     hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
-    note_sweep_kernel("sweep_clf_kernel<%s, %s, %s, BATCH=%d> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
-                      sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", batch, waves);
+    note_sweep_kernel("sweep_clf_kernel<%s, %s, %s, BATCH=%d, TAIL=%d> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
+                      sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", batch, (int)tail, waves);
     return hipGetLastError();
 }
 

@@ -88,10 +88,12 @@ __host__ __device__ constexpr long long clf_table_offset(long long ldf, int fbyt
     return clf_bits_offset(ldf, fbytes) + ((sstride / 8 + 15) & ~15);
 }
 inline size_t clf_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {  // + [2][CLF_MAX_WAVES][CLF_SLOT_INTS] decision slots
-    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)(table_m + 2) + 2 * 4 * CLF_SLOT_INTS * CLF_MAX_WAVES + 16;
+    return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)((table_m + 4) & ~3) + 2 * 4 * CLF_SLOT_INTS * CLF_MAX_WAVES + 16;
 }
 
-template <typename JT, typename FT, bool LEAN, int CLF_BATCH = CLF_BATCH_MAX>
+// TAIL: rows longer than CLF_BATCH chunks per wave (the rest is streamed inside the field update); built
+// without it the round holds no other global load than the two row requests, and their waits stay counted
+template <typename JT, typename FT, bool LEAN, int CLF_BATCH = CLF_BATCH_MAX, bool TAIL = true>
 __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const SweepArgs a) {
     constexpr int EPL = 16 / (int)sizeof(JT), EPC = 64 * EPL;  // elements per lane / per 1-KiB chunk
     constexpr int FB = (int)sizeof(FT);
@@ -133,13 +135,25 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
         vec_t x[CLF_BATCH];
     };
     auto elem0 = [&](int c) -> long long { return ((long long)c * 64 + lane) * EPL; };
+    // this lane's byte offset into a row for each chunk of the first batch (a lane past the row's end reads
+    // the row's first granule): 32-bit, computed once -- a request is then the scalar-base form of
+    // global_load (uniform row base in SGPRs + one offset VGPR), no address arithmetic per load
+    unsigned int req_off[CLF_BATCH];
+#pragma unroll
+    for (int q = 0; q < CLF_BATCH; ++q) {
+        const long long j0 = elem0(w + q * W);
+        req_off[q] = (unsigned int)((j0 < a.ldj ? j0 : 0) * (long long)sizeof(JT));
+    }
+    const unsigned int pitch = (unsigned int)(a.ldj * (long long)sizeof(JT));
     auto row_request = [&](int site) -> RowRegs {
         RowRegs o;
-        const JT *row = Jbase + (long long)site * a.ldj;
+        // wave-uniform; a row's pitch is below 4 GB, 32 x 32 -> 64 bit is the whole product
+        const unsigned char *row = reinterpret_cast<const unsigned char *>(Jbase) + (unsigned long long)(unsigned int)site * pitch;
 #pragma unroll
         for (int q = 0; q < CLF_BATCH; ++q) {
-            const long long j0 = elem0(w + q * W);
-            o.x[q] = *reinterpret_cast<const vec_t *>(row + (j0 < a.ldj ? j0 : 0));
+            unsigned int off = req_off[q];
+            asm volatile("" : "+v"(off));  // (kept a 32-bit value: folded into 64-bit pointer arithmetic the form is lost)
+            o.x[q] = *reinterpret_cast<const vec_t *>(row + off);
         }
         return o;
     };
@@ -205,6 +219,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             const long long j0 = elem0(w + q * W);
             if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult, neg);
         }
+        if constexpr (!TAIL) return;
         const JT *row = Jbase + (long long)site * a.ldj;
         for (int c0 = w + CLF_BATCH * W; c0 < n_chunks; c0 += CLF_BATCH * W) {  // (long rows only)
             vec_t x[CLF_BATCH];
@@ -232,27 +247,36 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
     struct Verdict {
         int k;      // LEAN
         double dE;  // !LEAN
+        int si;     // the spin at the candidate's site
     };
-    auto decide = [&](int site, float u, bool live, Verdict &v) -> bool {
-        const int f = (int)F[site];
-        const int si = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
+    // Both candidates of a lane at once: their field / spin-word reads travel together, then their two table
+    // reads (two dependent LDS round trips per round instead of four).
+    auto decide2 = [&](int sA, float uA, bool liveA, Verdict &vA, int sB, float uB, bool liveB, Verdict &vB, bool &fA,
+                       bool &fB) {
+        const int fa = (int)F[sA], fb = (int)F[sB];
+        const unsigned int wa = bits[sA >> 5], wb = bits[sB >> 5];
+        vA.si = ((wa >> (sA & 31)) & 1u) ? -1 : 1;
+        vB.si = ((wb >> (sB & 31)) & 1u) ? -1 : 1;
         if constexpr (LEAN) {
-            const int k = si * f;
-            v.k = k;
-            bool acc = u < ptab[min(max(k, 0), a.table_m)];
-            const bool beyond = live && k > a.table_m;
-            if (__ballot(beyond)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
-                const double dEk = (double)(2 * k) * inv_sc;
-                if (beyond) acc = !(dEk > T * 104.0) && u < expf_det((float)(-dEk / T));
+            const int ka = vA.si * fa, kb = vB.si * fb;
+            vA.k = ka, vB.k = kb;
+            const float pa = ptab[min(max(ka, 0), a.table_m)], pb = ptab[min(max(kb, 0), a.table_m)];
+            bool accA = uA < pa, accB = uB < pb;
+            const bool beyondA = liveA && ka > a.table_m, beyondB = liveB && kb > a.table_m;
+            if (__ballot(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
+                const double dA = (double)(2 * ka) * inv_sc, dB = (double)(2 * kb) * inv_sc;
+                if (beyondA) accA = !(dA > T * 104.0) && uA < expf_det((float)(-dA / T));
+                if (beyondB) accB = !(dB > T * 104.0) && uB < expf_det((float)(-dB / T));
             }
-            return live && acc;
+            fA = liveA && accA, fB = liveB && accB;
         } else {
-            return live && field_rule_accept(rule, arith, (double)f * inv_sc, si, T, u, v.dE);
+            fA = liveA && field_rule_accept(rule, arith, (double)fa * inv_sc, vA.si, T, uA, vA.dE);
+            fB = liveB && field_rule_accept(rule, arith, (double)fb * inv_sc, vB.si, T, uB, vB.dE);
         }
     };
     // what a wave found in its window, for the other waves: [2][CLF_MAX_WAVES][CLF_SLOT_INTS] ints behind the accept
     // table, the two halves taking turns (a wave may run one round ahead of a wave still reading)
-    int *slots2 = reinterpret_cast<int *>(ptab + ((a.table_m + 2) & ~1));
+    int *slots2 = reinterpret_cast<int *>(ptab + ((a.table_m + 4) & ~3));  // (16-byte aligned: a slot is two int4)
     int turn = 0;
     constexpr int NONE = 1 << 20;
 
@@ -274,8 +298,12 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             int sA = 0, sB = 0;
             float uA = 2.0f, uB = 2.0f;
             if (LEAN || a.site_mode != SGA_SITE_REPLAY) {
+                // (the key made opaque here: its ten round values are then formed by scalar adds on the spot; hoisted
+                //  out of the sweep loop they are spilled and come back through one v_readlane each)
+                uint32_t key_lo = a.seed_lo, key_hi = a.seed_hi;
+                asm volatile("" : "+s"(key_lo), "+s"(key_hi));
                 const u32x4 x = philox4x32_10((uint32_t)(tA >> 1), a.sweep0 + (uint32_t)k, a.replica0 + (uint32_t)r,
-                                              DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+                                              DOMAIN_SWEEP, key_lo, key_hi);
                 sA = (int)word_to_site(x.x, (uint32_t)n);
                 sB = (int)word_to_site(x.z, (uint32_t)n);
                 uA = word_to_u(x.y);
@@ -304,23 +332,26 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             // candidates per wave and round -- measured SLOWER: a round is ~400 issued instructions per
             // wave, not a memory round trip; profiles/r03_experiments.md 1.)
             // One row request per round, unconditionally (no predicted accept: the current row again, a
-            // cache hit): the loads in flight at the end of a round are then the same on every path, the
-            // compiler keeps counted waits, and the evaluation of the next round runs while they travel.
-            RowRegs nxt = row_request(0);
-            int nxt_pos = -1;  // super-window position whose row `nxt` holds (-1: none)
+            // cache hit): the loads in flight at the end of a round are then the same on every path and the
+            // compiler keeps counted waits.  The two row buffers take turns (the round body is expanded
+            // twice): the predicted row is never copied, so nothing waits for it before the round that
+            // uses it -- it travels during this round's field update, the barrier and the next evaluation.
+            RowRegs buf0 = row_request(0), buf1 = buf0;
+            int held_pos = -1;  // super-window position whose row the buffer `held` of the coming round holds (-1: none)
             auto first_of = [](unsigned long long mA, unsigned long long mB) -> int {
                 const int pA = mA ? 2 * (int)__builtin_ctzll(mA) : NONE;
                 const int pB = mB ? 2 * (int)__builtin_ctzll(mB) + 1 : NONE;
                 return min(pA, pB);
             };
-            for (;;) {
+            // one round; true = the super-window is done
+            auto round = [&](RowRegs &held, RowRegs &other) -> bool {
                 // this wave's window: first and second candidate that flip against the current state
-                Verdict vdA{0, 0.0}, vdB{0, 0.0};
-                const bool fA = decide(sA, uA, vA && gA >= pos, vdA);
-                const bool fB = decide(sB, uB, vB && gB >= pos, vdB);
+                Verdict vdA{0, 0.0, 1}, vdB{0, 0.0, 1};
+                bool fA, fB;
+                decide2(sA, uA, vA && gA >= pos, vdA, sB, uB, vB && gB >= pos, vdB, fA, fB);
                 unsigned long long mA = __ballot(fA), mB = __ballot(fB);
                 int p = first_of(mA, mB), p2 = NONE, site = 0, site2 = 0;
-                int s_old = 1;  // the spin at the first candidate's site, read while the state is stable
+                int s_old = 1;  // the spin at the first candidate's site, as evaluated (the state is stable here)
                 double dE = 0.0;
                 if (p < NONE) {
                     if (p & 1) mB &= mB - 1;
@@ -329,52 +360,56 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                     site = __builtin_amdgcn_readlane((p & 1) ? sB : sA, p >> 1);
                     if constexpr (LEAN) dE = (double)(2 * read_lane((p & 1) ? vdB.k : vdA.k, p >> 1)) * inv_sc;
                     else dE = read_lane((p & 1) ? vdB.dE : vdA.dE, p >> 1);
-                    s_old = ((bits[site >> 5] >> (site & 31)) & 1u) ? -1 : 1;
+                    s_old = __builtin_amdgcn_readlane((p & 1) ? vdB.si : vdA.si, p >> 1);
                     if (p2 < NONE) site2 = __builtin_amdgcn_readlane((p2 & 1) ? sB : sA, p2 >> 1);
                     p += w * CLF_WINDOW;
                     if (p2 < NONE) p2 += w * CLF_WINDOW;
                 }
                 if (W > 1) {
                     // the earliest window with an accept decides; the predicted next accept is that wave's
-                    // second, else the first of a later wave
+                    // second, else the first of a later wave.  Lane v reads wave v's whole slot (one LDS
+                    // round trip); the winner's entries are then picked across lanes.
                     int *slots = slots2 + turn * (CLF_SLOT_INTS * CLF_MAX_WAVES);
                     turn ^= 1;
-                    int *mine = slots + CLF_SLOT_INTS * w;
                     if (lane == 0) {
-                        mine[0] = p, mine[1] = p2, mine[2] = site, mine[3] = site2;
-                        *reinterpret_cast<double *>(mine + 4) = dE;
-                        mine[6] = s_old;  // (read BEFORE the barrier: wave 0 flips the spin right after its share
-                                          //  of the row, possibly before a slower wave would get to read it)
+                        int4 *mine = reinterpret_cast<int4 *>(slots + CLF_SLOT_INTS * w);
+                        const long long dbits = __double_as_longlong(dE);
+                        mine[0] = make_int4(p, p2, site, site2);
+                        // (s_old comes from the evaluation, BEFORE the barrier: wave 0 flips the spin right after its
+                        //  share of the row, possibly before a slower wave would get to read it)
+                        mine[1] = make_int4((int)(unsigned int)dbits, (int)(dbits >> 32), s_old, 0);
                     }
                     __syncthreads();  // (A) every wave has evaluated against the old state and published
-                    const int q0 = lane < W ? slots[CLF_SLOT_INTS * lane] : NONE;
-                    const unsigned long long have = __ballot(q0 < NONE);
+                    int4 q0 = make_int4(NONE, NONE, 0, 0), q1 = make_int4(0, 0, 1, 0);
+                    if (lane < W) {
+                        const int4 *theirs = reinterpret_cast<const int4 *>(slots + CLF_SLOT_INTS * lane);
+                        q0 = theirs[0], q1 = theirs[1];
+                    }
+                    const unsigned long long have = __ballot(q0.x < NONE);
                     if (have == 0ull) {
                         p = NONE;
                     } else {
-                        const int *win = slots + CLF_SLOT_INTS * (int)__builtin_ctzll(have);
-                        p = win[0], p2 = win[1], site = win[2], site2 = win[3];
-                        dE = *reinterpret_cast<const double *>(win + 4);
-                        s_old = win[6];
+                        const int win = (int)__builtin_ctzll(have);
+                        p = __builtin_amdgcn_readlane(q0.x, win), p2 = __builtin_amdgcn_readlane(q0.y, win);
+                        site = __builtin_amdgcn_readlane(q0.z, win), site2 = __builtin_amdgcn_readlane(q0.w, win);
+                        const unsigned int dlo = (unsigned int)__builtin_amdgcn_readlane(q1.x, win);
+                        const unsigned int dhi = (unsigned int)__builtin_amdgcn_readlane(q1.y, win);
+                        dE = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | dlo));
+                        s_old = __builtin_amdgcn_readlane(q1.z, win);
                         const unsigned long long later = have & (have - 1);
                         if (p2 >= NONE && later) {
-                            const int *nx = slots + CLF_SLOT_INTS * (int)__builtin_ctzll(later);
-                            p2 = nx[0], site2 = nx[2];
+                            const int nx = (int)__builtin_ctzll(later);
+                            p2 = __builtin_amdgcn_readlane(q0.x, nx), site2 = __builtin_amdgcn_readlane(q0.z, nx);
                         }
-                        p = __builtin_amdgcn_readfirstlane(p), p2 = __builtin_amdgcn_readfirstlane(p2);
-                        site = __builtin_amdgcn_readfirstlane(site), site2 = __builtin_amdgcn_readfirstlane(site2);
-                        s_old = __builtin_amdgcn_readfirstlane(s_old);
                     }
                 }
-                if (p >= NONE) break;  // the rest of the super-window is rejected
-                RowRegs cur;
-                if (nxt_pos == p) cur = nxt;
-                else cur = row_request(site);
-                nxt = row_request(p2 < NONE ? site2 : site);
-                nxt_pos = p2 < NONE ? p2 : -1;
+                if (p >= NONE) return true;  // the rest of the super-window is rejected
+                if (held_pos != p) held = row_request(site);
+                other = row_request(p2 < NONE ? site2 : site);
+                held_pos = p2 < NONE ? p2 : -1;
                 E += dE;
                 ++nacc;
-                apply_row(cur, site, -2 * sc * s_old);
+                apply_row(held, site, -2 * sc * s_old);
                 if (tid == 0) {
                     bits[site >> 5] ^= 1u << (site & 31);
                     if constexpr (!LEAN) {
@@ -385,7 +420,11 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                 }
                 pos = p + 1;
                 __syncthreads();  // (B) fields and spin of the new state are visible
-                if (pos >= CLF_WINDOW * W) break;
+                return pos >= CLF_WINDOW * W;
+            };
+            for (;;) {
+                if (round(buf0, buf1)) break;
+                if (round(buf1, buf0)) break;
             }
         }
         // sweep boundary: energy record, best tracking (annealing/gpu_annealer.py:151-153)

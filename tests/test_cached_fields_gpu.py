@@ -56,7 +56,7 @@ CLF_CASES = [
     (129, 33, "i8", 0), (300, 6, "f32", 2), (1000, 40, "f32", 0), (1000, 7, "i8", 3),
     (1100, 130, "f32", 5), (2500, 6, "f32", 0), (2500, 3, "i8", 2), (4100, 3, "i8", 0),
     (4000, 4, "f32", 16), (10000, 2, "f32", 0), (10000, 3, "i8", 0), (10000, 2, "i8", 1),
-    (10000, 2, "t2", 0),
+    (10000, 2, "t2", 0), (10000, 2, "f32", 4),  # (the last: rows longer than one batch of chunks per wave)
 ]
 
 
