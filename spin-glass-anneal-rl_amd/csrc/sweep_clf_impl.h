@@ -29,12 +29,18 @@
 // accepted site is dealt to the waves in 1-KiB chunks (chunk c -> wave c mod W), each wave updating the
 // fields under its chunks; a second barrier makes the new state visible and the candidates behind the
 // accept are evaluated again.  One row request per round: the row of the PREDICTED next accept (the second
-// accepting candidate) travels while the current accept is applied and the next round is evaluated.
+// accepting candidate) travels while the current accept is applied and the next round is evaluated; the two
+// row buffers take turns, so a predicted row is never copied or waited for before the round that uses it.
 // What must hold between the waves: nobody applies before everybody has evaluated (barrier A), nobody
 // evaluates before everybody has applied and wave 0 has flipped the spin (barrier B), and the spin at
-// the accepted site is read BEFORE barrier A (wave 0 flips it right after its own share of the row).
-// Cost: ~260 issued instructions per wave and accept + two barriers ~ 2 us; nothing per rejected
-// proposal beyond its share of an evaluation round (profiles/r03_experiments.md 1).
+// the accepted site comes from the EVALUATION (before barrier A: wave 0 flips it right after its own share
+// of the row).
+// Cost (profiles/r03_experiments.md 1, profiles/clf_cold.py): a round = one accept is a serial chain of
+// ~230 issued instructions per wave, two barriers and three dependent LDS round trips ~ 1.1 us for a
+// replica alone on its CU, ~1.7 us with four busy replicas per CU; a launch lasts as long as its replica
+// with the most accepts.  Proposals that are all rejected cost their Philox draws (18 v_mad_u64_u32 per
+// two proposals, the bound of the accept-free sweep: 25 us per 10 000-spin sweep at 4 replicas per CU =
+// 4.0e11 attempts/s).
 #pragma once
 #include <type_traits>
 
