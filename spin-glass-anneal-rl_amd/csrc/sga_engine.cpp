@@ -1604,9 +1604,16 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         // Pair look-ahead of the narrow table form: built and verified in round 3, measured -1 ... +3 % on
         // BASELINE configs[2] (same-box A/B, profiles/r03_experiments.md) -- not the default; kept behind
         // SGA_CSR_PAIR_AHEAD=1 (2: with the two wave sums interleaved) for the parity test and further A/Bs.
+        // Four updates per step (sweep_csr_rows4.hip; the launcher takes it for the production arguments of
+        // integer problems with int8 spins): every row <= 64 entries, entry offsets below 2^32 bytes.
+        // SGA_CSR_PAIR_AHEAD=0 turns it off (A/B, parity cross-check).
         a.csr_pair_ahead = 0;
-        if (e->csr && e->max_row_len <= 64 && std::getenv("SGA_CSR_PAIR_AHEAD"))
-            a.csr_pair_ahead = std::max(0, std::min(2, std::atoi(std::getenv("SGA_CSR_PAIR_AHEAD"))));
+        if (e->csr && e->max_row_len <= 64) {
+            const char *env = std::getenv("SGA_CSR_PAIR_AHEAD");
+            if (env) a.csr_pair_ahead = std::max(0, std::min(4, std::atoi(env)));
+            else if ((e->layout_entries + 64) * 8 < (1ll << 32)) a.csr_pair_ahead = 4;
+            if (a.csr_pair_ahead == 3) a.csr_pair_ahead = 0;
+        }
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
         a.cv = e->cv;

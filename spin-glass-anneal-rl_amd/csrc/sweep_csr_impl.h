@@ -740,6 +740,8 @@ inline hipError_t launch_csr_kernel(K kern, const SweepArgs &a, bool wide, bool 
     if (e != hipSuccess) return e;
     const int blocks = wide ? a.R : (a.R + waves - 1) / waves;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, st, a);
+    note_sweep_kernel("sweep_csr_kernel<acc=%d, %s, %s spins> x %d %s", a.csr_acc, wide ? "one replica per workgroup" : "narrow",
+                      big ? "bit" : "int8", waves, wide ? "wave(s)" : "replica(s) per workgroup");
     return hipGetLastError();
 }
 // the accept table is a specialisation of the production (LEAN) builds

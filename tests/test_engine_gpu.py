@@ -511,9 +511,11 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=7)
     got = {}
-    for ahead in (1, 2, 0):
-        if ahead:
-            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", str(ahead))
+    # "4" = four updates per step (sweep_csr_rows4.hip: one update per row of 16 lanes, replayed one at a time
+    # when an accepted update touches a later one of the step) -- the default where it applies (None)
+    for ahead in ("1", "2", "4", None, "0"):
+        if ahead is not None:
+            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
         else:
             monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
         with sg.AnnealEngine(0) as e:
@@ -522,11 +524,17 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
             assert "fast" in e.describe(), e.describe()
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
+            if not bits:
+                from spin_glass_anneal_rl_amd.engine import last_kernel
+                assert ("rows4" in last_kernel()) == (ahead in ("4", None)), (ahead, last_kernel())
             assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (ahead, e.describe())
             assert np.array_equal(e.spins(), s)
             assert np.array_equal(e.stats()[0], ref["n_accepted"])
+            assert np.array_equal(e.energies(), ref["energy"])
+            e.recompute_energies()
+            assert np.array_equal(e.energies(), ref["energy"])
             got[ahead] = (out["energy_trace"], e.best()[0])
-    assert np.array_equal(got[1][0], got[0][0]) and got[1][1] == got[0][1] and got[2][1] == got[0][1]
+    assert all(np.array_equal(got[k][0], got["0"][0]) and got[k][1] == got["0"][1] for k in got)
 
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
