@@ -1328,6 +1328,14 @@ static int init_replicas_body(sga_engine *e, int R_local, int R_global, int repl
             // 1.77e9 attempts/s with a quarter of the replicas resident; n = 60k, 2 per workgroup:
             // 1.17e9 vs 1.74e9); against the narrow bit form residency decides.
             if (R_local > res_i8 && res_bits > res_i8 && (narrow_bits || wide_i8 || rpb <= 2)) bits = true;
+            // ... unless the several-updates-per-step form (sweep_csr_rows.hip: int8 spins, 3-4.5 x the narrow
+            // forms) applies and at least half of the replicas are resident (3-D lattice, n = 10 648, 4096
+            // replicas: 3072 resident)
+            const char *rows_env = std::getenv("SGA_CSR_PAIR_AHEAD");
+            const bool rows_form = e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 && e->max_row_len <= 64 &&
+                                   (e->layout_entries + 64) * 8 < (1ll << 32) && !wide_i8 &&
+                                   (!rows_env || std::atoi(rows_env) >= 4);
+            if (bits && rows_form && 2 * res_i8 >= R_local) bits = false;
         }
         // Long rows with MANY replicas (C5 at 100 cities: degree 396, 2048 replicas): one wave per
         // replica either way, but the slot-addressed bit form (one replica per workgroup, scalar
@@ -1604,15 +1612,18 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         // Pair look-ahead of the narrow table form: built and verified in round 3, measured -1 ... +3 % on
         // BASELINE configs[2] (same-box A/B, profiles/r03_experiments.md) -- not the default; kept behind
         // SGA_CSR_PAIR_AHEAD=1 (2: with the two wave sums interleaved) for the parity test and further A/Bs.
-        // Four updates per step (sweep_csr_rows4.hip; the launcher takes it for the production arguments of
+        // Several updates per step (sweep_csr_rows.hip; the launcher takes it for the production arguments of
         // integer problems with int8 spins): every row <= 64 entries, entry offsets below 2^32 bytes.
-        // SGA_CSR_PAIR_AHEAD=0 turns it off (A/B, parity cross-check).
+        // SGA_CSR_PAIR_AHEAD=0 turns it off, 4 | 8 pick the rows per step (A/B, parity cross-check).
         a.csr_pair_ahead = 0;
+        a.csr_row_cap = (e->csr && e->max_row_len <= 64) ? (int)std::max<long long>(e->max_row_len, 1) : 0;
         if (e->csr && e->max_row_len <= 64) {
             const char *env = std::getenv("SGA_CSR_PAIR_AHEAD");
-            if (env) a.csr_pair_ahead = std::max(0, std::min(4, std::atoi(env)));
-            else if ((e->layout_entries + 64) * 8 < (1ll << 32)) a.csr_pair_ahead = 4;
-            if (a.csr_pair_ahead == 3) a.csr_pair_ahead = 0;
+            if (env) a.csr_pair_ahead = std::max(0, std::min(8, std::atoi(env)));
+            else a.csr_pair_ahead = e->max_row_len <= 32 ? 8 : 4;  // (profiles/r03_experiments.md: C3, rows of up to 50 entries,
+                // 1.0e10 | 2.67e10 | 2.44e10 attempts/s for 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 4.9e10)
+            if (a.csr_pair_ahead != 1 && a.csr_pair_ahead != 2 && a.csr_pair_ahead != 4 && a.csr_pair_ahead != 8) a.csr_pair_ahead = 0;
+            if (a.csr_pair_ahead >= 4 && (e->layout_entries + 64) * 8 >= (1ll << 32)) a.csr_pair_ahead = 0;
         }
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;

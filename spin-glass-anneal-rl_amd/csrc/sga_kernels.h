@@ -70,7 +70,8 @@ struct SweepArgs {
     int csr_acc;         // CSR: one of CSR_ACC_* (how a row sum is formed)
     int csr_head;        // CSR wide bit forms: head slots per wave the longest row needs (0: eight)
     int csr_pair_ahead;  // CSR narrow table form, every row <= 64 entries: 1 | 2 = the two updates of a pair reduced together
-                         // (opt-in), 4 = four updates per step, one per row of 16 lanes (sweep_csr_rows4.hip)
+                         // (opt-in), 4 | 8 = that many updates per step, one per row of 16 | 8 lanes (sweep_csr_rows.hip)
+    int csr_row_cap;     // CSR: entries of the longest row when that is <= 64 (else 0): sweep_csr_rows.hip picks its build by it
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     // cached-local-field sweep (sweep_clf_impl.h): resident fields F = field_scale * (J s + h)
@@ -178,8 +179,8 @@ hipError_t launch_sweep_dense_t2(const SweepArgs &a, int waves, int cpw, hipStre
 hipError_t launch_repack_tern2(const float *J, long long ldJ, int n, unsigned int *planes,
                                long long row_bits, float *row_nnz, hipStream_t st);
 hipError_t launch_sweep_csr(const SweepArgs &a, int waves_per_replica, hipStream_t st);
-bool sweep_csr_rows4_applies(const SweepArgs &a);  // sweep_csr_rows4.hip: four updates per step
-hipError_t launch_sweep_csr_rows4(const SweepArgs &a, int waves_per_block, hipStream_t st);
+bool sweep_csr_rows_applies(const SweepArgs &a);  // sweep_csr_rows.hip: four | eight updates per step
+hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st);
 hipError_t launch_sweep_wolff(const SweepArgs &a, const WolffArgs &wa, bool csr, bool j_is_i8, hipStream_t st);
 hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st);
 hipError_t launch_energy_tsp(const EnergyArgs &a, const TspArgs &t, hipStream_t st);

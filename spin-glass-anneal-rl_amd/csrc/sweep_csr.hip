@@ -47,14 +47,14 @@ static hipError_t launch_csr_narrow(const SweepArgs &a, int waves, hipStream_t s
 // > 1: one replica per workgroup, its rows dealt to that many waves (1, 2, 4 or 8: the engine rounds
 // up).  a.big: the bit-spin forms -- 2 = narrow, 1 = one replica per workgroup (1..8 waves).
 hipError_t launch_sweep_csr(const SweepArgs &a0, int waves_per_replica, hipStream_t st) {
-    // four updates per step (sweep_csr_rows4.hip): its own kernel; every other form reads 4 as "off"
-    if (waves_per_replica == 1 && sweep_csr_rows4_applies(a0)) {
+    // four | eight updates per step (sweep_csr_rows.hip): its own kernel; every other form reads 4 | 8 as "off"
+    if (waves_per_replica == 1 && sweep_csr_rows_applies(a0)) {
         const int wpb = csr_waves_per_block(a0.sstride, a0.table_m);
         if (wpb < 1) return hipErrorInvalidValue;
-        return launch_sweep_csr_rows4(a0, wpb, st);
+        return launch_sweep_csr_rows(a0, wpb, st);
     }
     SweepArgs a = a0;
-    if (a.csr_pair_ahead == 4) a.csr_pair_ahead = 0;
+    if (a.csr_pair_ahead >= 4) a.csr_pair_ahead = 0;
     if (a.big) {
         if (waves_per_replica < 1 || waves_per_replica > CSR_MAX_WIDE || !csr_big_fits(a.sstride, a.table_m))
             return hipErrorInvalidValue;

@@ -1,4 +1,4 @@
-// sweep_csr_rows4.hip -- narrow CSR sweep, FOUR UPDATES PER STEP: BASELINE configs[2] (10 000 spins,
+// sweep_csr_rows.hip -- narrow CSR sweep, SEVERAL UPDATES PER STEP: BASELINE configs[2] (10 000 spins,
 // degree ~32, 4096 replicas) in the production configuration (integer couplings and fields, Philox sites,
 // Metropolis with the accept table, int8 spins in LDS).
 //
@@ -7,26 +7,36 @@
 //
 // The one-update-at-a-time form (sweep_csr_impl.h) spends ~65 instructions of one wave on every update and
 // uses 32 of its 64 lanes at degree 32; it is bound by instruction issue and its dependent chain, not by
-// memory (the 2.6 MB structure is L2 resident).  Here a wave works on the four consecutive updates
-// t = 4m .. 4m + 3 at once, one per ROW of 16 lanes (lane j of a row holds entries 4j .. 4j + 3 of the
-// row's coupling row: rows of up to 64 entries), every row sum against the spins as they stand before
-// the first of the four:
+// memory (the 2.6 MB structure is L2 resident).  Here a wave works on the G consecutive updates
+// t = G m .. G m + G - 1 at once (G = 4 | 8), one per ROW of 64 / G lanes (lane j of a row holds entries
+// E j .. E j + E - 1 of the row's coupling row, E = G: rows of up to 64 entries), every row sum against the
+// spins as they stand before the first of the G:
 //   * sparse couplings make that exact almost always: flipping site A changes the local field of B only
-//     if J[B][A] != 0, and B's own spin only if B == A.  The four decisions are formed together, then
+//     if J[B][A] != 0, and B's own spin only if B == A.  The G decisions are formed together, then
 //     checked in chain order: for every accepted update the later rows look for its site among their
-//     columns (and their own site) -- one compare per entry and a ballot.  No hit (99 % of the steps at
-//     degree 32 of 10 000): all four decisions are the chain's.  A hit: the step is replayed one update
+//     columns (and their own site) -- one compare per entry and a ballot.  No hit (98-99 % of the steps at
+//     degree 32 of 10 000): all G decisions are the chain's.  A hit: the step is replayed one update
 //     at a time (same data, already in registers).
 //   * everything is an integer below 2^24 (the table form's precondition), so row sums, dE and the
 //     energy are exact in any order: E += the sum of the accepted dE of the step.
-// Per step: 4 x 16 row entries in two loads per lane, 4 LDS spin gathers per lane, a 4-step DPP row sum
-// (all four rows in the same instructions), one table look-up; sites, row extents and row entries are
-// requested two / one steps ahead (the site sequence is known from the counter RNG).
+// Per step: the row entries in E / 2 16-byte loads per lane, E LDS spin gathers per lane, a DPP row sum (all
+// rows in the same instructions), one table look-up.  Sites and uniforms of 128 updates come from one
+// vectorised Philox pass (lane l: block l), re-laid so that lane i holds update i (ds_bpermute); a step
+// picks its G updates with one more permute each.  Sites, row extents and row entries are requested
+// two / one steps ahead (the site sequence is known from the counter RNG).
 #include "sweep_csr_impl.h"
 
 namespace sga {
 
-__global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kernel(const SweepArgs a) {
+// (One replica per workgroup -- the spin slice at LDS address 0, a gather taking the column as its address --
+// measured SLOWER: C3 2.10 vs 1.53 ms per sweep at four updates per step.)
+// EPL = entries per lane: a row of the wave covers coupling rows of up to (64 / G) * EPL entries; the engine
+// picks the smallest build that covers the problem's longest row (a slot that can never hold an entry costs as
+// much as one that does): lattices and other low-degree graphs run with one entry per lane.
+template <int G, int EPL>
+__global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kernel(const SweepArgs a) {
+    constexpr int LPR = 64 / G;   // lanes per row
+    static_assert((G == 4 || G == 8) && LPR * EPL <= 64, "rows of 16 or 8 lanes, coupling rows of up to 64 entries");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,12 +53,11 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
         int4 *dst = reinterpret_cast<int4 *>(s);
         for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
     }
-    const int g = lane >> 4, j = lane & 15;  // row of the wave = update of the step, lane in the row
+    const int g = lane / LPR, j = lane % LPR;  // row of the wave = update of the step, lane in the row
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
     double T = 1.0;
-    const int nb = (n + 1) >> 1;     // Philox pairs per sweep
-    const int steps = (n + 3) >> 2;  // steps per sweep (the last one may hold fewer than four updates)
+    const int steps = (n + G - 1) / G;  // steps per sweep (the last one may hold fewer than G updates)
 
     struct Step {
         int site;       // this row's site
@@ -56,20 +65,36 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
         int live;       // the update exists (t < n, sweep < n_sweeps)
         int beg, end;   // row extent
         float h;
-        int2 e[4];      // entries beg + 4 j + q
+        int2 e[EPL];    // entries beg + EPL j + q
     };
-    PairSource<true> rng;
-    // the sites of step m of sweep k (valid: the sweep exists; past the end every row is dead, site 0)
+    // 128 consecutive updates of a sweep: lane i holds update 128 W + i (lo) and 128 W + 64 + i (hi)
+    int ws_lo = 0, ws_hi = 0, wu_lo = 0, wu_hi = 0;
+    auto permute = [&](int from_lane, int v) -> int { return __builtin_amdgcn_ds_bpermute(from_lane << 2, v); };
+    auto refill = [&](int k, int window) {
+        // the stream of sweep_common.h: block b serves updates 2 b (words x, y) and 2 b + 1 (words z, w)
+        const u32x4 x = philox4x32_10((uint32_t)(64 * window + lane), a.sweep0 + (uint32_t)k, a.replica0 + (uint32_t)r,
+                                      DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+        const int sA = (int)word_to_site(x.x, (uint32_t)n), sB = (int)word_to_site(x.z, (uint32_t)n);
+        const int uA = (int)(x.y >> 8), uB = (int)(x.w >> 8);
+        const bool odd = lane & 1;
+        const int lo = lane >> 1, hi = 32 + (lane >> 1);
+        const int a0 = permute(lo, sA), b0 = permute(lo, sB), a1 = permute(hi, sA), b1 = permute(hi, sB);
+        const int c0 = permute(lo, uA), d0 = permute(lo, uB), c1 = permute(hi, uA), d1 = permute(hi, uB);
+        ws_lo = odd ? b0 : a0;
+        ws_hi = odd ? b1 : a1;
+        wu_lo = odd ? d0 : c0;
+        wu_hi = odd ? d1 : c1;
+    };
+    // the sites of step m of sweep k (past the last sweep every row is dead, site 0)
     auto stage_sites = [&](Step &st, int k, int m) {
-        const bool valid = k < a.n_sweeps;
-        const int b0 = 2 * m, b1 = 2 * m + 1;
-        const UpdatePair p0 = rng.get(a, r, k, b0, valid && b0 < nb, lane);
-        const UpdatePair p1 = rng.get(a, r, k, b1, valid && b1 < nb, lane);
-        const int sa = (g & 2) ? p1.sA : p0.sA, sb = (g & 2) ? p1.sB : p0.sB;
-        const uint32_t ra = (g & 2) ? p1.rA : p0.rA, rb = (g & 2) ? p1.rB : p0.rB;
-        st.live = (valid && 4 * m + g < n) ? 1 : 0;
-        st.site = st.live ? ((g & 1) ? sb : sa) : 0;
-        st.ru = (g & 1) ? rb : ra;
+        const bool valid = k < a.n_sweeps;  // wave-uniform
+        const int t0 = G * m, p = t0 & 127;
+        if (valid && p == 0) refill(k, t0 >> 7);
+        const int from = (p & 63) + g;
+        const int sv = permute(from, p < 64 ? ws_lo : ws_hi), uv = permute(from, p < 64 ? wu_lo : wu_hi);
+        st.live = (valid && t0 + g < n) ? 1 : 0;
+        st.site = st.live ? sv : 0;
+        st.ru = (uint32_t)uv;
     };
     // scalar base + 32-bit lane offset: the scalar-base form of global_load (as in sweep_csr_impl.h)
     auto stage_extents = [&](Step &st) {
@@ -82,29 +107,29 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
     };
     auto stage_heads = [&](Step &st) {
         // (64 zeroed entries follow the array: lanes past the row's end read what lies behind it)
-        unsigned int off = (unsigned int)(st.beg + 4 * j) * 8u;
+        unsigned int off = (unsigned int)(st.beg + EPL * j) * 8u;
         asm volatile("" : "+v"(off));
         const unsigned char *cv = reinterpret_cast<const unsigned char *>(a.cv);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st.e[q] = *reinterpret_cast<const int2 *>(cv + off + 8 * q);
+        for (int q = 0; q < EPL; ++q) st.e[q] = *reinterpret_cast<const int2 *>(cv + off + 8 * q);
     };
-    // sum over the 16 lanes of a row, in every lane of the row (exact: integers below 2^24)
+    // sum over the lanes of a row, in every lane of the row (exact: integers below 2^24)
     auto row_sum = [&](float v) -> float {
         v += dpp_move<DPP_QUAD_XOR1>(v);
         v += dpp_move<DPP_QUAD_XOR2>(v);
         v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
-        v += dpp_move<DPP_ROW_MIRROR>(v);
+        if constexpr (LPR == 16) v += dpp_move<DPP_ROW_MIRROR>(v);
         return v;
     };
     // this row's decision against the spins as they stand: flips?, fk = s_i (row sum + h)
     auto decide = [&](const Step &st, int &si, float &fk) -> bool {
-        const int left = st.end - st.beg - 4 * j;  // entries of the row from this lane's first on
+        const int left = st.end - st.beg - EPL * j;  // entries of the row from this lane's first on
         si = s[st.site];
-        float dot = 0.0f;
+        float dot = (0 < left ? __int_as_float(st.e[0].y) : 0.0f) * (float)s[st.e[0].x];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 1; q < EPL; ++q) {
             const float v = q < left ? __int_as_float(st.e[q].y) : 0.0f;
-            dot += v * (float)s[st.e[q].x];
+            dot = __builtin_fmaf(v, (float)s[st.e[q].x], dot);  // (exact either way: small integers)
         }
         dot = row_sum(dot);
         // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2 fk exactly (half-integer
@@ -120,23 +145,23 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
         }
         return st.live != 0 && flip;
     };
+    constexpr unsigned long long HEADS = G == 4 ? 0x0001000100010001ull : 0x0101010101010101ull;  // lane 0 of every row
     auto step = [&](const Step &st) {
         int si;
         float fk;
         const bool flip = decide(st, si, fk);
-        const unsigned long long heads = 0x0001000100010001ull;  // lane 0 of every row
-        const unsigned long long acc = __ballot(flip) & heads;
-        // does an accepted update touch a LATER one of the step?  (its site among their columns or their sites)
+        const unsigned long long acc = __ballot(flip) & HEADS;
+        // does an accepted update touch a LATER one of the step?  (its site among their columns or their
+        // sites; entries past a row's end take part -- a stray hit costs a replay, nothing else)
         unsigned long long hit = 0;
-        if (acc & 0x0000000100010001ull) {  // (an accept in the last row touches nobody)
-            const int left = st.end - st.beg - 4 * j;
+        if (acc & (HEADS >> LPR)) {  // (an accept in the last row touches nobody)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if ((acc >> (16 * q)) & 1ull) {  // wave-uniform
-                    const int sq = __builtin_amdgcn_readlane(st.site, 16 * q);
+            for (int q = 0; q + 1 < G; ++q) {
+                if ((acc >> (LPR * q)) & 1ull) {  // wave-uniform
+                    const int sq = __builtin_amdgcn_readlane(st.site, LPR * q);
                     bool mine = st.site == sq;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) mine = mine || (x < left && st.e[x].x == sq);
+                    for (int x = 0; x < EPL; ++x) mine = mine || st.e[x].x == sq;
                     hit |= __ballot(mine && st.live != 0 && g > q);
                 }
             }
@@ -145,17 +170,14 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
             if (acc) {
                 if (flip && j == 0) s[st.site] = (int8_t)(-si);
                 asm volatile("" ::: "memory");  // (the next step's gathers are reloads as well)
-                float tot = flip ? 2.0f * fk : 0.0f;  // the same in every lane of a row
-                tot += dpp_move<DPP_ROW_BCAST15, 0xa>(tot);
-                tot += dpp_move<DPP_ROW_BCAST31, 0xc>(tot);
-                E += (double)read_lane(tot, 63);
+                E += (double)wave_sum((flip && j == 0) ? 2.0f * fk : 0.0f);
                 nacc += (unsigned long long)__builtin_popcountll(acc);
             }
             return;
         }
         // one update at a time: the row's decision against the spins as the earlier rows left them
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < G; ++q) {
             // The spins are re-read from LDS in every pass: another LANE may have flipped one in the pass before.
             // (To the compiler a lane is a thread of its own and this a plain reload of what it just read --
             // it forwarded the old values, and two accepted updates at ONE site of a step went wrong.  LDS
@@ -164,9 +186,9 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
             int si2;
             float fk2;
             const bool flip2 = decide(st, si2, fk2);
-            if ((__ballot(flip2) >> (16 * q)) & 1ull) {
-                if (lane == 16 * q) s[st.site] = (int8_t)(-si2);
-                E += (double)(2.0f * read_lane(fk2, 16 * q));
+            if ((__ballot(flip2) >> (LPR * q)) & 1ull) {
+                if (lane == LPR * q) s[st.site] = (int8_t)(-si2);
+                E += (double)(2.0f * read_lane(fk2, LPR * q));
                 ++nacc;
             }
         }
@@ -239,14 +261,28 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows4_kern
 
 // the form applies to: production arguments with the accept table, int8 spins, 32-bit row extents whose
 // byte offsets fit 32 bits (the engine checks the row lengths: every row <= 64 entries)
-bool sweep_csr_rows4_applies(const SweepArgs &a) {
+bool sweep_csr_rows_applies(const SweepArgs &a) {
     const bool lean = csr_args_are_lean(a);
-    return a.csr_pair_ahead == 4 && !a.big && a.rowptr && lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE;
+    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 && !a.big && a.rowptr &&
+           lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE;
 }
 
-hipError_t launch_sweep_csr_rows4(const SweepArgs &a, int waves_per_block, hipStream_t st) {
-    const hipError_t e = launch_csr_kernel(sweep_csr_rows4_kernel, a, false, false, waves_per_block, st);
-    note_sweep_kernel("sweep_csr_rows4_kernel x %d replica(s) per workgroup", waves_per_block);
+// a.csr_row_cap = entries of the problem's longest row (<= 64)
+hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
+    const int cap = a.csr_row_cap;
+    void (*kern)(const SweepArgs) = nullptr;
+    int g = 4, epl = 4;
+    if (a.csr_pair_ahead == 8) {  // rows of 8 lanes
+        g = 8;
+        epl = cap <= 8 ? 1 : cap <= 16 ? 2 : cap <= 32 ? 4 : 8;
+        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1> : epl == 2 ? sweep_csr_rows_kernel<8, 2>
+             : epl == 4 ? sweep_csr_rows_kernel<8, 4> : sweep_csr_rows_kernel<8, 8>;
+    } else {                      // rows of 16 lanes
+        epl = cap <= 16 ? 1 : cap <= 32 ? 2 : 4;
+        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1> : epl == 2 ? sweep_csr_rows_kernel<4, 2> : sweep_csr_rows_kernel<4, 4>;
+    }
+    const hipError_t e = launch_csr_kernel(kern, a, false, false, waves_per_block, st);
+    note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane> x %d replica(s) per workgroup", g, epl, waves_per_block);
     return e;
 }
 

@@ -474,6 +474,8 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
     (65, 64, 1, False, False),    # rows of exactly 64 entries
     (1000, 32, 1, False, False),  # the C3 shape
     (301, 9, 5, True, True),
+    (400, 6, 1, False, False),    # lattice-like degree: one entry per lane in the several-updates-per-step builds
+    (120, 30, 2, False, False),   # rows of 17..32 entries
 ])
 def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h, dups, bits, monkeypatch):
     """Narrow table form (integer problems, rows of <= 64 entries): the two updates of a Philox pair are
@@ -511,9 +513,9 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=7)
     got = {}
-    # "4" = four updates per step (sweep_csr_rows4.hip: one update per row of 16 lanes, replayed one at a time
-    # when an accepted update touches a later one of the step) -- the default where it applies (None)
-    for ahead in ("1", "2", "4", None, "0"):
+    # "4" | "8" = that many updates per step (sweep_csr_rows.hip: one update per row of 16 | 8 lanes, replayed one
+    # at a time when an accepted update touches a later one of the step) -- the default where it applies (None)
+    for ahead in ("1", "2", "4", "8", None, "0"):
         if ahead is not None:
             monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
         else:
@@ -526,7 +528,7 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
             out = e.sweep(ns, energy_trace=True)
             if not bits:
                 from spin_glass_anneal_rl_amd.engine import last_kernel
-                assert ("rows4" in last_kernel()) == (ahead in ("4", None)), (ahead, last_kernel())
+                assert ("sweep_csr_rows_kernel" in last_kernel()) == (ahead in ("4", "8", None)), (ahead, last_kernel())
             assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (ahead, e.describe())
             assert np.array_equal(e.spins(), s)
             assert np.array_equal(e.stats()[0], ref["n_accepted"])
