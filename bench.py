@@ -482,6 +482,8 @@ def main():
     elif a.workload == "c5" and (a.cities, R) in ((100, 2048), (1000, 256)):
         pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
     kernel_name = "sweep_tsp_kernel" if implicit else ("sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
+    if kernel_inst.startswith("sweep_csr_rows_kernel"):  # several updates per step (short integer rows: C3)
+        kernel_name = "sweep_csr_rows_kernel"
     if implicit:
         pmc_tag = f"c5_{a.cities}_implicit"
     traffic, traffic_src = pmc_traffic(pmc_tag, kernel_name)
@@ -542,8 +544,10 @@ def main():
         nbytes = float(len(csr[1])) * 8.0
         out["roofline"]["note"] = (
             f"CSR structure = {nbytes / 1e6:.0f} MB: " +
-            ("cache resident (PMC traffic far below the algorithmic bytes): the sweep is paced by the dependent "
-             "chain of one update, not by HBM" if nbytes < 2.0e8 else
+            ("cache resident (PMC traffic far below the algorithmic bytes): the sweep is paced by " +
+             ("vector-instruction issue (several updates per step, one per row of lanes: sweep_csr_rows.hip), not by HBM"
+              if kernel_name == "sweep_csr_rows_kernel" else "the dependent chain of one update, not by HBM")
+             if nbytes < 2.0e8 else
              "streamed from HBM (up to 256 MB partly re-served by the Infinity Cache); bandwidth bound, "
              "DESIGN.md 4.2"))
     elif a.workload == "c2a" and not implicit:

@@ -2,6 +2,7 @@
 # Round-3 rocprofv3 passes (run on the GPU box through gpurun; summaries via summarize_rocprof.py).
 #   headline  bench.py C2a fp32 with --waves = the autotuner's pick ON THIS BOX (read from a first plain
 #             run), so that the traced instantiation is the timed one; stats + FETCH_SIZE + WRITE_SIZE
+#   c3        bench.py --workload c3 (CSR, degree ~32, 4096 replicas)
 #   cached    the cached-local-field variant on the same instance (profiles/clf_profile_run.py)
 #   energy    the all-replica field pass: C2 fp32 / int8, n = 32768 fp32, and the per-replica kernel (A/B)
 # One counter per --pmc pass, never with other trace domains; the program comes directly after `--`.
@@ -31,6 +32,8 @@ for t in "$@"; do
       echo "autotuner's pick on this box: $W waves per replica"
       passes c2a_f32 "bench.py --waves $W --no-variants --no-cpu-baseline (the autotuner's pick on this box)" \
              python3 bench.py --waves $W --no-variants --no-cpu-baseline ;;
+    c3) passes c3_csr "bench.py --workload c3 --no-cpu-baseline (several updates per step: sweep_csr_rows_kernel)" \
+               python3 bench.py --workload c3 --no-cpu-baseline ;;
     cached) passes c2a_cached "profiles/clf_profile_run.py (3 + 20 sweeps, exchange every 10)" python3 profiles/clf_profile_run.py ;;
     energy)
       N=10000 STORAGE=f32 passes energy_c2_f32 "profiles/energy_profile_run.py N=10000 f32" python3 profiles/energy_profile_run.py

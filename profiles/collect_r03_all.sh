@@ -12,4 +12,4 @@ b c5_1000_csr --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1
 b c5_implicit --workload c5 --implicit
 b c5_1000_implicit --workload c5 --implicit --cities 1000 --replicas 256 --steps 2 --warmup 1
 # the headline profile is taken at the geometry the committed headline line ran (its autotuner's pick)
-PICK_FROM=gpurun_out/r03_bench_c2a_f32.json timeout -k 10 900 bash profiles/collect_r03.sh headline cached energy > gpurun_out/r03_collect_all.log 2>&1; echo "collect rc=$?"
+PICK_FROM=gpurun_out/r03_bench_c2a_f32.json timeout -k 10 900 bash profiles/collect_r03.sh headline c3 cached energy > gpurun_out/r03_collect_all.log 2>&1; echo "collect rc=$?"

@@ -52,8 +52,8 @@ while time.time() < t_end:
     cache = str(rng.choice(["off", "auto", "auto"]))
     if cache == "auto" and rng.rand() < 0.6:
         env["SGA_CLF_WAVES"] = str(rng.choice([1, 2, 3, 4, 8]))
-    if kind == "csr" and rng.rand() < 0.3:
-        env["SGA_CSR_PAIR_AHEAD"] = str(rng.choice([1, 2]))
+    if kind == "csr" and rng.rand() < 0.5:  # (unset: several updates per step wherever the form applies)
+        env["SGA_CSR_PAIR_AHEAD"] = str(rng.choice([0, 1, 2, 4, 8]))
     seed = int(rng.randint(1, 1 << 30))
     temps = np.geomspace(3.0 * max(1.0, np.sqrt(n)), 0.2, R) if R > 1 else np.asarray([1.5])
     mode = str(rng.choice(["plain", "plain", "rules", "pt", "batch", "tsp", "wolff"]))

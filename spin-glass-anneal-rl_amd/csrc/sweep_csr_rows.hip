@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
     double T = 1.0;
+    int dE_lane = 0;  // this lane's share of the sweep's energy change (integer; see step())
     const int steps = (n + G - 1) / G;  // steps per sweep (the last one may hold fewer than G updates)
 
     struct Step {
@@ -170,7 +171,9 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             if (acc) {
                 if (flip && j == 0) s[st.site] = (int8_t)(-si);
                 asm volatile("" ::: "memory");  // (the next step's gathers are reloads as well)
-                E += (double)wave_sum((flip && j == 0) ? 2.0f * fk : 0.0f);
+                // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
+                // at the end of the sweep (exact in any order; a wave sum per step cost ~14 instructions)
+                dE_lane += (flip && j == 0) ? (int)(2.0f * fk) : 0;
                 nacc += (unsigned long long)__builtin_popcountll(acc);
             }
             return;
@@ -239,6 +242,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             S1 = S2;
             S2 = t;
         }
+        E += (double)wave_sum(dE_lane);  // |sum| < 2^31: sweep_csr_rows_applies
+        dE_lane = 0;
         if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
@@ -263,8 +268,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
 // byte offsets fit 32 bits (the engine checks the row lengths: every row <= 64 entries)
 bool sweep_csr_rows_applies(const SweepArgs &a) {
     const bool lean = csr_args_are_lean(a);
+    // (the energy change of a sweep is summed in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m, where
+    //  table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale)
     return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 && !a.big && a.rowptr &&
-           lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE;
+           lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE && a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
 }
 
 // a.csr_row_cap = entries of the problem's longest row (<= 64)
