@@ -1328,14 +1328,8 @@ static int init_replicas_body(sga_engine *e, int R_local, int R_global, int repl
             // 1.77e9 attempts/s with a quarter of the replicas resident; n = 60k, 2 per workgroup:
             // 1.17e9 vs 1.74e9); against the narrow bit form residency decides.
             if (R_local > res_i8 && res_bits > res_i8 && (narrow_bits || wide_i8 || rpb <= 2)) bits = true;
-            // ... unless the several-updates-per-step form (sweep_csr_rows.hip: int8 spins, 3-4.5 x the narrow
-            // forms) applies and at least half of the replicas are resident (3-D lattice, n = 10 648, 4096
-            // replicas: 3072 resident)
-            const char *rows_env = std::getenv("SGA_CSR_PAIR_AHEAD");
-            const bool rows_form = e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 && e->max_row_len <= 64 &&
-                                   (e->layout_entries + 64) * 8 < (1ll << 32) && !wide_i8 &&
-                                   (!rows_env || std::atoi(rows_env) >= 4);
-            if (bits && rows_form && 2 * res_i8 >= R_local) bits = false;
+            // (the several-updates-per-step form, sweep_csr_rows.hip, runs on either: 3-D lattice, n = 10 648, 4096
+            //  replicas: 3.55e10 attempts/s on int8 spins with 3072 replicas resident, 5.5e10 on bits with all)
         }
         // Long rows with MANY replicas (C5 at 100 cities: degree 396, 2048 replicas): one wave per
         // replica either way, but the slot-addressed bit form (one replica per workgroup, scalar

@@ -49,7 +49,7 @@ static hipError_t launch_csr_narrow(const SweepArgs &a, int waves, hipStream_t s
 hipError_t launch_sweep_csr(const SweepArgs &a0, int waves_per_replica, hipStream_t st) {
     // four | eight updates per step (sweep_csr_rows.hip): its own kernel; every other form reads 4 | 8 as "off"
     if (waves_per_replica == 1 && sweep_csr_rows_applies(a0)) {
-        const int wpb = csr_waves_per_block(a0.sstride, a0.table_m);
+        const int wpb = a0.big ? csr_bits_waves_per_block(a0.sstride, a0.table_m) : csr_waves_per_block(a0.sstride, a0.table_m);
         if (wpb < 1) return hipErrorInvalidValue;
         return launch_sweep_csr_rows(a0, wpb, st);
     }

@@ -33,7 +33,9 @@ namespace sga {
 // EPL = entries per lane: a row of the wave covers coupling rows of up to (64 / G) * EPL entries; the engine
 // picks the smallest build that covers the problem's longest row (a slot that can never hold an entry costs as
 // much as one that does): lattices and other low-degree graphs run with one entry per lane.
-template <int G, int EPL>
+// BIG: the replica's spins as one bit each in LDS (1 = down), for problems whose int8 spins would not fit or
+// would leave few replicas resident -- the narrow bit-spin form's layout (a.big == 2).
+template <int G, int EPL, bool BIG>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kernel(const SweepArgs a) {
     constexpr int LPR = 64 / G;   // lanes per row
     static_assert((G == 4 || G == 8) && LPR * EPL <= 64, "rows of 16 or 8 lanes, coupling rows of up to 64 entries");
@@ -46,13 +48,38 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     if (r >= a.R) return;  // wave-uniform; no barriers in this kernel
     const int n = a.n;
     // LDS as in the narrow form of sweep_csr_kernel: [nw] spin slices, then [nw] accept tables
-    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)w * a.sstride;
-    unsigned int *itab = reinterpret_cast<unsigned int *>(smem + (long long)nw * a.sstride) + (long long)w * (a.table_m + 1);
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
-        int4 *dst = reinterpret_cast<int4 *>(s);
-        for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
-    }
+    const long long sbytes = BIG ? a.sstride / 8 : a.sstride;  // LDS bytes of one replica's spins
+    int8_t *s = reinterpret_cast<int8_t *>(smem) + (long long)w * sbytes;
+    unsigned int *sbits = reinterpret_cast<unsigned int *>(smem + (long long)w * sbytes);
+    unsigned int *itab = reinterpret_cast<unsigned int *>(smem + (long long)nw * sbytes) + (long long)w * (a.table_m + 1);
+    auto load_spins = [&]() {
+        if constexpr (BIG) {
+            spins_to_bits(a.spins + (long long)r * a.sstride, sbits, a.sstride, lane, 64);
+        } else {
+            const int4 *src = reinterpret_cast<const int4 *>(a.spins + (long long)r * a.sstride);
+            int4 *dst = reinterpret_cast<int4 *>(s);
+            for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+        }
+    };
+    auto store_spins = [&](int8_t *dst_row) {
+        if constexpr (BIG) {
+            bits_to_spins(sbits, dst_row, a.sstride, n, lane, 64);
+        } else {
+            int4 *dst = reinterpret_cast<int4 *>(dst_row);
+            const int4 *src = reinterpret_cast<const int4 *>(s);
+            for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+        }
+    };
+    load_spins();
+    // spin at a site; value * spin of a column (bit spins: the spin bit XORed into the value's sign bit)
+    auto spin_at = [&](int c) -> int {
+        if constexpr (BIG) return ((sbits[c >> 5] >> (c & 31)) & 1u) ? -1 : 1;
+        else return s[c];
+    };
+    auto flip_at = [&](int c, int si_old) {  // one lane per site (distinct sites; words may be shared)
+        if constexpr (BIG) atomicXor(&sbits[c >> 5], 1u << (c & 31));
+        else s[c] = (int8_t)(-si_old);
+    };
     const int g = lane / LPR, j = lane % LPR;  // row of the wave = update of the step, lane in the row
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
@@ -125,12 +152,24 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     // this row's decision against the spins as they stand: flips?, fk = s_i (row sum + h)
     auto decide = [&](const Step &st, int &si, float &fk) -> bool {
         const int left = st.end - st.beg - EPL * j;  // entries of the row from this lane's first on
-        si = s[st.site];
-        float dot = (0 < left ? __int_as_float(st.e[0].y) : 0.0f) * (float)s[st.e[0].x];
+        si = spin_at(st.site);
+        float dot;
+        if constexpr (BIG) {
+            auto term = [&](int q) -> float {
+                const int c = st.e[q].x;
+                const unsigned int sign = (sbits[c >> 5] >> (c & 31)) << 31;
+                return __int_as_float((q < left ? st.e[q].y : 0) ^ (int)sign);
+            };
+            dot = term(0);
 #pragma unroll
-        for (int q = 1; q < EPL; ++q) {
-            const float v = q < left ? __int_as_float(st.e[q].y) : 0.0f;
-            dot = __builtin_fmaf(v, (float)s[st.e[q].x], dot);  // (exact either way: small integers)
+            for (int q = 1; q < EPL; ++q) dot += term(q);
+        } else {
+            dot = (0 < left ? __int_as_float(st.e[0].y) : 0.0f) * (float)s[st.e[0].x];
+#pragma unroll
+            for (int q = 1; q < EPL; ++q) {
+                const float v = q < left ? __int_as_float(st.e[q].y) : 0.0f;
+                dot = __builtin_fmaf(v, (float)s[st.e[q].x], dot);  // (exact either way: small integers)
+            }
         }
         dot = row_sum(dot);
         // core/spin_dynamics.py:131-152 with every quantity an integer: dE = 2 fk exactly (half-integer
@@ -169,7 +208,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         }
         if (hit == 0ull) {
             if (acc) {
-                if (flip && j == 0) s[st.site] = (int8_t)(-si);
+                if (flip && j == 0) flip_at(st.site, si);
                 asm volatile("" ::: "memory");  // (the next step's gathers are reloads as well)
                 // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
                 // at the end of the sweep (exact in any order; a wave sum per step cost ~14 instructions)
@@ -190,7 +229,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             float fk2;
             const bool flip2 = decide(st, si2, fk2);
             if ((__ballot(flip2) >> (LPR * q)) & 1ull) {
-                if (lane == LPR * q) s[st.site] = (int8_t)(-si2);
+                if (lane == LPR * q) flip_at(st.site, si2);
                 E += (double)(2.0f * read_lane(fk2, LPR * q));
                 ++nacc;
             }
@@ -247,16 +286,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
-            int4 *dst = reinterpret_cast<int4 *>(a.best_spins + (long long)r * a.sstride);
-            const int4 *src = reinterpret_cast<const int4 *>(s);
-            for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
+            store_spins(a.best_spins + (long long)r * a.sstride);
         }
     }
-    {
-        int4 *dst = reinterpret_cast<int4 *>(a.spins + (long long)r * a.sstride);
-        const int4 *src = reinterpret_cast<const int4 *>(s);
-        for (int i = lane; i < a.sstride / 16; i += 64) dst[i] = src[i];
-    }
+    store_spins(a.spins + (long long)r * a.sstride);
     if (lane == 0) {
         a.energy[r] = E;
         a.best_energy[r] = bestE;
@@ -270,27 +303,34 @@ bool sweep_csr_rows_applies(const SweepArgs &a) {
     const bool lean = csr_args_are_lean(a);
     // (the energy change of a sweep is summed in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m, where
     //  table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale)
-    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 && !a.big && a.rowptr &&
-           lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE && a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
+    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
+           (a.big == 0 || a.big == 2) && a.rowptr && lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE &&
+           a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
 }
 
-// a.csr_row_cap = entries of the problem's longest row (<= 64)
-hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
-    const int cap = a.csr_row_cap;
+template <bool BIG>
+static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
+    const int cap = a.csr_row_cap;  // entries of the problem's longest row (<= 64)
     void (*kern)(const SweepArgs) = nullptr;
     int g = 4, epl = 4;
     if (a.csr_pair_ahead == 8) {  // rows of 8 lanes
         g = 8;
         epl = cap <= 8 ? 1 : cap <= 16 ? 2 : cap <= 32 ? 4 : 8;
-        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1> : epl == 2 ? sweep_csr_rows_kernel<8, 2>
-             : epl == 4 ? sweep_csr_rows_kernel<8, 4> : sweep_csr_rows_kernel<8, 8>;
+        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG>
+             : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG> : sweep_csr_rows_kernel<8, 8, BIG>;
     } else {                      // rows of 16 lanes
         epl = cap <= 16 ? 1 : cap <= 32 ? 2 : 4;
-        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1> : epl == 2 ? sweep_csr_rows_kernel<4, 2> : sweep_csr_rows_kernel<4, 4>;
+        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG>
+                                                           : sweep_csr_rows_kernel<4, 4, BIG>;
     }
-    const hipError_t e = launch_csr_kernel(kern, a, false, false, waves_per_block, st);
-    note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane> x %d replica(s) per workgroup", g, epl, waves_per_block);
+    const hipError_t e = launch_csr_kernel(kern, a, false, BIG, waves_per_block, st);
+    note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane, %s spins> x %d replica(s) per workgroup", g, epl,
+                      BIG ? "bit" : "int8", waves_per_block);
     return e;
+}
+
+hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
+    return a.big ? launch_rows<true>(a, waves_per_block, st) : launch_rows<false>(a, waves_per_block, st);
 }
 
 }  // namespace sga

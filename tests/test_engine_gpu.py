@@ -526,9 +526,9 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
             assert "fast" in e.describe(), e.describe()
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
-            if not bits:
-                from spin_glass_anneal_rl_amd.engine import last_kernel
-                assert ("sweep_csr_rows_kernel" in last_kernel()) == (ahead in ("4", "8", None)), (ahead, last_kernel())
+            from spin_glass_anneal_rl_amd.engine import last_kernel
+            assert ("sweep_csr_rows_kernel" in last_kernel()) == (ahead in ("4", "8", None)), (ahead, last_kernel())
+            assert ("bit spins" in last_kernel()) == bits, last_kernel()
             assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (ahead, e.describe())
             assert np.array_equal(e.spins(), s)
             assert np.array_equal(e.stats()[0], ref["n_accepted"])
