@@ -931,6 +931,21 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
     return SGA_OK;
 }
 
+// Narrow CSR forms of integer problems whose longest row has <= 64 entries: 0 = one update at a time,
+// 1 | 2 = the pair look-ahead (opt-in, SGA_CSR_PAIR_AHEAD: round 3 measured -1 ... +3 % on BASELINE configs[2]),
+// 4 | 8 = that many updates per step, one per row of 16 | 8 lanes (sweep_csr_rows.hip; the launcher takes it
+// for production arguments -- Philox sites, Metropolis with the accept table): the default where it applies
+// (profiles/r03_experiments.md 4b: C3, rows of up to 50 entries, 1.0e10 | 2.87e10 | 2.47e10 attempts/s for
+// 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 5.1e10).  SGA_CSR_PAIR_AHEAD=0 turns it off.
+static int csr_updates_per_step(const sga_engine *e) {
+    if (!e->csr || e->max_row_len > 64) return 0;
+    int v = e->max_row_len <= 32 ? 8 : 4;
+    if (const char *env = std::getenv("SGA_CSR_PAIR_AHEAD")) v = std::atoi(env);
+    if (v != 1 && v != 2 && v != 4 && v != 8) return 0;
+    if (v >= 4 && (e->layout_entries + 64) * 8 >= (1ll << 32)) return 0;  // (32-bit byte offsets of the entries)
+    return v;
+}
+
 // The wide sweep forms (a row dealt to several waves) address rows by 64-entry slots: re-pad an
 // unpadded layout on demand (short-row problems run wide only when tuning asks for it).
 static int ensure_slotted(sga_engine *e) {
@@ -1603,22 +1618,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 10);
         }
         a.big = e->big_form;
-        // Pair look-ahead of the narrow table form: built and verified in round 3, measured -1 ... +3 % on
-        // BASELINE configs[2] (same-box A/B, profiles/r03_experiments.md) -- not the default; kept behind
-        // SGA_CSR_PAIR_AHEAD=1 (2: with the two wave sums interleaved) for the parity test and further A/Bs.
-        // Several updates per step (sweep_csr_rows.hip; the launcher takes it for the production arguments of
-        // integer problems with int8 spins): every row <= 64 entries, entry offsets below 2^32 bytes.
-        // SGA_CSR_PAIR_AHEAD=0 turns it off, 4 | 8 pick the rows per step (A/B, parity cross-check).
-        a.csr_pair_ahead = 0;
         a.csr_row_cap = (e->csr && e->max_row_len <= 64) ? (int)std::max<long long>(e->max_row_len, 1) : 0;
-        if (e->csr && e->max_row_len <= 64) {
-            const char *env = std::getenv("SGA_CSR_PAIR_AHEAD");
-            if (env) a.csr_pair_ahead = std::max(0, std::min(8, std::atoi(env)));
-            else a.csr_pair_ahead = e->max_row_len <= 32 ? 8 : 4;  // (profiles/r03_experiments.md: C3, rows of up to 50 entries,
-                // 1.0e10 | 2.67e10 | 2.44e10 attempts/s for 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 4.9e10)
-            if (a.csr_pair_ahead != 1 && a.csr_pair_ahead != 2 && a.csr_pair_ahead != 4 && a.csr_pair_ahead != 8) a.csr_pair_ahead = 0;
-            if (a.csr_pair_ahead >= 4 && (e->layout_entries + 64) * 8 >= (1ll << 32)) a.csr_pair_ahead = 0;
-        }
+        a.csr_pair_ahead = csr_updates_per_step(e);
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
         a.cv = e->cv;
@@ -2365,6 +2366,10 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,
                                                   e->use_t2 ? e->waves_t2 : e->waves, e->R)
                           : 1);
+    if (e->csr && csr_updates_per_step(e) >= 4 && e->waves <= 1 && (e->big_form == 0 || e->big_form == 2) &&
+        e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 && e->table_m < 2048 &&
+        (long long)e->n * e->table_m < (1ll << 31))
+        std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp), " updates_per_step=%d", csr_updates_per_step(e));
     if (e->csr && e->slotted)
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                       " rows=64-entry-slots(+%.1f%%) longest_row_slots=%lld",
