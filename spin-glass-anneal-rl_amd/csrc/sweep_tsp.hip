@@ -232,8 +232,232 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_kernel(const Swe
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// SEVERAL UPDATES PER STEP (production arguments): wave w of the workgroup works on update W m + w of the
+// sweep -- the whole row, NPF = npad / 256 passes -- against the state as it stands before the first of the W.
+// An update at (c, p) reads the columns p - 1 and p + 1 and the sums of city c and position p, so a flip at
+// (c, p) matters to a later update (c', p') of the step only if c' == c or p' is p - 1, p or p + 1 (mod n):
+// four of n^2 sites in n -- at 1000 cities eight updates are independent in 97 % of the steps.  The waves
+// publish (flips?, c, p, dE), meet at ONE barrier, and everyone checks the accepted updates against the later
+// ones by index arithmetic; no hit: every wave applies its own flip (distinct cities and positions, so the
+// sums do not collide), a second barrier, next step.  A hit: the step is replayed one update at a time (wave q
+// decides again from the rows it still holds, a barrier per update).  The energy is added in chain order by
+// every wave from the published dE.  Same chain bit for bit as the one-update form above (row sums are exact
+// in any order: set-time check), which remains the form for traces / replayed streams.
+// One update per wave instead of one per workgroup: at 1000 cities (one 136 KB workgroup per CU) the chip ran
+// two waves per CU on one dependent chain; now eight chains per CU.
+// ---------------------------------------------------------------------------------------
+constexpr int TSP_PAR_SLOT_INTS = 8;  // flip, c, p, pad, dE (2 ints), pad, pad
+template <int NPF, bool F64>
+__global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_par_kernel(const SweepArgs a, const TspArgs t) {
+    using acc_t = typename std::conditional<F64, double, float>::type;
+    const int rule = a.rule;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = t.n_cities, cw = t.npad >> 5;
+    unsigned int *bits = reinterpret_cast<unsigned int *>(smem);      // [n positions][cw words]
+    int *sums = reinterpret_cast<int *>(smem + 4ll * n * cw);         // S_city[n], S_pos[n]
+    int *slots = reinterpret_cast<int *>(smem + ((4ll * n * cw + 8ll * n + 15) & ~15ll) + 2 * TSP_MAX_WAVES * sizeof(double));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = (int)(blockDim.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x;
+    tsp_load_spins(a.spins + (long long)r * a.sstride, bits, sums, n, cw, tid, (int)blockDim.x);
+
+    double E = a.energy[r], bestE = a.best_energy[r], T = 1.0;
+    unsigned long long nacc = 0;
+    const unsigned int lane16 = (unsigned int)lane * 16u;  // byte offset of this lane's float4 in pass 0
+    const int N = a.n;
+    const int steps = (N + W - 1) / W;  // steps per sweep
+
+    struct Slot {
+        float4 prev[NPF], next[NPF];
+        int site, c, p, live;
+        float u, h;
+    };
+    // this wave's Philox window: blocks 64 q .. 64 q + 63 of sweep k (lane l: block 64 q + l)
+    uint32_t vsa = 0, vua = 0, vsb = 0, vub = 0;
+    int win_k = -1, win_q = -1;
+    auto produce = [&](Slot &sl, int k, int m) {  // update W m + w of sweep k (past the end: dead, site 0)
+        const int tu = W * m + w;
+        sl.live = (k < a.n_sweeps && tu < N) ? 1 : 0;
+        sl.site = 0;
+        sl.u = 2.0f;
+        if (sl.live) {  // wave-uniform
+            const int b = tu >> 1;
+            if (win_k != k || win_q != (b >> 6)) {
+                win_k = k, win_q = b >> 6;
+                const u32x4 x = philox4x32_10((uint32_t)(64 * win_q + lane), a.sweep0 + (uint32_t)k, a.replica0 + (uint32_t)r,
+                                              DOMAIN_SWEEP, a.seed_lo, a.seed_hi);
+                vsa = word_to_site(x.x, (uint32_t)N), vua = x.y, vsb = word_to_site(x.z, (uint32_t)N), vub = x.w;
+            }
+            const int l = b & 63;
+            sl.site = __builtin_amdgcn_readlane((int)((tu & 1) ? vsb : vsa), l);
+            sl.u = word_to_u((uint32_t)__builtin_amdgcn_readlane((int)((tu & 1) ? vub : vua), l));
+        }
+        sl.c = (int)(((unsigned long long)(unsigned int)sl.site * t.div_magic) >> 32);
+        sl.p = sl.site - sl.c * n;
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(t.nd4t) + (unsigned long long)sl.c * t.row_bytes;
+        const unsigned char *rn = reinterpret_cast<const unsigned char *>(t.nd4) + (unsigned long long)sl.c * t.row_bytes;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            unsigned int off = lane16 + (unsigned int)q * 1024u;
+            asm volatile("" : "+v"(off));
+            sl.prev[q] = *reinterpret_cast<const float4 *>(rp + off);
+            sl.next[q] = *reinterpret_cast<const float4 *>(rn + off);
+        }
+        sl.h = a.h[sl.site];
+    };
+    // this wave's decision against the state as it stands
+    auto decide = [&](const Slot &sl, int &si, double &dE) -> bool {
+        const int c = sl.c, p = sl.p;
+        const int pm = p == 0 ? n - 1 : p - 1, pn = p == n - 1 ? 0 : p + 1;
+        acc_t acc = 0;
+        tsp_accumulate<true>(acc, sl.prev[0], sl.next[0], bits, cw, pm, pn, 4 * lane);
+#pragma unroll
+        for (int q = 1; q < NPF; ++q) tsp_accumulate(acc, sl.prev[q], sl.next[q], bits, cw, pm, pn, 4 * (lane + 64 * q));
+        const acc_t dist = wave_sum(acc);
+        si = ((bits[p * cw + (c >> 5)] >> (c & 31)) & 1u) ? -1 : 1;
+        const int sc = sums[c], sp = sums[n + p];
+        // exact products, exact sum (set-time check), one rounding to fp32 (core/ising_model.py:183)
+        const double row = (double)t.a2 * (double)(sc - si) + (double)t.b2 * (double)(sp - si) + (double)dist;
+        const bool flip = metropolis_accept(rule, SGA_ARITH_F64, (float)row, si, sl.h, 0.0f, T, sl.u, dE);
+        return sl.live != 0 && flip;
+    };
+    auto apply = [&](const Slot &sl, int si) {  // this wave's own flip
+        if (lane == 0) {
+            atomicXor(&bits[sl.p * cw + (sl.c >> 5)], 1u << (sl.c & 31));
+            sums[sl.c] -= 2 * si;
+            sums[n + sl.p] -= 2 * si;
+        }
+    };
+    int turn = 0;
+    auto step = [&](const Slot &sl) {
+        int si;
+        double dE;
+        const bool flip = decide(sl, si, dE);
+        int *mine = slots + (turn * TSP_MAX_WAVES + w) * TSP_PAR_SLOT_INTS;
+        if (lane == 0) {
+            const long long db = __double_as_longlong(dE);
+            *reinterpret_cast<int4 *>(mine) = make_int4(flip ? 1 : 0, sl.c, sl.p, sl.live);
+            *reinterpret_cast<int2 *>(mine + 4) = make_int2((int)(unsigned int)db, (int)(db >> 32));
+        }
+        __syncthreads();  // (A) every wave has decided against the old state and published
+        int4 q0 = make_int4(0, -1, -1, 0);
+        int2 q1 = make_int2(0, 0);
+        if (lane < W) {
+            const int *theirs = slots + (turn * TSP_MAX_WAVES + lane) * TSP_PAR_SLOT_INTS;
+            q0 = *reinterpret_cast<const int4 *>(theirs);
+            q1 = *reinterpret_cast<const int2 *>(theirs + 4);
+        }
+        turn ^= 1;
+        const unsigned long long acc = __ballot(q0.x != 0);
+        // does an accepted update matter to a later one of the step?
+        unsigned long long hit = 0;
+        unsigned long long rest = acc;
+        while (rest) {  // (few: wave-uniform loop over the accepted updates)
+            const int q = (int)__builtin_ctzll(rest);
+            rest &= rest - 1;
+            const int cq = __builtin_amdgcn_readlane(q0.y, q), pq = __builtin_amdgcn_readlane(q0.z, q);
+            int dp = q0.z - pq;
+            dp = dp < 0 ? -dp : dp;
+            const bool near = dp <= 1 || dp == n - 1;  // p' in {p - 1, p, p + 1} (mod n)
+            hit |= __ballot(lane > q && lane < W && q0.w != 0 && (q0.y == cq || near));
+        }
+        if (hit == 0ull) {
+            if (flip) apply(sl, si);
+            unsigned long long order = acc;
+            while (order) {  // chain order
+                const int q = (int)__builtin_ctzll(order);
+                order &= order - 1;
+                const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane(q1.x, q), hi = (unsigned int)__builtin_amdgcn_readlane(q1.y, q);
+                E += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                ++nacc;
+            }
+            __syncthreads();  // (B) the new state is visible
+            return;
+        }
+        // one update at a time: wave q decides again from the rows it holds, against what the earlier ones left
+        for (int q = 0; q < W; ++q) {
+            int *slot = slots + (turn * TSP_MAX_WAVES) * TSP_PAR_SLOT_INTS;  // one shared record per pass
+            if (w == q) {
+                asm volatile("" ::: "memory");  // (the state is re-read: other waves' flips behind barriers)
+                int si2;
+                double dE2;
+                const bool flip2 = decide(sl, si2, dE2);
+                if (flip2) apply(sl, si2);
+                if (lane == 0) {
+                    const long long db = __double_as_longlong(dE2);
+                    slot[0] = flip2 ? 1 : 0;
+                    *reinterpret_cast<int2 *>(slot + 4) = make_int2((int)(unsigned int)db, (int)(db >> 32));
+                }
+            }
+            __syncthreads();
+            if (slot[0]) {
+                const int2 d = *reinterpret_cast<const int2 *>(slot + 4);
+                E += __longlong_as_double((long long)(((unsigned long long)(unsigned int)d.y << 32) | (unsigned int)d.x));
+                ++nacc;
+            }
+            __syncthreads();  // (the record is free again)
+        }
+    };
+    auto later = [&](int k, int m, int ahead, int &ko, int &mo) {
+        mo = m + ahead;
+        ko = k;
+        while (mo >= steps) {
+            mo -= steps;
+            ++ko;
+        }
+    };
+    // the rows of the next step are in flight while a step is reduced (eight waves: 128 VGPRs each -- two
+    // steps of rows at four passes would not fit)
+    constexpr int NB = 2;
+    Slot ring[NB];
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) {
+        int kj, mj;
+        later(0, 0, j, kj, mj);
+        produce(ring[j], kj, mj);
+    }
+    for (int k = 0; k < a.n_sweeps; ++k) {
+        T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
+        int m = 0;
+        for (; m + NB <= steps; m += NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int k2, m2;
+                later(k, m + j, NB - 1, k2, m2);
+                produce(ring[(j + NB - 1) % NB], k2, m2);
+                step(ring[j]);
+            }
+        }
+        for (; m < steps; ++m) {
+            int k2, m2;
+            later(k, m, NB - 1, k2, m2);
+            produce(ring[NB - 1], k2, m2);
+            step(ring[0]);
+#pragma unroll
+            for (int j = 0; j + 1 < NB; ++j) ring[j] = ring[j + 1];
+        }
+        if (tid == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
+        if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
+            bestE = E;
+            tsp_store_spins(bits, a.best_spins + (long long)r * a.sstride, n, cw, a.sstride, tid, (int)blockDim.x);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    tsp_store_spins(bits, a.spins + (long long)r * a.sstride, n, cw, a.sstride, tid, (int)blockDim.x);
+    if (tid == 0) {
+        a.energy[r] = E;
+        a.best_energy[r] = bestE;
+        a.n_accepted[r] += nacc;
+    }
+}
+
 size_t tsp_lds_bytes(int n_cities, int npad) {
-    return (size_t)(((4ll * n_cities * (npad >> 5) + 8ll * n_cities + 7) & ~7ll) + 2 * TSP_MAX_WAVES * sizeof(double));
+    // bits | sums | [2][8] partial sums (one-update form) | [2][8] decision records (several-updates form)
+    return (size_t)(((4ll * n_cities * (npad >> 5) + 8ll * n_cities + 15) & ~15ll) + 2 * TSP_MAX_WAVES * sizeof(double) +
+                    2 * TSP_MAX_WAVES * TSP_PAR_SLOT_INTS * sizeof(int));
 }
 
 template <int NP>
@@ -249,8 +473,39 @@ static hipError_t launch_tsp_np(const SweepArgs &a, const TspArgs &t, int waves,
     return hipGetLastError();
 }
 
+// updates per step of the several-updates form for n cities (0: the one-update form): a pair of updates is
+// independent with probability 1 - 4/n
+int tsp_parallel_updates(int n_cities, int npad) {
+    int want = n_cities >= 256 ? 8 : n_cities >= 64 ? 4 : n_cities >= 24 ? 2 : 0;
+    if (const char *env = std::getenv("SGA_TSP_PARALLEL")) want = std::atoi(env);  // A/B switch, parity tests
+    if (want < 2 || npad > 1024) return 0;  // (builds for rows of up to 4 passes per wave)
+    return std::min(want, TSP_MAX_WAVES);
+}
+
+template <int NPF>
+static hipError_t launch_tsp_par(const SweepArgs &a, const TspArgs &t, int waves, hipStream_t st) {
+    void (*kern)(const SweepArgs, const TspArgs) = t.f64 ? sweep_tsp_par_kernel<NPF, true> : sweep_tsp_par_kernel<NPF, false>;
+    const size_t lds = tsp_lds_bytes(t.n_cities, t.npad);
+    hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a, t);
+    note_sweep_kernel("sweep_tsp_par_kernel<%d passes, %s> x %d updates per step", NPF, t.f64 ? "f64" : "f32", waves);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st) {
     if (waves < 1 || waves > TSP_MAX_WAVES || 256 * waves * passes != t.npad) return hipErrorInvalidValue;
+    const int par = sweep_args_are_lean(a) ? tsp_parallel_updates(t.n_cities, t.npad) : 0;
+    if (par >= 2) {
+        switch (t.npad / 256) {
+            case 1: return launch_tsp_par<1>(a, t, par, st);
+            case 2: return launch_tsp_par<2>(a, t, par, st);
+            case 3: return launch_tsp_par<3>(a, t, par, st);
+            case 4: return launch_tsp_par<4>(a, t, par, st);
+            default: break;
+        }
+    }
+    note_sweep_kernel("sweep_tsp_kernel<%d passes> x %d wave(s)", passes, waves);
     switch (passes) {
         case 1: return launch_tsp_np<1>(a, t, waves, st);
         case 2: return launch_tsp_np<2>(a, t, waves, st);

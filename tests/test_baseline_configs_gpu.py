@@ -233,6 +233,47 @@ def test_tsp_implicit_form_equals_stored_couplings_and_oracle(sg, n_cities, inte
                     e.flip(0, 1)
 
 
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n_cities", [3, 6, 17, 40, 260])
+def test_tsp_implicit_form_several_updates_per_step(sg, n_cities, integer, monkeypatch):
+    """The production sweep of the implicit TSP form works on 2 | 4 | 8 consecutive updates at once, one per
+    wave, and replays a step one update at a time when an accepted update shares its city or a neighbouring
+    position with a later one (always, at a handful of cities; a few per cent of the steps at hundreds):
+    every setting walks the oracle's chain."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    dist = _tsp_distances(n_cities, 300 + n_cities, integer)
+    d32, A, B, h, _ = enc.tsp_structure(dist, 200.0, 120.0, auto_scale=not integer)
+    n, R, ns, seed = n_cities ** 2, 5, (6 if n_cities <= 40 else 1), 77 + n_cities
+    csr = oracle.tsp_to_csr(d32, A, B)
+    temps = ladder(R, 300.0, 3.0)
+    prob = oracle.Problem(csr=(csr[0].astype(np.int32), csr[1], csr[2]), h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
+    for par in ("0", "2", "4", "8", None):
+        if par is None:
+            monkeypatch.delenv("SGA_TSP_PARALLEL")
+        else:
+            monkeypatch.setenv("SGA_TSP_PARALLEL", par)
+        with sg.AnnealEngine(0) as e:
+            e.set_tsp(d32, A, B, h)
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            k = last_kernel()
+            want = int(par) if par is not None else (8 if n_cities >= 256 else 4 if n_cities >= 64 else 2 if n_cities >= 24 else 0)
+            assert ("sweep_tsp_par_kernel" in k and f"x {want} updates" in k) if want >= 2 else k.startswith("sweep_tsp_kernel"), k
+            assert np.array_equal(e.spins(), s), (par, k)
+            assert np.array_equal(e.stats()[0], ref["n_accepted"]), (par, k)
+            if integer:
+                assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (par, k)
+                assert np.array_equal(e.energies(), ref["energy"]), (par, k)
+            else:
+                assert np.allclose(out["energy_trace"], ref["energy_trace"], rtol=1e-9, atol=1e-6), (par, k)
+            be, bs, br = e.best()
+            assert np.array_equal(bs, ref["best_spins"][br]), (par, k)
+
+
 @pytest.mark.parametrize("n_cities,splits", [(300, [(1, 2), (2, 1)]), (900, [(2, 2), (1, 4), (4, 1)])])
 def test_tsp_implicit_form_waves_and_passes_give_one_chain(sg, n_cities, splits):
     """The implicit TSP sweep deals a distance row to waves x passes of 256 cities (default: two passes
