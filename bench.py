@@ -484,6 +484,8 @@ def main():
     kernel_name = "sweep_tsp_kernel" if implicit else ("sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
     if kernel_inst.startswith("sweep_csr_rows_kernel"):  # several updates per step (short integer rows: C3)
         kernel_name = "sweep_csr_rows_kernel"
+    elif kernel_inst.startswith("sweep_tsp_par_kernel"):  # implicit TSP form, one update per wave
+        kernel_name = "sweep_tsp_par_kernel"
     if implicit:
         pmc_tag = f"c5_{a.cities}_implicit"
     traffic, traffic_src = pmc_traffic(pmc_tag, kernel_name)
@@ -540,6 +542,7 @@ def main():
             f"two {4 * a.cities}-byte rows of the scaled distance table ({8 * a.cities ** 2 / 1e6:.0f} MB, cache "
             "resident), so the kernel is bound by the per-update chain (reduction, barrier, decision), not by HBM; "
             "the same chain as the CSR form, bit for bit")
+        out["roofline"]["cache_resident"] = True  # (its frac compares a cache-served rate with the HBM number)
     if csr is not None:
         nbytes = float(len(csr[1])) * 8.0
         out["roofline"]["note"] = (
