@@ -93,9 +93,17 @@ while time.time() < t_end:
                 out = e.sweep(ns, trace=True)
                 ok = (np.array_equal(out["accept_trace"], ref["accept_trace"]) and np.array_equal(out["dE_trace"], ref["dE_trace"])
                       and np.array_equal(e.spins(), st))
+                # the production sweep (several updates per step, one per wave: sweep_tsp_par_kernel) from the same start
+                par = str(rng.choice([0, 2, 4, 8]))
+                os.environ["SGA_TSP_PARALLEL"] = par
+                e.init_replicas(Rt, seed=seed)
+                e.set_temperatures(tt)
+                e.sweep(ns)
+                os.environ.pop("SGA_TSP_PARALLEL", None)
+                ok = ok and np.array_equal(e.spins(), st) and np.array_equal(e.stats()[0], ref["n_accepted"])
                 if not ok:
                     n_fail += 1
-                    print("MISMATCH tsp", desc, f"cities={nc}", "|", e.describe(), flush=True)
+                    print("MISMATCH tsp", desc, f"cities={nc} par={par}", "|", e.describe(), flush=True)
         except Exception as ex:
             n_fail += 1
             print("ERROR tsp", desc, "|", str(ex)[:200], flush=True)
