@@ -41,8 +41,20 @@ def random_graph(n, half_degree, seed):
     return A
 
 
+def gaussian(A, seed):
+    """the same graph with symmetric Gaussian couplings (no accept table: fp64 row sums in the canonical order)"""
+    rng = np.random.RandomState(seed)
+    U = sp.triu(A, 1).tocoo()
+    v = rng.randn(U.nnz)
+    B = sp.coo_matrix((np.concatenate([v, v]), (np.concatenate([U.row, U.col]), np.concatenate([U.col, U.row]))), shape=A.shape).tocsr()
+    B.sort_indices()
+    return B
+
+
 R = int(os.environ.get("R", 4096))
-cases = [("3-D EA lattice L=22 (degree 6)", lattice3d(22, 1)), ("random graph, degree ~4", random_graph(10000, 2, 2)),
+cases = [("3-D EA lattice L=22 (degree 6)", lattice3d(22, 1)),
+         ("3-D Gaussian EA lattice L=22", gaussian(lattice3d(22, 1), 5)),
+         ("Gaussian random graph, degree ~32", gaussian(random_graph(10000, 16, 3), 6)), ("random graph, degree ~4", random_graph(10000, 2, 2)),
          ("random graph, degree ~16", random_graph(10000, 8, 3)), ("random graph, degree ~32 (C3)", random_graph(10000, 16, 3))]
 for name, A in cases:
     n = A.shape[0]

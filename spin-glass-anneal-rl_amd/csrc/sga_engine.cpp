@@ -2366,9 +2366,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,
                                                   e->use_t2 ? e->waves_t2 : e->waves, e->R)
                           : 1);
-    if (e->csr && csr_updates_per_step(e) >= 4 && e->waves <= 1 && (e->big_form == 0 || e->big_form == 2) &&
-        e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 && e->table_m < 2048 &&
-        (long long)e->n * e->table_m < (1ll << 31))
+    if (e->csr && csr_updates_per_step(e) >= 4 && e->waves <= 1 && (e->big_form == 0 || e->big_form == 2) && e->rowptr)
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp), " updates_per_step=%d", csr_updates_per_step(e));
     if (e->csr && e->slotted)
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),

@@ -35,7 +35,13 @@ namespace sga {
 // much as one that does): lattices and other low-degree graphs run with one entry per lane.
 // BIG: the replica's spins as one bit each in LDS (1 = down), for problems whose int8 spins would not fit or
 // would leave few replicas resident -- the narrow bit-spin form's layout (a.big == 2).
-template <int G, int EPL, bool BIG>
+// REAL: couplings or fields that are not (half-)integers -- no accept table, row sums in fp64 in the CANONICAL
+// order of sweep_csr_impl.h (entry e in lane e of a 64-lane adjacent-pairs tree; lanes past the row's end add
+// +-0): a lane's EPL consecutive entries are the leaves of one subtree, folded locally by adjacent pairs, and the
+// DPP steps over the row's lanes continue the same tree (IEEE addition commutes, so which side a partner comes
+// from does not matter) -- the same bits as the one-update form for every launch geometry.  The energy is
+// then added in chain order.
+template <int G, int EPL, bool BIG, bool REAL>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kernel(const SweepArgs a) {
     constexpr int LPR = 64 / G;   // lanes per row
     static_assert((G == 4 || G == 8) && LPR * EPL <= 64, "rows of 16 or 8 lanes, coupling rows of up to 64 entries");
@@ -141,18 +147,37 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
 #pragma unroll
         for (int q = 0; q < EPL; ++q) st.e[q] = *reinterpret_cast<const int2 *>(cv + off + 8 * q);
     };
-    // sum over the lanes of a row, in every lane of the row (exact: integers below 2^24)
-    auto row_sum = [&](float v) -> float {
+    // sum over the lanes of a row, in every lane of the row (table form: exact, integers below 2^24; REAL: the
+    // upper levels of the canonical tree)
+    auto row_sum = [&](auto v) {
         v += dpp_move<DPP_QUAD_XOR1>(v);
         v += dpp_move<DPP_QUAD_XOR2>(v);
         v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
         if constexpr (LPR == 16) v += dpp_move<DPP_ROW_MIRROR>(v);
         return v;
     };
-    // this row's decision against the spins as they stand: flips?, fk = s_i (row sum + h)
-    auto decide = [&](const Step &st, int &si, float &fk) -> bool {
+    // this row's decision against the spins as they stand: flips?, dE of the move (table form: 2 fk, fk = s_i
+    // (row sum + h), an integer)
+    auto decide = [&](const Step &st, int &si, double &dE) -> bool {
         const int left = st.end - st.beg - EPL * j;  // entries of the row from this lane's first on
         si = spin_at(st.site);
+        if constexpr (REAL) {
+            double tr[EPL];
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                const float v = q < left ? __int_as_float(st.e[q].y) : 0.0f;
+                tr[q] = (double)(v * (float)spin_at(st.e[q].x));  // (exact product)
+            }
+#pragma unroll
+            for (int stride = 1; stride < EPL; stride *= 2)
+#pragma unroll
+                for (int q = 0; q + stride < EPL; q += 2 * stride) tr[q] += tr[q + stride];
+            const float dotr = (float)row_sum(tr[0]);  // rounded to fp32 once (core/ising_model.py:183)
+            const float u = (float)st.ru * 0x1.0p-24f;
+            const bool flipr = metropolis_accept(SGA_RULE_METROPOLIS, SGA_ARITH_F64, dotr, si, st.h, 0.0f, T, u, dE);
+            return st.live != 0 && flipr;
+        }
+        float fk;
         float dot;
         if constexpr (BIG) {
             auto term = [&](int q) -> float {
@@ -179,8 +204,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         const int idx = min(max((int)fq, 0), a.table_m);
         bool flip = fk <= 0.0f || st.ru < itab[idx];  // u < p on the uniform's raw bits
         const bool beyond = fq > (float)a.table_m;
+        dE = (double)(2.0f * fk);
         if (__ballot(beyond)) {  // beyond the table (p == 0 past -104)
-            const double dE = (double)(2.0f * fk);
             if (beyond) flip = (dE > T * 104.0) ? false : ((float)st.ru * 0x1.0p-24f < expf_det((float)(-dE / T)));
         }
         return st.live != 0 && flip;
@@ -188,8 +213,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     constexpr unsigned long long HEADS = G == 4 ? 0x0001000100010001ull : 0x0101010101010101ull;  // lane 0 of every row
     auto step = [&](const Step &st) {
         int si;
-        float fk;
-        const bool flip = decide(st, si, fk);
+        double dE;
+        const bool flip = decide(st, si, dE);
         const unsigned long long acc = __ballot(flip) & HEADS;
         // does an accepted update touch a LATER one of the step?  (its site among their columns or their
         // sites; entries past a row's end take part -- a stray hit costs a replay, nothing else)
@@ -210,9 +235,18 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             if (acc) {
                 if (flip && j == 0) flip_at(st.site, si);
                 asm volatile("" ::: "memory");  // (the next step's gathers are reloads as well)
-                // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
-                // at the end of the sweep (exact in any order; a wave sum per step cost ~14 instructions)
-                dE_lane += (flip && j == 0) ? (int)(2.0f * fk) : 0;
+                if constexpr (REAL) {
+                    unsigned long long order = acc;
+                    while (order) {  // chain order
+                        const int q = (int)__builtin_ctzll(order);
+                        order &= order - 1;
+                        E += read_lane(dE, q);
+                    }
+                } else {
+                    // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
+                    // at the end of the sweep (exact in any order; a wave sum per step cost ~14 instructions)
+                    dE_lane += (flip && j == 0) ? (int)dE : 0;
+                }
                 nacc += (unsigned long long)__builtin_popcountll(acc);
             }
             return;
@@ -226,11 +260,11 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             // operations of a wave execute in order, so no hardware fence is needed, only the reload.)
             asm volatile("" ::: "memory");
             int si2;
-            float fk2;
-            const bool flip2 = decide(st, si2, fk2);
+            double dE2;
+            const bool flip2 = decide(st, si2, dE2);
             if ((__ballot(flip2) >> (LPR * q)) & 1ull) {
                 if (lane == LPR * q) flip_at(st.site, si2);
-                E += (double)(2.0f * read_lane(fk2, LPR * q));
+                E += read_lane(dE2, LPR * q);
                 ++nacc;
             }
         }
@@ -265,9 +299,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     for (int k = 0; k < a.n_sweeps; ++k) {
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         // exp(float32(-dE / T)) for dE = 2 q / table_scale as integer thresholds on the uniform's raw bits
-        for (int q = lane; q <= a.table_m; q += 64)
-            itab[q] = (unsigned int)__builtin_ceilf(
-                expf_det((float)(-((double)(2 * q) / (double)a.table_scale) / T)) * 16777216.0f);
+        if constexpr (!REAL)
+            for (int q = lane; q <= a.table_m; q += 64)
+                itab[q] = (unsigned int)__builtin_ceilf(
+                    expf_det((float)(-((double)(2 * q) / (double)a.table_scale) / T)) * 16777216.0f);
         int m = 0;
         for (; m + 3 <= steps; m += 3) {
             step3(S0, S1, S2, k, m);
@@ -301,14 +336,17 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
 // byte offsets fit 32 bits (the engine checks the row lengths: every row <= 64 entries)
 bool sweep_csr_rows_applies(const SweepArgs &a) {
     const bool lean = csr_args_are_lean(a);
-    // (the energy change of a sweep is summed in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m, where
-    //  table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale)
-    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
-           (a.big == 0 || a.big == 2) && a.rowptr && lean && csr_effective_acc(a, lean) == CSR_ACC_F32_TABLE &&
-           a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
+    if (!((a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
+          (a.big == 0 || a.big == 2) && a.rowptr && lean))
+        return false;
+    if (csr_effective_acc(a, lean) != CSR_ACC_F32_TABLE) return true;  // fp64 sums in the canonical order, no table
+    // (table form: the energy change of a sweep is summed in 32-bit integers per lane -- n / 4 moves of
+    //  |dE| <= 2 table_m, where table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale;
+    //  beyond that the fp64 form serves: integer sums are exact there too)
+    return true;
 }
 
-template <bool BIG>
+template <bool BIG, bool REAL>
 static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
     const int cap = a.csr_row_cap;  // entries of the problem's longest row (<= 64)
     void (*kern)(const SweepArgs) = nullptr;
@@ -316,21 +354,24 @@ static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream
     if (a.csr_pair_ahead == 8) {  // rows of 8 lanes
         g = 8;
         epl = cap <= 8 ? 1 : cap <= 16 ? 2 : cap <= 32 ? 4 : 8;
-        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG>
-             : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG> : sweep_csr_rows_kernel<8, 8, BIG>;
+        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG, REAL>
+             : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG, REAL> : sweep_csr_rows_kernel<8, 8, BIG, REAL>;
     } else {                      // rows of 16 lanes
         epl = cap <= 16 ? 1 : cap <= 32 ? 2 : 4;
-        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG>
-                                                           : sweep_csr_rows_kernel<4, 4, BIG>;
+        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG, REAL>
+                                                                 : sweep_csr_rows_kernel<4, 4, BIG, REAL>;
     }
     const hipError_t e = launch_csr_kernel(kern, a, false, BIG, waves_per_block, st);
-    note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane, %s spins> x %d replica(s) per workgroup", g, epl,
-                      BIG ? "bit" : "int8", waves_per_block);
+    note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane, %s spins, %s> x %d replica(s) per workgroup", g, epl,
+                      BIG ? "bit" : "int8", REAL ? "fp64 canonical sums" : "accept table", waves_per_block);
     return e;
 }
 
 hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
-    return a.big ? launch_rows<true>(a, waves_per_block, st) : launch_rows<false>(a, waves_per_block, st);
+    const bool table = csr_effective_acc(a, true) == CSR_ACC_F32_TABLE && a.table_m < 2048 &&
+                       (long long)a.n * a.table_m < (1ll << 31);
+    if (a.big) return table ? launch_rows<true, false>(a, waves_per_block, st) : launch_rows<true, true>(a, waves_per_block, st);
+    return table ? launch_rows<false, false>(a, waves_per_block, st) : launch_rows<false, true>(a, waves_per_block, st);
 }
 
 }  // namespace sga

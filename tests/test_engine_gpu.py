@@ -539,6 +539,53 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     assert all(np.array_equal(got[k][0], got["0"][0]) and got[k][1] == got["0"][1] for k in got)
 
 
+@pytest.mark.parametrize("bits", [False, True])
+@pytest.mark.parametrize("n,deg,grid", [
+    (6, 4, False),       # every step hits
+    (400, 6, False),     # lattice-like degree, Gaussian couplings: one entry per lane
+    (300, 24, True),     # couplings on a 2^-10 grid (the fp64-exact row-sum class), rows of up to ~40 entries
+    (150, 60, False),    # rows of up to 64 entries
+])
+def test_csr_several_updates_per_step_with_real_valued_couplings(sg, n, deg, grid, bits, monkeypatch):
+    """The several-updates-per-step form without the accept table: fp64 row sums in the canonical order (a lane's
+    consecutive entries are one subtree of the 64-lane adjacent-pairs tree, the DPP steps over the row's lanes
+    continue it), energies added in chain order -- bit for bit the oracle's chain, for 4 and 8 rows per step, on
+    int8 and on bit spins, and equal to the one-update-at-a-time form."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    if bits:
+        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    rng = np.random.RandomState(11 * n + deg)
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rng.choice(n, min(deg // 2, n), replace=False):
+            if i != j and np.count_nonzero(J[i]) < 62 and np.count_nonzero(J[j]) < 62:
+                v = rng.randn()
+                J[i, j] = J[j, i] = np.float32(np.rint(v * 1024.0) / 1024.0 if grid else v)
+    h = rng.randn(n).astype(np.float32)
+    csr = csr_of(J)
+    assert np.diff(csr[0]).max() <= 64
+    prob = oracle.Problem(csr=csr, h=h)
+    R, ns, seed = 6, 8, 4242 + n
+    temps = ladder(R, 3.0, 0.2)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
+    for ahead in ("4", "8", None, "0"):
+        if ahead is not None:
+            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
+        else:
+            monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
+        with sg.AnnealEngine(0) as e:
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            k = last_kernel()
+            assert ("sweep_csr_rows_kernel" in k and "fp64 canonical sums" in k) == (ahead != "0"), (ahead, k)
+            assert np.array_equal(e.spins(), s), (ahead, k)
+            assert np.array_equal(e.stats()[0], ref["n_accepted"]), (ahead, k)
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (ahead, k)
+
+
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("integer", [True, False])
 @pytest.mark.parametrize("big", [False, True])
