@@ -102,7 +102,10 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
  * and packed into the engine's layout -- (column, value) entries interleaved, rows of long-row
  * problems padded to whole 64-entry slots; the caller's buffers are not referenced after the call.
  * The same pass classifies how a row sum can be formed exactly (integer / fp64-exact / canonical
- * order, see sga_describe's "path=" and DESIGN.md 2). */
+ * order, see sga_describe's "path=" and DESIGN.md 2).  Problems whose longest row has <= 64 entries
+ * (lattices, low-degree graphs, BASELINE configs[2]) are swept several updates per step -- one per
+ * row of 8 or 16 lanes, replayed one at a time when an accepted update touches a later one of the
+ * step: the same chain, 3-6 x the one-update rate (sga_describe: "updates_per_step="). */
 int sga_set_csr(sga_engine *e, const int32_t *rowptr, const int32_t *colidx, const float *val,
                 const float *h, int n, int64_t nnz);
 /* Same with 64-bit row extents, for nnz >= 2^31 (BASELINE config 5 at 1000 cities: n = 10^6,
@@ -121,7 +124,8 @@ int sga_set_csr64(sga_engine *e, const int64_t *rowptr, const int32_t *colidx, c
  * dist: fp32 [n_cities][ld] (host or device; its diagonal is ignored), h: [n_cities^2] fields.
  * The sweep reads two 4 n_cities-byte distance rows per update instead of a 32 n_cities-byte
  * coupling row.  Row sums are exact (checked here) and rounded once to fp32, as in the stored
- * forms, so the chain equals sga_set_csr's on the same couplings bit for bit; sga_describe says
+ * forms, so the chain equals sga_set_csr's on the same couplings bit for bit (production sweeps work
+ * on up to eight updates at once, one per wave, wherever they are independent); sga_describe says
  * "acc=f64" without "-exact" in the one case where that cannot be guaranteed (distances spanning
  * more than ~40 binary orders of magnitude).  Single-site flip / update are not available on this
  * form (SGA_ERR_UNSUPPORTED); local fields are. */
