@@ -410,7 +410,10 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_par_kernel(const
     };
     // the rows of the next step are in flight while a step is reduced (eight waves: 128 VGPRs each -- two
     // steps of rows at four passes would not fit)
-    constexpr int NB = 2;
+#ifndef TSP_PAR_RING
+#define TSP_PAR_RING 2
+#endif
+    constexpr int NB = TSP_PAR_RING;
     Slot ring[NB];
 #pragma unroll
     for (int j = 0; j + 1 < NB; ++j) {
