@@ -1,6 +1,6 @@
-// sweep_csr_rows.hip -- narrow CSR sweep, SEVERAL UPDATES PER STEP: BASELINE configs[2] (10 000 spins,
-// degree ~32, 4096 replicas) in the production configuration (integer couplings and fields, Philox sites,
-// Metropolis with the accept table, int8 spins in LDS).
+// sweep_csr_rows.hip -- narrow CSR sweep, SEVERAL UPDATES PER STEP: sparse problems whose longest row has <= 64
+// entries (BASELINE configs[2]: 10 000 spins, degree ~32, 4096 replicas; lattices; low-degree graphs) under the
+// production arguments (Philox sites, Metropolis, no per-update traces), spins in LDS as int8 or as bits.
 //
 // Replaces the same reference functions as sweep_csr_kernel (core/spin_dynamics.py:73-94,131-152,
 // core/ising_model.py:176-185) and walks the same chain bit for bit.
@@ -9,18 +9,20 @@
 // uses 32 of its 64 lanes at degree 32; it is bound by instruction issue and its dependent chain, not by
 // memory (the 2.6 MB structure is L2 resident).  Here a wave works on the G consecutive updates
 // t = G m .. G m + G - 1 at once (G = 4 | 8), one per ROW of 64 / G lanes (lane j of a row holds entries
-// E j .. E j + E - 1 of the row's coupling row, E = G: rows of up to 64 entries), every row sum against the
-// spins as they stand before the first of the G:
+// EPL j .. EPL j + EPL - 1 of the row's coupling row, EPL = 1 .. 8 picked by the problem's longest row), every
+// row sum against the spins as they stand before the first of the G:
 //   * sparse couplings make that exact almost always: flipping site A changes the local field of B only
 //     if J[B][A] != 0, and B's own spin only if B == A.  The G decisions are formed together, then
 //     checked in chain order: for every accepted update the later rows look for its site among their
 //     columns (and their own site) -- one compare per entry and a ballot.  No hit (98-99 % of the steps at
 //     degree 32 of 10 000): all G decisions are the chain's.  A hit: the step is replayed one update
 //     at a time (same data, already in registers).
-//   * everything is an integer below 2^24 (the table form's precondition), so row sums, dE and the
-//     energy are exact in any order: E += the sum of the accepted dE of the step.
-// Per step: the row entries in E / 2 16-byte loads per lane, E LDS spin gathers per lane, a DPP row sum (all
-// rows in the same instructions), one table look-up.  Sites and uniforms of 128 updates come from one
+//   * integer problems (the accept-table builds): everything is an integer below 2^24, so row sums, dE and
+//     the energy are exact in any order -- a row's lane 0 keeps its share of the sweep's dE as an integer.
+//     Real-valued problems (REAL builds): fp64 row sums in the canonical order of sweep_csr_impl.h, the energy
+//     added in chain order.
+// Per step: the row entries in EPL / 2 16-byte loads per lane, EPL LDS spin gathers per lane, a DPP row sum
+// (all rows in the same instructions), one table look-up.  Sites and uniforms of 128 updates come from one
 // vectorised Philox pass (lane l: block l), re-laid so that lane i holds update i (ds_bpermute); a step
 // picks its G updates with one more permute each.  Sites, row extents and row entries are requested
 // two / one steps ahead (the site sequence is known from the counter RNG).
@@ -332,18 +334,12 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     }
 }
 
-// the form applies to: production arguments with the accept table, int8 spins, 32-bit row extents whose
-// byte offsets fit 32 bits (the engine checks the row lengths: every row <= 64 entries)
+// the form applies to: production arguments (Philox sites, Metropolis, no per-update traces), int8 spins or the
+// narrow bit-spin layout, 32-bit row extents whose byte offsets fit 32 bits; the engine checks the row lengths
+// (every row <= 64 entries: a.csr_row_cap) and sets a.csr_pair_ahead = 4 | 8
 bool sweep_csr_rows_applies(const SweepArgs &a) {
-    const bool lean = csr_args_are_lean(a);
-    if (!((a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
-          (a.big == 0 || a.big == 2) && a.rowptr && lean))
-        return false;
-    if (csr_effective_acc(a, lean) != CSR_ACC_F32_TABLE) return true;  // fp64 sums in the canonical order, no table
-    // (table form: the energy change of a sweep is summed in 32-bit integers per lane -- n / 4 moves of
-    //  |dE| <= 2 table_m, where table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale;
-    //  beyond that the fp64 form serves: integer sums are exact there too)
-    return true;
+    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
+           (a.big == 0 || a.big == 2) && a.rowptr && csr_args_are_lean(a);
 }
 
 template <bool BIG, bool REAL>
@@ -368,6 +364,9 @@ static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream
 }
 
 hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
+    // The accept-table builds sum a sweep's energy change in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m,
+    // where a table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale.  Everything else --
+    // real-valued couplings, integer problems beyond that -- runs the fp64 builds (exact for integers too).
     const bool table = csr_effective_acc(a, true) == CSR_ACC_F32_TABLE && a.table_m < 2048 &&
                        (long long)a.n * a.table_m < (1ll << 31);
     if (a.big) return table ? launch_rows<true, false>(a, waves_per_block, st) : launch_rows<true, true>(a, waves_per_block, st);
