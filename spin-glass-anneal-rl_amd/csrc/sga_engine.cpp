@@ -937,11 +937,20 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
 // for production arguments -- Philox sites, Metropolis with the accept table): the default where it applies
 // (profiles/r03_experiments.md 4b: C3, rows of up to 50 entries, 1.0e10 | 2.87e10 | 2.47e10 attempts/s for
 // 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 5.1e10).  SGA_CSR_PAIR_AHEAD=0 turns it off.
+// Rows of 65 ... 256 entries (assignment / small scheduling problems: degree 100-250, cache resident, bound by the
+// one-update chain): four per step with 8 | 16 entries per lane, integer problems with the accept table only.
+static bool csr_rows_medium(const sga_engine *e) {
+    return e->csr && e->max_row_len > 64 && e->max_row_len <= 256 && e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 &&
+           e->table_m < 2048 && (long long)e->n * e->table_m < (1ll << 31);
+}
 static int csr_updates_per_step(const sga_engine *e) {
-    if (!e->csr || e->max_row_len > 64) return 0;
+    if (!e->csr || e->max_row_len > 256) return 0;
+    const bool medium = e->max_row_len > 64;
+    if (medium && !csr_rows_medium(e)) return 0;
     int v = e->max_row_len <= 32 ? 8 : 4;
     if (const char *env = std::getenv("SGA_CSR_PAIR_AHEAD")) v = std::atoi(env);
     if (v != 1 && v != 2 && v != 4 && v != 8) return 0;
+    if (medium) v = v >= 4 ? 4 : 0;  // (the pair look-ahead holds one wave-load per row)
     if (v >= 4 && (e->layout_entries + 64) * 8 >= (1ll << 32)) return 0;  // (32-bit byte offsets of the entries)
     return v;
 }
@@ -1315,7 +1324,13 @@ static int init_replicas_body(sga_engine *e, int R_local, int R_global, int repl
         const double deg = (double)e->nnz / e->n;
         const int bits_stride = (e->n + 127) / 128 * 128;
         const bool bits_fit = sga::csr_big_fits(bits_stride, 0);
-        const bool long_rows = deg >= 192.0;
+        // (rows the several-updates-per-step form covers are "short": one wave per replica, several replicas per workgroup)
+        // -- while the structure is L2 resident or the replicas are few: beyond that the form is bound by the cache
+        // fabric (8-byte entries), where the one-wave bit-spin form with packed 4-byte entries stays ahead (assignment
+        // 100 x 100, degree 198, 20 MB: 1024 replicas 1.3e9 -> 3.7e9 attempts/s, 4096 replicas 6.3e9 -> 4.0e9)
+        const bool rows_medium = csr_rows_medium(e) && csr_updates_per_step(e) >= 4 && e->tune_waves <= 1 &&
+                                 (e->layout_entries * 8 <= (6ll << 20) || R_local <= 1024);
+        const bool long_rows = deg >= 192.0 && !rows_medium;
         // the bit-spin form that would be used: narrow (several replicas per workgroup, 32-bit
         // extents) on short rows, else one replica per workgroup with its row dealt to waves
         const int rpb_bits = (e->rowptr && !long_rows && e->tune_waves <= 1)
@@ -1618,7 +1633,9 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             a.csr_head = (int)std::min<long long>(std::max<long long>(need, 1), 10);
         }
         a.big = e->big_form;
-        a.csr_row_cap = (e->csr && e->max_row_len <= 64) ? (int)std::max<long long>(e->max_row_len, 1) : 0;
+        // (a slotted layout's row extents include the padding to whole 64-entry slots)
+        a.csr_row_cap = (e->csr && e->max_row_len <= 256)
+                            ? (int)std::max<long long>(e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len, 1) : 0;
         a.csr_pair_ahead = csr_updates_per_step(e);
         // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
         a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;

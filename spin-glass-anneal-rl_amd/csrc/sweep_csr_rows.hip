@@ -46,7 +46,10 @@ namespace sga {
 template <int G, int EPL, bool BIG, bool REAL>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kernel(const SweepArgs a) {
     constexpr int LPR = 64 / G;   // lanes per row
-    static_assert((G == 4 || G == 8) && LPR * EPL <= 64, "rows of 16 or 8 lanes, coupling rows of up to 64 entries");
+    // (rows of 65 ... 256 entries: G = 4 with 8 | 16 entries per lane, accept-table builds only -- the canonical
+    //  order of real-valued sums is defined on 64-entry virtual waves, which a lane's 16 consecutive entries straddle)
+    static_assert((G == 4 || G == 8) && LPR * EPL <= 256 && (!REAL || LPR * EPL <= 64),
+                  "rows of 16 or 8 lanes; coupling rows of up to 256 entries (64 for real-valued sums)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,9 +340,16 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
 // the form applies to: production arguments (Philox sites, Metropolis, no per-update traces), int8 spins or the
 // narrow bit-spin layout, 32-bit row extents whose byte offsets fit 32 bits; the engine checks the row lengths
 // (every row <= 64 entries: a.csr_row_cap) and sets a.csr_pair_ahead = 4 | 8
+static bool rows_table_form(const SweepArgs &a) {
+    // The accept-table builds sum a sweep's energy change in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m,
+    // where a table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale.
+    return csr_effective_acc(a, true) == CSR_ACC_F32_TABLE && a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
+}
 bool sweep_csr_rows_applies(const SweepArgs &a) {
-    return (a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 64 &&
-           (a.big == 0 || a.big == 2) && a.rowptr && csr_args_are_lean(a);
+    if (!((a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 256 &&
+          (a.big == 0 || a.big == 2) && a.rowptr && csr_args_are_lean(a)))
+        return false;
+    return a.csr_row_cap <= 64 || (a.csr_pair_ahead == 4 && rows_table_form(a));  // longer rows: integer problems, four per step
 }
 
 template <bool BIG, bool REAL>
@@ -353,9 +363,14 @@ static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream
         kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG, REAL>
              : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG, REAL> : sweep_csr_rows_kernel<8, 8, BIG, REAL>;
     } else {                      // rows of 16 lanes
-        epl = cap <= 16 ? 1 : cap <= 32 ? 2 : 4;
+        epl = cap <= 16 ? 1 : cap <= 32 ? 2 : cap <= 64 ? 4 : cap <= 128 ? 8 : 16;
         kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG, REAL>
-                                                                 : sweep_csr_rows_kernel<4, 4, BIG, REAL>;
+             : epl == 4 ? sweep_csr_rows_kernel<4, 4, BIG, REAL> : nullptr;
+        if constexpr (!REAL) {
+            if (epl == 8) kern = sweep_csr_rows_kernel<4, 8, BIG, false>;
+            if (epl == 16) kern = sweep_csr_rows_kernel<4, 16, BIG, false>;
+        }
+        if (!kern) return hipErrorInvalidValue;
     }
     const hipError_t e = launch_csr_kernel(kern, a, false, BIG, waves_per_block, st);
     note_sweep_kernel("sweep_csr_rows_kernel<%d rows, %d entries per lane, %s spins, %s> x %d replica(s) per workgroup", g, epl,
@@ -364,11 +379,9 @@ static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream
 }
 
 hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
-    // The accept-table builds sum a sweep's energy change in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m,
-    // where a table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale.  Everything else --
-    // real-valued couplings, integer problems beyond that -- runs the fp64 builds (exact for integers too).
-    const bool table = csr_effective_acc(a, true) == CSR_ACC_F32_TABLE && a.table_m < 2048 &&
-                       (long long)a.n * a.table_m < (1ll << 31);
+    // Everything but the accept-table class -- real-valued couplings, integer problems with larger sums -- runs the
+    // fp64 builds (exact for integers too).
+    const bool table = rows_table_form(a);
     if (a.big) return table ? launch_rows<true, false>(a, waves_per_block, st) : launch_rows<true, true>(a, waves_per_block, st);
     return table ? launch_rows<false, false>(a, waves_per_block, st) : launch_rows<false, true>(a, waves_per_block, st);
 }
