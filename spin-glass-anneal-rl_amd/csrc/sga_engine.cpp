@@ -940,8 +940,7 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
 // Rows of 65 ... 256 entries (assignment / small scheduling problems: degree 100-250, cache resident, bound by the
 // one-update chain): four per step with 8 | 16 entries per lane, integer problems with the accept table only.
 static bool csr_rows_medium(const sga_engine *e) {
-    return e->csr && e->max_row_len > 64 && e->max_row_len <= 256 && e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0 &&
-           e->table_m < 2048 && (long long)e->n * e->table_m < (1ll << 31);
+    return e->csr && e->max_row_len > 64 && e->max_row_len <= 256 && e->csr_acc == sga::CSR_ACC_F32_TABLE && e->table_m > 0;
 }
 static int csr_updates_per_step(const sga_engine *e) {
     if (!e->csr || e->max_row_len > 256) return 0;

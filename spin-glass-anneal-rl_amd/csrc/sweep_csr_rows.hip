@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
     double T = 1.0;
-    int dE_lane = 0;  // this lane's share of the sweep's energy change (integer; see step())
+    double dE_lane = 0.0;  // this lane's share of the sweep's energy change (an integer: exact; see step())
     const int steps = (n + G - 1) / G;  // steps per sweep (the last one may hold fewer than G updates)
 
     struct Step {
@@ -249,8 +249,9 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
                     }
                 } else {
                     // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
-                    // at the end of the sweep (exact in any order; a wave sum per step cost ~14 instructions)
-                    dE_lane += (flip && j == 0) ? (int)dE : 0;
+                    // at the end of the sweep (exact in any order, far below 2^53; a wave sum per step cost ~14
+                    // instructions)
+                    dE_lane += (flip && j == 0) ? dE : 0.0;
                 }
                 nacc += (unsigned long long)__builtin_popcountll(acc);
             }
@@ -321,8 +322,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             S1 = S2;
             S2 = t;
         }
-        E += (double)wave_sum(dE_lane);  // |sum| < 2^31: sweep_csr_rows_applies
-        dE_lane = 0;
+        E += wave_sum(dE_lane);
+        dE_lane = 0.0;
         if (lane == 0 && a.energy_trace) a.energy_trace[(long long)k * a.R + r] = E;
         if (E < bestE && !a.no_best) {  // annealing/gpu_annealer.py:151-153
             bestE = E;
@@ -340,10 +341,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
 // the form applies to: production arguments (Philox sites, Metropolis, no per-update traces), int8 spins or the
 // narrow bit-spin layout, 32-bit row extents whose byte offsets fit 32 bits; the engine checks the row lengths
 // (every row <= 64 entries: a.csr_row_cap) and sets a.csr_pair_ahead = 4 | 8
-static bool rows_table_form(const SweepArgs &a) {
-    // The accept-table builds sum a sweep's energy change in 32-bit integers per lane: n / 4 moves of |dE| <= 2 table_m,
-    // where a table_m below the engine's cap of 2048 is the true bound of |s_i F_i| * table_scale.
-    return csr_effective_acc(a, true) == CSR_ACC_F32_TABLE && a.table_m < 2048 && (long long)a.n * a.table_m < (1ll << 31);
+static bool rows_table_form(const SweepArgs &a) {  // integer problems (moves beyond the table's 2048 entries: computed)
+    return csr_effective_acc(a, true) == CSR_ACC_F32_TABLE;
 }
 bool sweep_csr_rows_applies(const SweepArgs &a) {
     if (!((a.csr_pair_ahead == 4 || a.csr_pair_ahead == 8) && a.csr_row_cap >= 1 && a.csr_row_cap <= 256 &&

@@ -544,6 +544,8 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     (300, 100, 1, False),    # rows of ~80-130 entries: 8 entries per lane
     (420, 200, 2, True),     # rows of ~170-250 entries: 16 entries per lane; half-integer fields
     (144, 22, 1, False),     # (control: short rows through the same test)
+    (300, 100, 60, False),   # penalties: moves beyond the accept table's 2048 entries (computed, not looked up)
+    (144, 22, 120, True),
 ])
 def test_csr_several_updates_per_step_medium_rows(sg, n, deg, amp, half_h, bits, monkeypatch):
     """Integer problems whose rows hold 65 ... 256 entries (assignment / small scheduling instances) run four
