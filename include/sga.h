@@ -54,7 +54,9 @@ typedef struct sga_engine sga_engine;
 #define SGA_ERR_UNSUPPORTED -4
 
 /* coupling storage in HBM */
-#define SGA_J_AUTO 0 /* bit-planes if J is ternary and n >= 4096, int8 if integer in [-127,127], else fp32 */
+#define SGA_J_AUTO 0 /* bit-planes if J is ternary and n >= 4096, int8 if integer in [-127,127], else fp32;
+                        * a sparse integer matrix (n >= 4096, <= 256 non-zeros per row) is kept as CSR when the
+                        * field cache is OFF, or AUTO on a problem the cached-field sweep cannot serve */
 #define SGA_J_F32 1
 #define SGA_J_I8 2
 #define SGA_J_T2 3 /* J in {-1,0,+1} as two bit-planes (sign, non-zero): 2 bits per coupling */

@@ -167,6 +167,7 @@ struct sga_engine {
     int table_m = 0;  // integer problems: largest possible |dE| / 2 (0 = not integer / too big)
     // cached-local-field sweep (sweep_clf_impl.h)
     int field_cache = SGA_FIELD_CACHE_OFF;  // what the caller asked for
+    bool from_dense = false;  // CSR problem built from a sparse matrix handed over dense (sga_set_dense, SGA_J_AUTO)
     bool clf_problem = false;  // dense, one model, J and h integer valued, symmetric, zero diagonal, sums < 2^24
     float row_abs_max = 0.0f;  // max_i(sum_j |J_ij| + |h_i|)
     int clf_scale = 1, clf_bits = 16;
@@ -770,6 +771,53 @@ int sga_set_dense(sga_engine *e, const float *J, int64_t ldJ, const float *h, in
     return sga_set_dense_batch(e, J, ldJ, h, n, 1, storage);
 }
 
+static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, const int32_t *colidx, const float *val,
+                          const float *h, int n, int64_t nnz);
+
+// Sparse couplings handed over as a dense matrix (the reference's IsingModel is dense by default; its assignment
+// and scheduling encoders fill 1-2 % of it): with SGA_J_AUTO, one model, n >= 4096, integer-valued J and no row of
+// more than 256 non-zeros the problem is taken as CSR -- a proposal then reads its row's entries instead of n
+// couplings, and the several-updates-per-step forms apply (sweep_csr_rows.hip).  Integer row sums are exact in
+// either form, so the chain is the dense forms' bit for bit.  When: see the call (the cached-field sweep is a dense
+// form); never under SGA_NO_SPARSE_ROUTE (A/B switch).
+// Returns SGA_OK with *taken = true when the problem was set as CSR.
+static int route_sparse_dense(sga_engine *e, const float *src, long long ld_src, const float *h, int n, bool *taken) {
+    *taken = false;
+    int *nnz_d = nullptr;
+    HIPCHK(hipMalloc(&nnz_d, sizeof(int) * ((size_t)n + 1)));
+    struct Guard {
+        int *a = nullptr, *b = nullptr, *c = nullptr;
+        float *v = nullptr;
+        ~Guard() { dev_free(a), dev_free(b), dev_free(c), dev_free(v); }
+    } g;
+    g.a = nnz_d;
+    HIPCHK(sga::launch_dense_row_nnz(src, ld_src, n, nnz_d, e->stream));
+    std::vector<int> len((size_t)n), rp((size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(len.data(), nnz_d, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    long long total = 0;
+    int longest = 0;
+    for (int i = 0; i < n; ++i) {
+        rp[(size_t)i] = (int)total;
+        total += len[(size_t)i];
+        longest = std::max(longest, len[(size_t)i]);
+    }
+    rp[(size_t)n] = (int)total;
+    if (longest > 256 || total == 0 || total >= (long long)INT32_MAX) return SGA_OK;
+    HIPCHK(hipMalloc(&g.b, sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(hipMalloc(&g.c, sizeof(int) * (size_t)total));
+    HIPCHK(hipMalloc(&g.v, sizeof(float) * (size_t)total));
+    HIPCHK(hipMemcpyAsync(g.b, rp.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(sga::launch_dense_to_csr(src, ld_src, n, g.b, g.c, g.v, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int rc = set_csr_common(e, g.b, false, g.c, g.v, h, n, total);
+    if (rc == SGA_OK) {
+        *taken = true;
+        e->from_dense = true;
+    }
+    return rc;
+}
+
 int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float *h, int n,
                         int n_models, int storage) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
@@ -782,6 +830,7 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     e->free_replicas();
     e->free_problem();
     e->csr = false;
+    e->from_dense = false;
     e->table_m = 0;
     e->n = n;
     e->n_models = n_models;
@@ -851,6 +900,17 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     e->clf_scale = (nonint & 2u) ? 2 : 1;
     e->clf_problem = (nonint & 5u) == 0u && (double)m * e->clf_scale < 16777216.0 && e->consistent_dE && n_models == 1;
     e->clf_bits = (double)m * e->clf_scale < 32768.0 ? 16 : 32;
+    // Sparse matrix?  (route_sparse_dense above.)  Taken when the caller asked for one row read per proposal
+    // (field cache OFF), or left the choice (AUTO) on a problem the cached-field sweep cannot serve: where that
+    // sweep applies it is the better form while few proposals are accepted (C2b, 1024 replicas, acceptance 2 %:
+    // dense int8 rows 7.7e8, as CSR four updates per step 4.3e9, cached fields 1.06e10 attempts/s).
+    if (storage == SGA_J_AUTO && n_models == 1 && n >= 4096 && (nonint & 1u) == 0u &&
+        (e->field_cache == SGA_FIELD_CACHE_OFF || (e->field_cache == SGA_FIELD_CACHE_AUTO && !e->clf_problem)) &&
+        std::getenv("SGA_NO_SPARSE_ROUTE") == nullptr) {
+        bool taken = false;
+        const int rcr = route_sparse_dense(e, src, ld_src, h, n, &taken);  // (h: the caller's pointer)
+        if (rcr != SGA_OK || taken) return rcr;
+    }
     int rc = pack_dense(e, src, ld_src);
     if (rc == SGA_OK) rc = ensure_packed(e);
     // the source (the caller's buffer, or the staging copy about to be released) is done with
@@ -1030,6 +1090,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     e->free_replicas();
     e->free_problem();
     e->csr = true;
+    e->from_dense = false;
     e->n = n;
     e->n_models = 1;
     e->nnz = nnz;
@@ -2384,6 +2445,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                           : 1);
     if (e->csr && csr_updates_per_step(e) >= 4 && e->waves <= 1 && (e->big_form == 0 || e->big_form == 2) && e->rowptr)
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp), " updates_per_step=%d", csr_updates_per_step(e));
+    if (e->csr && e->from_dense) std::strncat(tmp, " source=dense-matrix(sparse)", sizeof(tmp) - std::strlen(tmp) - 1);
     if (e->csr && e->slotted)
         std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                       " rows=64-entry-slots(+%.1f%%) longest_row_slots=%lld",

@@ -294,6 +294,8 @@ size_t sweep_dense_lds_bytes(long long ld, int table_m, bool acc64);
 // integrality and max_i(sum_j |J_ij| + |h_i|) of a dense problem: out[0] = float bits of the
 // max, out[1] bit 0 = some J is not an integer, bit 1 = some h is not an integer, bit 2 = some h is not a
 // multiple of 1/2
+hipError_t launch_dense_row_nnz(const float *J, long long ld, int n, int *nnz, hipStream_t st);  // sparse matrices given dense
+hipError_t launch_dense_to_csr(const float *J, long long ld, int n, const int *rowptr, int *col, float *val, hipStream_t st);
 hipError_t launch_dense_row_abs_max(const float *J, long long ldJ, const float *h, long long rows,
                                     int n, unsigned int *out, hipStream_t st);
 

@@ -275,6 +275,47 @@ hipError_t launch_pack_cv_rows(const long long *src_ptr, const long long *dst_pt
     return hipGetLastError();
 }
 
+// Sparse couplings handed over as a dense matrix (sga_set_dense with SGA_J_AUTO): non-zeros per row, then the
+// CSR arrays (columns ascending), one wave per row.
+__global__ void __launch_bounds__(256) dense_row_nnz_kernel(const float *__restrict__ J, long long ld, int n, int *__restrict__ nnz) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *row = J + (long long)i * ld;
+    int count = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + lane;
+        count += __builtin_popcountll(__ballot(c < n && row[c] != 0.0f));
+    }
+    if (lane == 0) nnz[i] = count;
+}
+__global__ void __launch_bounds__(256) dense_to_csr_kernel(const float *__restrict__ J, long long ld, int n,
+                                                           const int *__restrict__ rowptr, int *__restrict__ col,
+                                                           float *__restrict__ val) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *row = J + (long long)i * ld;
+    int at = rowptr[i];
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + lane;
+        const float v = c < n ? row[c] : 0.0f;
+        const unsigned long long m = __ballot(v != 0.0f);
+        if (v != 0.0f) {
+            const int k = at + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            col[k] = c;
+            val[k] = v;
+        }
+        at += __builtin_popcountll(m);
+    }
+}
+hipError_t launch_dense_row_nnz(const float *J, long long ld, int n, int *nnz, hipStream_t st) {
+    hipLaunchKernelGGL(dense_row_nnz_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, J, ld, n, nnz);
+    return hipGetLastError();
+}
+hipError_t launch_dense_to_csr(const float *J, long long ld, int n, const int *rowptr, int *col, float *val, hipStream_t st) {
+    hipLaunchKernelGGL(dense_to_csr_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, J, ld, n, rowptr, col, val);
+    return hipGetLastError();
+}
+
 // (column, fp32 value) -> column | int8 value << 24; *bad is set when some value is not an integer in [-127, 127]
 // or some column needs more than 24 bits
 __global__ void __launch_bounds__(256) pack_entries_kernel(const int2 *cv, uint32_t *cvp, long long count, int *bad) {

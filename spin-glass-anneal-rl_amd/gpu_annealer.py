@@ -101,8 +101,8 @@ class GPUAnnealer:
             else N.ARITH_F32
         n = model.n_spins
         with AnnealEngine(dev_idx) as eng:
+            eng.set_field_cache(cfg.field_cache)  # (before the couplings: "on" keeps a sparse matrix dense)
             model.load_into(eng, storage=cfg.coupling_storage)
-            eng.set_field_cache(cfg.field_cache)
             eng.set_update_rule(rule)
             eng.init_replicas(1, seed=fresh_seed(cfg.random_seed), s0=model.spins_int8()[None, :])
             energy_history = [float(eng.energies()[0])]

@@ -127,16 +127,16 @@ class MultiGPUAnnealer:
                                   else torch.device("cpu"))
             dist.broadcast(seed_t, src=0)  # all ranks must share the Philox key
             eng = AnnealEngine(gpu)
-            model.load_into(eng, storage=acfg.coupling_storage)
             eng.set_field_cache(acfg.field_cache)
+            model.load_into(eng, storage=acfg.coupling_storage)
             pt = ShardedTempering(eng, Rl, rank, world, int(seed_t.item()), temps, 1, dist,
                                   torch.device("cuda", gpu))
             engines = [eng]
         else:
             engines = [AnnealEngine(g) for g in cfg.gpu_ids]
             for e in engines:
-                model.load_into(e, storage=acfg.coupling_storage)
                 e.set_field_cache(acfg.field_cache)
+                model.load_into(e, storage=acfg.coupling_storage)
             pt = LocalShardedTempering(engines, Rl, seed, temps, 1)
         done, history = 0, []
         while done < acfg.n_sweeps:

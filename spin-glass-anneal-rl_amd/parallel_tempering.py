@@ -90,8 +90,8 @@ class ParallelTempering:
         best_energy, best_configuration = float("inf"), None
         acc_slot, att_slot = np.zeros(R, np.int64), np.zeros(R, np.int64)
         with AnnealEngine(dev_idx) as eng:
+            eng.set_field_cache(cfg.field_cache)  # (before the couplings: "on" keeps a sparse matrix dense)
             model.load_into(eng, storage=cfg.coupling_storage)
-            eng.set_field_cache(cfg.field_cache)
             eng.set_update_rule(rule)
             eng.init_replicas(R, seed=fresh_seed(cfg.random_seed),
                               s0=None if _replay is None else _replay["s0"])

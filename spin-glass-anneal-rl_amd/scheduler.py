@@ -68,8 +68,8 @@ class SpinGlassScheduler:
         dev = _device_index(self.device)
         e_hist, t_hist = [], []
         with AnnealEngine(dev) as eng:
+            eng.set_field_cache(field_cache)  # (before the couplings: "on" keeps a sparse matrix dense)
             ising_model.load_into(eng, storage=coupling_storage)
-            eng.set_field_cache(field_cache)
             eng.init_replicas(n_replicas, seed=fresh_seed(self.random_seed))
             eng.set_ladder(temps, n_ladders)
             eng.maybe_autotune(n_sweeps, autotune)  # measured launch geometry for long runs

@@ -569,24 +569,36 @@ def test_scheduler_result_does_not_depend_on_autotune(sg):
     assert runs[0].energy_history == runs[1].energy_history
 
 
-@pytest.mark.parametrize("cache", ["off", "on"])
-def test_c2b_assignment_instance_full_size(sg, cache):
+@pytest.mark.parametrize("cache", ["off", "on", "sparse"])
+def test_c2b_assignment_instance_full_size(sg, cache, monkeypatch):
     """BASELINE configs[1] parity instance: 100 agents x 100 tasks one-hot
     penalties (lambda = 100), 10 000 spins dense, 1024 replicas -- with one coupling-row read per
-    proposal and with the cached-local-field sweep (a hot ladder: most proposals are accepted)."""
+    proposal, with the cached-local-field sweep (a hot ladder: most proposals are accepted), and as the
+    engine takes the matrix by itself: 198 of 10 000 couplings per row are non-zero, so `sga_set_dense`
+    keeps it as CSR and the sweeps work on four updates per step ("sparse")."""
     from spin_glass_anneal_rl_amd import encoders as enc
+    from spin_glass_anneal_rl_amd.engine import last_kernel
     b = enc.assignment_ising(100, 100, weight=100.0)
     J, h = torch.from_numpy(b.to_dense()).cuda(), b.fields()
     n, R, seed = 10000, 1024, 77
     temps = np.asarray(sg.temperature_ladder(R, 1.0, 400.0))
+    if cache == "off":
+        monkeypatch.setenv("SGA_NO_SPARSE_ROUTE", "1")
     with sg.AnnealEngine(0) as e:
-        e.set_field_cache(cache)
+        e.set_field_cache("off" if cache == "sparse" else cache)
         e.set_dense(J, h)
-        assert "storage=i8" in e.describe()          # penalties are +-25 / -50: integer
+        if cache == "sparse":
+            assert "csr n=10000 nnz=1980000" in e.describe() and "source=dense-matrix" in e.describe(), e.describe()
+        else:
+            assert "storage=i8" in e.describe()          # penalties are +-25 / -50: integer
         e.init_replicas(R, seed=seed)
         assert ("sweep=cached-local-fields" in e.describe()) == (cache == "on"), e.describe()
+        if cache == "sparse":
+            assert "updates_per_step=4" in e.describe(), e.describe()
         e.set_ladder(temps)
         out = e.sweep(3, energy_trace=True)
+        if cache == "sparse":
+            assert "sweep_csr_rows_kernel" in last_kernel() and "16 entries per lane" in last_kernel(), last_kernel()
         e.exchange()
         e.sweep(2)
         tracked = e.energies()
