@@ -316,6 +316,40 @@ int sga_set_csr_storage(sga_engine *e, int storage);
 #define SGA_FIELD_CACHE_ON 1
 #define SGA_FIELD_CACHE_AUTO 2
 int sga_set_field_cache(sga_engine *e, int mode);
+/* Form-selection options of ONE engine -- the A/B switches of the measurements and what the parity tests use to
+ * force a kernel form -- by name.  None changes a result: every form walks the same chain.  The
+ * environment is read once, in sga_create, for the defaults (variable in brackets); afterwards only these calls
+ * count, so two engines of one process can run different forms.  SGA_ERR_INVALID: unknown key, value out of range.
+ * When a value takes effect: [set] at the next sga_set_dense / sga_set_csr, [init] at the next sga_init_replicas,
+ * [sweep] at the next sga_sweep / sga_recompute_energies.
+ *   "look_ahead"            0 | 1 (default)   dense integer problems: several updates reduced together  [sweep; SGA_NO_LOOK_AHEAD]
+ *   "force_general"         0 (default) | 1   general kernel builds even for production arguments       [sweep; SGA_FORCE_GENERAL]
+ *   "clf_waves"             0 = measured table (default), 1 ... 8: waves per replica of the cached-field sweep [sweep; SGA_CLF_WAVES]
+ *   "clf_solo"              -1 = adaptive (default), 0 | 1: cached-field sweep, one wave evaluates the candidates
+ *                           of a round (busy replicas) instead of every wave its own window            [sweep; SGA_CLF_SOLO]
+ *   "replica_routing"       0 | 1 (default)   SGA_FIELD_CACHE_AUTO routes each replica by its own acceptance (two
+ *                           concurrent launches) instead of the whole launch by the hottest replica    [sweep; SGA_NO_REPLICA_ROUTING]
+ *   "batched_energy"        0 = one pass over the couplings per replica, 1 (default) = all replicas in one pass where
+ *                           that carries the same bits (not for real-valued couplings that need the canonical
+ *                           summation order), 2 = always                                                [sweep; SGA_NO_MFMA_ENERGY]
+ *   "fields_scratch_mb"     256 (default): cap in MiB of the scratch of the all-replica field / energy pass over dense
+ *                           couplings; larger replica sets go through in tiles of 128-replica blocks    [sweep; SGA_FIELDS_SCRATCH_MB]
+ *   "csr_updates_per_step"  -1 = by the longest row (default), 0 = one update at a time, 1 | 2 = pair look-ahead,
+ *                           4 | 8 = that many updates per step (rows <= 256 entries)                    [init, sweep; SGA_CSR_PAIR_AHEAD]
+ *   "tsp_updates_per_step"  -1 = by the number of cities (default), 0 | 1 = one, 2 | 4 | 8              [sweep; SGA_TSP_PARALLEL]
+ *   "sparse_route"          0 | 1 (default)   sga_set_dense keeps a sparse integer matrix as CSR        [set; SGA_NO_SPARSE_ROUTE]
+ *   "csr_slots"             0 | 1 (default)   long-row CSR problems padded to 64-entry slots at set time [set; SGA_NO_CSR_SLOTS]
+ *   "half_integer_table"    0 | 1 (default)   accept table for integer J with half-integer h            [set; SGA_NO_HALF_TABLE]
+ *   "force_csr_acc"         0 (default) ... 3: at least this CSR_ACC class (1 f32, 2 f64, 3 f64 canonical) [set; SGA_FORCE_CSR_ACC]
+ *   "force_dense_canonical" 0 (default) | 1   canonical fp64 order for every fp64-accumulated dense problem [set; SGA_FORCE_DENSE_CANON]
+ *   "zero_slot_every"       0 = 2^21 (default), k: an all-zero slot inside the slotted layout after every k slots [set; SGA_ZERO_SLOT_EVERY]
+ *   "csr_bits"              0 | 1 (default)   bit spins where they keep more replicas LDS resident      [init; SGA_NO_CSR_BITS]
+ *   "force_csr_bits"        0 (default) | 1   CSR sweeps with bit spins whatever the size               [init; SGA_FORCE_CSR_BIG]
+ * sga_option_name enumerates the keys (index 0, 1, ... until SGA_ERR_INVALID).
+ * (No reference counterpart: the reference has one code path, core/spin_dynamics.py:61-152.) */
+int sga_set_option(sga_engine *e, const char *key, int64_t value);
+int sga_get_option(sga_engine *e, const char *key, int64_t *value);
+int sga_option_name(int index, char *buf, int buflen);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
 /* Measured choice of the dense launch geometry: times the sweep kernel for every feasible

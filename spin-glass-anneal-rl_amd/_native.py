@@ -68,6 +68,9 @@ SYMBOLS = [
     ("sga_last_kernel", _i, [C.c_char_p, _i]),
     ("sga_set_csr_storage", _i, [_p, _i]),
     ("sga_set_field_cache", _i, [_p, _i]),
+    ("sga_set_option", _i, [_p, C.c_char_p, _i64]),
+    ("sga_get_option", _i, [_p, C.c_char_p, C.POINTER(_i64)]),
+    ("sga_option_name", _i, [_i, C.c_char_p, _i]),
     ("sga_set_tuning", _i, [_p, _i, _i]),
     ("sga_autotune", _i, [_p, C.POINTER(_d)]),
     ("sga_probe_read_bandwidth", _i, [_i, _i64, _i, C.POINTER(_d)]),

@@ -23,6 +23,48 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
+// ---- engine options (sga_set_option / sga_get_option, include/sga.h) ----------------------------------
+// Form selection switches -- A/B measurements, parity tests that force the slower forms -- are per-engine
+// values behind the C ABI.  The environment is consulted ONCE, in sga_create, for the defaults (the variable
+// named here); nothing else in the library reads it.
+enum Opt {
+    OPT_LOOK_AHEAD, OPT_CLF_WAVES, OPT_SPARSE_ROUTE, OPT_BATCHED_ENERGY, OPT_FORCE_GENERAL, OPT_CSR_UPDATES_PER_STEP,
+    OPT_TSP_PARALLEL, OPT_FORCE_CSR_BITS, OPT_CSR_BITS, OPT_CSR_SLOTS, OPT_HALF_TABLE, OPT_FORCE_CSR_ACC,
+    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_SOLO, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_COUNT
+};
+struct OptDef {
+    const char *key;
+    const char *env;     // environment variable giving the default at sga_create (nullptr: none)
+    int env_presence;    // 1: the variable being set means `env_value`; 0: its integer value is taken
+    long long env_value;
+    long long def, lo, hi;
+};
+constexpr OptDef OPT_DEFS[OPT_COUNT] = {
+    {"look_ahead", "SGA_NO_LOOK_AHEAD", 1, 0, 1, 0, 1},
+    {"clf_waves", "SGA_CLF_WAVES", 0, 0, 0, 0, 8},
+    {"sparse_route", "SGA_NO_SPARSE_ROUTE", 1, 0, 1, 0, 1},
+    {"batched_energy", "SGA_NO_MFMA_ENERGY", 1, 0, 1, 0, 2},
+    {"force_general", "SGA_FORCE_GENERAL", 1, 1, 0, 0, 1},
+    {"csr_updates_per_step", "SGA_CSR_PAIR_AHEAD", 0, 0, -1, -1, 8},
+    {"tsp_updates_per_step", "SGA_TSP_PARALLEL", 0, 0, -1, -1, 8},
+    {"force_csr_bits", "SGA_FORCE_CSR_BIG", 1, 1, 0, 0, 1},
+    {"csr_bits", "SGA_NO_CSR_BITS", 1, 0, 1, 0, 1},
+    {"csr_slots", "SGA_NO_CSR_SLOTS", 1, 0, 1, 0, 1},
+    {"half_integer_table", "SGA_NO_HALF_TABLE", 1, 0, 1, 0, 1},
+    {"force_csr_acc", "SGA_FORCE_CSR_ACC", 0, 0, 0, 0, 3},
+    {"force_dense_canonical", "SGA_FORCE_DENSE_CANON", 1, 1, 0, 0, 1},
+    {"zero_slot_every", "SGA_ZERO_SLOT_EVERY", 0, 0, 0, 0, 1ll << 21},
+    {"clf_solo", "SGA_CLF_SOLO", 0, 0, -1, -1, 1},
+    {"replica_routing", "SGA_NO_REPLICA_ROUTING", 1, 0, 1, 0, 1},
+    {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536},
+};
+int find_option(const char *key) {
+    if (!key) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(key, OPT_DEFS[i].key) == 0) return i;
+    return -1;
+}
+
 #define HIPCHK(expr)                                                                       \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -119,6 +161,7 @@ struct DevOut {
 struct sga_engine {
     int device = 0;
     int cus = 256;  // compute units of the device
+    long long opt[OPT_COUNT];  // sga_set_option values (defaults: OPT_DEFS, the environment read once in sga_create)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
@@ -179,7 +222,14 @@ struct sga_engine {
     // SGA_FIELD_CACHE_AUTO looks at the acceptance of the last sweeps now and then (host read-back of the
     // per-replica counters): an accept costs ~2 us of its replica's chain, so the cached-field sweep only
     // pays while the HOTTEST replica accepts little
-    bool auto_use_clf = false;
+    bool auto_unavailable = false;      // the fields could not be allocated: AUTO stays on the row-per-proposal kernels
+    std::vector<int> route;             // AUTO, per local replica: 0 = cached-field kernel, 1 = row-per-proposal kernel
+    int n_route_clf = 0;                // replicas routed to the cached-field kernel
+    bool route_dirty = true;            // the device copy of the replica lists is stale
+    int *d_rep_lists = nullptr;         // [2][R]: the cached-field kernel's replicas, then the row kernels'
+    hipStream_t aux_stream = nullptr;   // the second launch of a mixed sweep
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    char last_mixed[448] = {0};
     long long auto_mark_attempted = 0;  // per-replica attempts at the last look
     int auto_interval = 4;              // sweeps until the next look (doubles up to 32)
     std::vector<unsigned long long> auto_mark_acc;
@@ -261,7 +311,11 @@ struct sga_engine {
         fields_valid = false;
         dev_free(ybuf);
         ybuf_bytes = 0;
-        auto_use_clf = false;
+        auto_unavailable = false;
+        route.clear();
+        n_route_clf = 0;
+        route_dirty = true;
+        dev_free(d_rep_lists);
         auto_mark_attempted = 0;
         auto_interval = 4;
         auto_mark_acc.clear();
@@ -273,6 +327,11 @@ struct sga_engine {
 namespace {
 
 int elems_per_chunk(bool i8) { return i8 ? 1024 : 256; }
+// Zeroed (column 0, value 0) entries behind the CSR entry array.  The sweep kernels load a row's entries without
+// a bounds test and mask what lies past the row's end when summing: the one-update forms reach up to 64 entries
+// past the last row's first entry (also the wide forms' zero slot), the several-updates-per-step builds for rows of
+// 65 ... 256 entries (sweep_csr_rows.hip: 16 lanes x 8 | 16 entries per lane) up to 256.
+constexpr long long CSR_TAIL_PAD = 256;
 constexpr int T2_ELEMS_PER_CHUNK = 8192;  // 1 KiB of one bit-plane
 long long t2_row_bits(int n) { return ((long long)n + 127) / 128 * 128; }  // 16-byte granules
 
@@ -321,35 +380,59 @@ bool choose_geometry(int n, int epc, int R, int forced_waves, int &W, int &CPW,
 // All replicas' local fields in one pass over the couplings on the matrix cores (fields_dense.hip),
 // then energies and / or the resident fields of the cached-field sweep from them.
 bool fields_pass_applies(const sga_engine *e, int count) {
-    const bool off = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // A/B switch (read per call: tests flip it)
-    return !off && !e->csr && !e->tsp && e->n_models == 1 && count >= 32 && e->J_packed;
+    // option "batched_energy": 0 = off (A/B switch), 1 = where the batched sums carry the same bits as the
+    // per-replica kernels', 2 = always.  Real-valued couplings that need the canonical summation order keep the
+    // per-replica kernels under 1: the matrix-core pass sums a row in k-order, and the fp32-rounded row sum could
+    // differ in its last bit with the number of replicas recomputed together (sga_set_spins: one; a shard: R_local).
+    const long long mode = e->opt[OPT_BATCHED_ENERGY];
+    if (mode == 0 || (mode == 1 && e->acc_canon)) return false;
+    return !e->csr && !e->tsp && e->n_models == 1 && count >= 32 && e->J_packed;
 }
+// The pass writes Y = S J^T for the replicas it is given into a scratch buffer ([tile][ldj] int32 | fp32) before
+// the finish kernel reduces it.  The scratch is bounded: replica sets whose Y would exceed the cap go
+// through in tiles of whole 128-replica blocks (option "fields_scratch_mb", 256; one more pass over J per tile: 16 384 replicas of 10 000 spins =
+// three passes over 100 MB instead of 655 MB of scratch kept for the life of the replicas), and a failed
+// allocation halves the tile before giving up with SGA_ERR_MEMORY -- which the callers treat as "this fast path is
+// not available" (per-replica energy kernels; SGA_FIELD_CACHE_AUTO stays on the row-per-proposal kernels).
 int fields_pass(sga_engine *e, int r0, int count, double *energy, void *fields) {
-    const size_t need = sizeof(float) * (size_t)count * (size_t)e->ldj;
-    if (need > e->ybuf_bytes) {
+    const size_t row = sizeof(float) * (size_t)e->ldj;
+    long long tile = count;
+    const size_t scratch_cap = (size_t)e->opt[OPT_FIELDS_SCRATCH_MB] << 20;  // option "fields_scratch_mb" (256)
+    const long long cap_rows = std::max<long long>(128, (long long)(scratch_cap / row) / 128 * 128);
+    if (tile > cap_rows) tile = cap_rows;
+    while (row * (size_t)tile > e->ybuf_bytes) {
         dev_free(e->ybuf);
         e->ybuf_bytes = 0;
-        HIPCHK(hipMalloc(&e->ybuf, need));
-        e->ybuf_bytes = need;
+        if (hipMalloc(&e->ybuf, row * (size_t)tile) == hipSuccess) {
+            e->ybuf_bytes = row * (size_t)tile;
+            break;
+        }
+        (void)hipGetLastError();  // (cleared: the caller may go on without this pass)
+        e->ybuf = nullptr;
+        if (tile <= 128) return fail(SGA_ERR_MEMORY, "no memory for the scratch of the all-replica field pass");
+        tile = std::max<long long>(128, tile / 2 / 128 * 128);
     }
-    sga::FieldsArgs f{};
-    f.J = e->J_packed;
-    f.spins = e->spins + (long long)r0 * e->sstride;
-    f.Y = e->ybuf;
-    f.h = e->h;
-    f.energy = energy;
-    f.fields = fields;
-    f.ldj = e->ldj;
-    f.ldy = e->ldj;
-    f.ldf = e->ldf;
-    f.n = e->n;
-    f.R = count;
-    f.sstride = e->sstride;
-    f.field_bits = fields ? e->clf_bits : 0;
-    f.field_scale = e->clf_scale;
     const int mode = e->want_i8 ? 0 : (e->acc64 ? 2 : 1);
-    HIPCHK(sga::launch_fields_dense(f, mode, e->stream));
-    HIPCHK(sga::launch_fields_finish(f, mode == 0, e->stream));
+    const size_t fbytes = (size_t)(e->clf_bits / 8);
+    for (long long t0 = 0; t0 < count; t0 += tile) {
+        sga::FieldsArgs f{};
+        f.J = e->J_packed;
+        f.spins = e->spins + (long long)(r0 + t0) * e->sstride;
+        f.Y = e->ybuf;
+        f.h = e->h;
+        f.energy = energy ? energy + t0 : nullptr;
+        f.fields = fields ? static_cast<unsigned char *>(fields) + (size_t)t0 * (size_t)e->ldf * fbytes : nullptr;
+        f.ldj = e->ldj;
+        f.ldy = e->ldj;
+        f.ldf = e->ldf;
+        f.n = e->n;
+        f.R = (int)std::min<long long>(tile, count - t0);
+        f.sstride = e->sstride;
+        f.field_bits = fields ? e->clf_bits : 0;
+        f.field_scale = e->clf_scale;
+        HIPCHK(sga::launch_fields_dense(f, mode, e->stream));
+        HIPCHK(sga::launch_fields_finish(f, mode == 0, e->stream));
+    }
     return SGA_OK;
 }
 
@@ -374,7 +457,11 @@ bool clf_active(const sga_engine *e) {
 int ensure_fields(sga_engine *e) {
     if (e->fields_valid && e->fields) return SGA_OK;
     e->ldf = (e->ldj + 127) / 128 * 128;
-    if (!e->fields) HIPCHK(hipMalloc(&e->fields, (size_t)e->R * (size_t)e->ldf * (size_t)(e->clf_bits / 8)));
+    if (!e->fields && hipMalloc(&e->fields, (size_t)e->R * (size_t)e->ldf * (size_t)(e->clf_bits / 8)) != hipSuccess) {
+        (void)hipGetLastError();
+        e->fields = nullptr;
+        return fail(SGA_ERR_MEMORY, "no memory for the resident local fields of the cached-field sweep");
+    }
     int rc = fields_pass(e, 0, e->R, nullptr, e->fields);  // (any replica count: short tiles are clamped)
     if (rc != SGA_OK) return rc;
     e->fields_valid = true;
@@ -382,19 +469,25 @@ int ensure_fields(sga_engine *e) {
 }
 
 int recompute_energy_range(sga_engine *e, int r0, int count) {
-    if (fields_pass_applies(e, count)) return fields_pass(e, r0, count, e->energy + r0, nullptr);
-    const bool no_csr_all = std::getenv("SGA_NO_MFMA_ENERGY") != nullptr;  // (one A/B switch for both passes)
-    if (e->csr && !e->tsp && count >= 64 && !no_csr_all) {
+    if (fields_pass_applies(e, count)) {
+        const int rc = fields_pass(e, r0, count, e->energy + r0, nullptr);
+        if (rc != SGA_ERR_MEMORY) return rc;  // (no room for its scratch: the per-replica kernels below need none)
+    }
+    const long long batched = e->opt[OPT_BATCHED_ENERGY];  // (one switch for both passes)
+    const bool csr_all = batched == 2 || (batched == 1 && e->csr_acc != sga::CSR_ACC_F64_CANON);
+    if (e->csr && !e->tsp && count >= 64 && csr_all) {
         // all replicas in one pass over the entries: spins transposed to bits, 32 replicas per lane
         // row groups: enough (group, replica word) threads to fill the chip -- ~4 waves per SIMD -- whatever
         // the replica count (256 replicas = 8 words: 4096 groups left half the SIMDs without a wave)
         const int words = (count + 31) / 32;
         const int groups = std::max(1, std::min(e->n, std::max(1024, 262144 / words)));
-        HIPCHK(e->csr_energy.reserve(sga::csr_energy_scratch_bytes(e->n, count, groups)));
-        const bool exact32 = e->csr_acc == sga::CSR_ACC_F32_TABLE || e->csr_acc == sga::CSR_ACC_F32;
-        HIPCHK(sga::launch_energy_csr_all(e->rowptr64, e->cv, e->h, e->spins + (long long)r0 * e->sstride, e->sstride, e->n,
-                                          count, groups, exact32, e->csr_energy.ptr, e->energy + r0, e->stream));
-        return SGA_OK;
+        if (e->csr_energy.reserve(sga::csr_energy_scratch_bytes(e->n, count, groups)) == hipSuccess) {
+            const bool exact32 = e->csr_acc == sga::CSR_ACC_F32_TABLE || e->csr_acc == sga::CSR_ACC_F32;
+            HIPCHK(sga::launch_energy_csr_all(e->rowptr64, e->cv, e->h, e->spins + (long long)r0 * e->sstride, e->sstride,
+                                              e->n, count, groups, exact32, e->csr_energy.ptr, e->energy + r0, e->stream));
+            return SGA_OK;
+        }
+        (void)hipGetLastError();  // no room for the transposed spin bits / partial sums: one pass per replica instead
     }
     sga::EnergyArgs a{};
     a.J = e->J_packed;
@@ -505,7 +598,7 @@ int pack_dense(sga_engine *e, const float *src, long long ld_src) {
 extern "C" {
 
 const char *sga_last_error(void) { return g_last_error.c_str(); }
-int sga_version(void) { return 300; }  // round 2: + sga_exchange_pairs, sga_set_tsp, sga_set_wolff_replay, state blob v2
+int sga_version(void) { return 400; }  // round 4: + sga_set_option / sga_get_option / sga_option_name, per-replica routing
 
 int sga_create(int device, sga_engine **out) {
     if (!out) return fail(SGA_ERR_INVALID, "out is NULL");
@@ -521,6 +614,12 @@ int sga_create(int device, sga_engine **out) {
     sga_engine *eng = new (std::nothrow) sga_engine();
     if (!eng) return fail(SGA_ERR_MEMORY, "host allocation failed");
     eng->device = device;
+    for (int i = 0; i < OPT_COUNT; ++i) {  // the ONE place the library reads the environment
+        const OptDef &d = OPT_DEFS[i];
+        eng->opt[i] = d.def;
+        const char *v = d.env ? std::getenv(d.env) : nullptr;
+        if (v) eng->opt[i] = d.env_presence ? d.env_value : std::max(d.lo, std::min(d.hi, (long long)std::atoll(v)));
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
@@ -560,6 +659,9 @@ void sga_destroy(sga_engine *e) {
     e->csr_energy.release();
     dev_free(e->d_count);
     dev_free(e->d_flags);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
+    if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -569,6 +671,33 @@ int sga_set_stream(sga_engine *e, void *hip_stream) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return SGA_OK;
+}
+
+int sga_set_option(sga_engine *e, const char *key, int64_t value) {
+    if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
+    const int i = find_option(key);
+    if (i < 0) return fail(SGA_ERR_INVALID, std::string("unknown option: ") + (key ? key : "(null)"));
+    const OptDef &d = OPT_DEFS[i];
+    if (value < d.lo || value > d.hi)
+        return fail(SGA_ERR_INVALID, std::string("option ") + key + ": value outside [" + std::to_string(d.lo) + ", " +
+                                         std::to_string(d.hi) + "]");
+    e->opt[i] = (long long)value;
+    return SGA_OK;
+}
+
+int sga_get_option(sga_engine *e, const char *key, int64_t *value) {
+    if (!e || !value) return fail(SGA_ERR_INVALID, "NULL argument");
+    const int i = find_option(key);
+    if (i < 0) return fail(SGA_ERR_INVALID, std::string("unknown option: ") + (key ? key : "(null)"));
+    *value = (int64_t)e->opt[i];
+    return SGA_OK;
+}
+
+int sga_option_name(int index, char *buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(SGA_ERR_INVALID, "bad arguments");
+    if (index < 0 || index >= OPT_COUNT) return fail(SGA_ERR_INVALID, "no such option");
+    std::snprintf(buf, (size_t)buflen, "%s", OPT_DEFS[index].key);
     return SGA_OK;
 }
 
@@ -593,6 +722,12 @@ int sga_set_field_cache(sga_engine *e, int mode) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (mode != SGA_FIELD_CACHE_OFF && mode != SGA_FIELD_CACHE_ON && mode != SGA_FIELD_CACHE_AUTO)
         return fail(SGA_ERR_INVALID, "bad field-cache mode");
+    // A sparse matrix handed over dense with the cache OFF was kept as CSR and its dense source released: the
+    // cached-field sweep (a dense form) cannot serve it any more.  Said here, not at every later sga_sweep.
+    if (mode == SGA_FIELD_CACHE_ON && e->csr && e->from_dense)
+        return fail(SGA_ERR_UNSUPPORTED, "sga_set_field_cache(ON) after sga_set_dense: this sparse matrix was kept as CSR "
+                                         "because the field cache was OFF when it was set -- call sga_set_field_cache "
+                                         "before sga_set_dense (or hand the matrix over with an explicit storage)");
     e->field_cache = mode;
     return SGA_OK;
 }
@@ -779,7 +914,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
 // more than 256 non-zeros the problem is taken as CSR -- a proposal then reads its row's entries instead of n
 // couplings, and the several-updates-per-step forms apply (sweep_csr_rows.hip).  Integer row sums are exact in
 // either form, so the chain is the dense forms' bit for bit.  When: see the call (the cached-field sweep is a dense
-// form); never under SGA_NO_SPARSE_ROUTE (A/B switch).
+// form); never with option "sparse_route" = 0 (A/B switch).
 // Returns SGA_OK with *taken = true when the problem was set as CSR.
 static int route_sparse_dense(sga_engine *e, const float *src, long long ld_src, const float *h, int n, bool *taken) {
     *taken = false;
@@ -890,7 +1025,7 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
         const bool any = hflags[5] != 0;
         const int span = (hflags[5] - 1024) - (1024 - hflags[6]) + 1;
         e->acc_canon = e->acc64 && any && span + carry > 52;
-        if (std::getenv("SGA_FORCE_DENSE_CANON") != nullptr) e->acc_canon = e->acc64;  // parity tests
+        if (e->opt[OPT_FORCE_DENSE_CANON]) e->acc_canon = e->acc64;  // parity tests
     }
     // integer problem: tabulate exp(float32(-2k/T)) for the moves k <= min(M, 2048) per sweep
     if (nonint == 0u && m >= 1.0f && m < 16777216.0f) e->table_m = (int)std::min(m, 2048.0f);
@@ -906,7 +1041,7 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // dense int8 rows 7.7e8, as CSR four updates per step 4.3e9, cached fields 1.06e10 attempts/s).
     if (storage == SGA_J_AUTO && n_models == 1 && n >= 4096 && (nonint & 1u) == 0u &&
         (e->field_cache == SGA_FIELD_CACHE_OFF || (e->field_cache == SGA_FIELD_CACHE_AUTO && !e->clf_problem)) &&
-        std::getenv("SGA_NO_SPARSE_ROUTE") == nullptr) {
+        e->opt[OPT_SPARSE_ROUTE] != 0) {
         bool taken = false;
         const int rcr = route_sparse_dense(e, src, ld_src, h, n, &taken);  // (h: the caller's pointer)
         if (rcr != SGA_OK || taken) return rcr;
@@ -930,8 +1065,8 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
 static int build_layout(sga_engine *e, const std::vector<long long> &src, bool slotted) {
     const int n = e->n;
     long long ZERO_SLOT_EVERY = 1ll << 21;
-    if (const char *every = std::getenv("SGA_ZERO_SLOT_EVERY"))  // parity tests: zero slots inside small layouts
-        ZERO_SLOT_EVERY = std::max(1ll, std::min(ZERO_SLOT_EVERY, std::atoll(every)));
+    if (e->opt[OPT_ZERO_SLOT_EVERY] > 0)  // parity tests: zero slots inside small layouts
+        ZERO_SLOT_EVERY = std::max(1ll, std::min(ZERO_SLOT_EVERY, e->opt[OPT_ZERO_SLOT_EVERY]));
     std::vector<long long> dst((size_t)n + 1);
     std::vector<int4> info(slotted ? (size_t)n : 0);
     std::vector<int32_t> narrow;
@@ -992,11 +1127,11 @@ static int build_layout(sga_engine *e, const std::vector<long long> &src, bool s
 }
 
 // Narrow CSR forms of integer problems whose longest row has <= 64 entries: 0 = one update at a time,
-// 1 | 2 = the pair look-ahead (opt-in, SGA_CSR_PAIR_AHEAD: round 3 measured -1 ... +3 % on BASELINE configs[2]),
+// 1 | 2 = the pair look-ahead (opt-in, option "csr_updates_per_step": round 3 measured -1 ... +3 % on BASELINE configs[2]),
 // 4 | 8 = that many updates per step, one per row of 16 | 8 lanes (sweep_csr_rows.hip; the launcher takes it
 // for production arguments -- Philox sites, Metropolis with the accept table): the default where it applies
 // (profiles/r03_experiments.md 4b: C3, rows of up to 50 entries, 1.0e10 | 2.87e10 | 2.47e10 attempts/s for
-// 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 5.1e10).  SGA_CSR_PAIR_AHEAD=0 turns it off.
+// 1 | 4 | 8 updates per step; degree ~16: 1.0e10 | 3.7e10 | 5.1e10).  Option value 0 turns it off.
 // Rows of 65 ... 256 entries (assignment / small scheduling problems: degree 100-250, cache resident, bound by the
 // one-update chain): four per step with 8 | 16 entries per lane, integer problems with the accept table only.
 static bool csr_rows_medium(const sga_engine *e) {
@@ -1007,10 +1142,10 @@ static int csr_updates_per_step(const sga_engine *e) {
     const bool medium = e->max_row_len > 64;
     if (medium && !csr_rows_medium(e)) return 0;
     int v = e->max_row_len <= 32 ? 8 : 4;
-    if (const char *env = std::getenv("SGA_CSR_PAIR_AHEAD")) v = std::atoi(env);
+    if (e->opt[OPT_CSR_UPDATES_PER_STEP] >= 0) v = (int)e->opt[OPT_CSR_UPDATES_PER_STEP];
     if (v != 1 && v != 2 && v != 4 && v != 8) return 0;
     if (medium) v = v >= 4 ? 4 : 0;  // (the pair look-ahead holds one wave-load per row)
-    if (v >= 4 && (e->layout_entries + 64) * 8 >= (1ll << 32)) return 0;  // (32-bit byte offsets of the entries)
+    if (v >= 4 && (e->layout_entries + CSR_TAIL_PAD) * 8 >= (1ll << 32)) return 0;  // (32-bit byte offsets of the entries)
     return v;
 }
 
@@ -1028,8 +1163,8 @@ static int ensure_slotted(sga_engine *e) {
     int rc = he == hipSuccess ? build_layout(e, src, true) : fail(SGA_ERR_DEVICE, hipGetErrorString(he));
     if (rc == SGA_OK) {
         e->cv = nullptr;
-        he = hipMalloc(&e->cv, sizeof(int2) * ((size_t)e->layout_entries + 64));
-        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * 64, e->stream);
+        he = hipMalloc(&e->cv, sizeof(int2) * (size_t)(e->layout_entries + CSR_TAIL_PAD));
+        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * CSR_TAIL_PAD, e->stream);
         if (he == hipSuccess)
             he = sga::launch_pack_cv_rows(old_ptr, e->rowptr64, nullptr, nullptr, old_cv, e->cv, e->n, e->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -1171,7 +1306,7 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
     if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f) {
         e->table_m = (int)std::min(m, 2048.0f);
     } else if ((flags[sga::CSR_NOT_INTEGRAL] & 5) == 0 && m >= 1.0f && m < 8388608.0f &&
-               std::getenv("SGA_NO_HALF_TABLE") == nullptr) {
+               e->opt[OPT_HALF_TABLE] != 0) {
         e->table_m = (int)std::min(2.0f * m, 2048.0f);
         e->table_scale = 2;
     }
@@ -1197,20 +1332,20 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
             e->csr_acc = sga::CSR_ACC_F64;
         else
             e->csr_acc = sga::CSR_ACC_F64_CANON;
-        if (const char *force = std::getenv("SGA_FORCE_CSR_ACC"))  // parity tests: the slower forms
-            e->csr_acc = std::max(e->csr_acc, std::min(3, std::atoi(force)));
+        if (e->opt[OPT_FORCE_CSR_ACC] > 0)  // parity tests: the slower forms
+            e->csr_acc = std::max(e->csr_acc, std::min(3, (int)e->opt[OPT_FORCE_CSR_ACC]));
     }
     // The layout the kernels read: (column, value) interleaved, one 8-byte load per entry.  Long
     // rows (mean degree >= 192: the problems that run the wide forms) are padded to whole 64-entry
-    // slots; +64 zeroed entries behind the array (an empty last row's slot 0).
+    // slots; CSR_TAIL_PAD zeroed entries behind the array (an empty last row's slot 0; unmasked row loads).
     long long *src_ptr = nullptr;  // the caller's extents, on the device, while rows are packed
     HIPCHK(hipMalloc(&src_ptr, sizeof(long long) * np1));
     he = hipMemcpyAsync(src_ptr, e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToDevice, e->stream);
-    int rc = he == hipSuccess ? build_layout(e, src, avg_deg >= 192.0 && std::getenv("SGA_NO_CSR_SLOTS") == nullptr)
+    int rc = he == hipSuccess ? build_layout(e, src, avg_deg >= 192.0 && e->opt[OPT_CSR_SLOTS] != 0)
                               : fail(SGA_ERR_DEVICE, hipGetErrorString(he));
     if (rc == SGA_OK) {
-        he = hipMalloc(&e->cv, sizeof(int2) * ((size_t)e->layout_entries + 64));
-        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * 64, e->stream);
+        he = hipMalloc(&e->cv, sizeof(int2) * (size_t)(e->layout_entries + CSR_TAIL_PAD));
+        if (he == hipSuccess) he = hipMemsetAsync(e->cv + e->layout_entries, 0, sizeof(int2) * CSR_TAIL_PAD, e->stream);
         if (he == hipSuccess) he = sga::launch_pack_cv_rows(src_ptr, e->rowptr64, ci, vv, nullptr, e->cv, n, e->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
         if (he != hipSuccess) rc = fail(he == hipErrorOutOfMemory ? SGA_ERR_MEMORY : SGA_ERR_DEVICE, hipGetErrorString(he));
@@ -1397,13 +1532,13 @@ static int init_replicas_body(sga_engine *e, int R_local, int R_global, int repl
                                  ? sga::csr_bits_waves_per_block(bits_stride, e->table_m) : 0;
         const bool narrow_bits = rpb_bits >= 2;
         // Spins as bits in LDS: beyond the int8 capacity or the 32-bit extents
-        // (SGA_FORCE_CSR_BIG: parity tests run the small cases through the same forms) ...
+        // (option "force_csr_bits": parity tests run the small cases through the same forms) ...
         bool bits = sga::csr_waves_per_block(e->sstride, 0) < 1 || !e->rowptr ||
-                    std::getenv("SGA_FORCE_CSR_BIG") != nullptr;
+                    e->opt[OPT_FORCE_CSR_BITS] != 0;
         // ... or when the int8 spins fit, but not for all replicas at once: workgroups beyond the
         // LDS-resident set run as a second, mostly empty round (C4: 50 KB per replica = 3 per CU
         // = 768 of 1024 replicas resident, 4.7e8 attempts/s; as bits all are resident: 6.8e8)
-        if (!bits && bits_fit && std::getenv("SGA_NO_CSR_BITS") == nullptr) {
+        if (!bits && bits_fit && e->opt[OPT_CSR_BITS] != 0) {
             const bool wide_i8 = e->tune_waves > 1 || (e->tune_waves == 0 && long_rows && R_local <= 1024);
             const int rpb = wide_i8 ? 1 : std::max(1, sga::csr_waves_per_block(e->sstride, e->table_m));
             const long long budget = 160 * 1024 - 256;
@@ -1426,7 +1561,7 @@ static int init_replicas_body(sga_engine *e, int R_local, int R_global, int repl
         // addressing, no per-lane bounds tests) beats the entry-addressed int8 form with four replicas
         // per workgroup: 10.6 vs 11.9 ms per sweep.
         const bool many_long = long_rows && R_local > 1024 && e->tune_waves == 0 && bits_fit && e->slotted &&
-                               std::getenv("SGA_NO_CSR_BITS") == nullptr;
+                               e->opt[OPT_CSR_BITS] != 0;
         if (many_long) bits = true;
         e->big = bits;
         e->big_form = !bits ? 0 : (narrow_bits ? 2 : 1);
@@ -1640,43 +1775,109 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         clf = clf_possible(e, &why);
         if (!clf && e->field_cache == SGA_FIELD_CACHE_ON) return fail(SGA_ERR_UNSUPPORTED, why);
     }
+    // AUTO routes every replica by ITS OWN acceptance: the cached-field kernel costs a replica ~1.1 - 1.7 us of its
+    // serial chain per ACCEPTED proposal and next to nothing per rejected one, the row-per-proposal kernels cost
+    // every replica the same per update whatever happens (~0.4 us on bit-planes, ~1.3 us on int8 rows, ~5 us on
+    // fp32 rows at n = 10^4) -- so a replica belongs on the row kernels only while its acceptance exceeds the ratio
+    // of the two (profiles/r04_experiments.md 2), and a ladder with a hot end runs as TWO concurrent launches (two
+    // streams) over disjoint replica lists.  The chain of a replica does not depend on the kernel that walks it.
+    // The run starts on the row kernels (nothing is known yet); the per-replica counters are read back every
+    // 4 ... 32 sweeps.  Option "replica_routing" = 0: one launch, decided by the hottest replica (round 3).
+    int n_clf = clf ? R : 0;  // replicas on the cached-field kernel in this call
     if (clf && e->field_cache == SGA_FIELD_CACHE_AUTO) {
-        // AUTO: the row-per-proposal kernels until the acceptance is known, then whichever pays.  The
-        // cached-field kernel ends with its hottest replica (~2 us per accept, nothing per reject), the
-        // streaming kernels take 0.1 - 1.4 us per update whatever happens: measured break-even at 12 - 19 %
-        // acceptance of the hottest replica (profiles/clf_crossover.py).  The chain is the same either way.
-        if ((long long)e->auto_mark_acc.size() != e->R) {
-            e->auto_mark_acc.assign((size_t)e->R, 0ull);
-            e->auto_mark_attempted = 0;
-            e->auto_interval = 4;
-            e->auto_use_clf = false;
-        }
-        const long long since = e->attempted - e->auto_mark_attempted;
-        if (since >= (long long)e->auto_interval * n || since < 0) {
-            std::vector<unsigned long long> now((size_t)e->R);
-            HIPCHK(hipMemcpyAsync(now.data(), e->n_acc, sizeof(unsigned long long) * e->R, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (since > 0) {
-                unsigned long long top = 0;
-                for (int r2 = 0; r2 < e->R; ++r2) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
-                const double hottest = (double)top / (double)since;
-                e->auto_use_clf = e->auto_use_clf ? hottest < 0.16 : hottest < 0.10;  // (hysteresis)
-                e->auto_interval = std::min(32, e->auto_interval * 2);
+        if (e->auto_unavailable) {
+            n_clf = 0;
+        } else {
+            if ((long long)e->auto_mark_acc.size() != e->R) {
+                e->auto_mark_acc.assign((size_t)e->R, 0ull);
+                e->route.assign((size_t)e->R, 1);  // 1 = row-per-proposal kernel, 0 = cached-field kernel
+                e->n_route_clf = 0;
+                e->auto_mark_attempted = 0;
+                e->auto_interval = 4;
             }
-            e->auto_mark_acc.swap(now);
-            e->auto_mark_attempted = e->attempted;
+            const long long since = e->attempted - e->auto_mark_attempted;
+            if (since >= (long long)e->auto_interval * n || since < 0) {
+                std::vector<unsigned long long> now((size_t)e->R);
+                HIPCHK(hipMemcpyAsync(now.data(), e->n_acc, sizeof(unsigned long long) * e->R, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (since > 0) {
+                    // (enter, leave): acceptance below which a replica is taken onto the cached-field kernel, above
+                    // which it is given back (hysteresis)
+                    const double enter = e->use_t2 ? 0.16 : (e->want_i8 ? 0.50 : 0.90);
+                    const double leave = e->use_t2 ? 0.24 : (e->want_i8 ? 0.66 : 2.0);
+                    bool back = false;
+                    if (e->opt[OPT_REPLICA_ROUTING] != 0) {
+                        for (int r2 = 0; r2 < e->R; ++r2) {
+                            const double acc = (double)(now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]) / (double)since;
+                            int &rt = e->route[(size_t)r2];
+                            if (rt == 0 && acc > leave) rt = 1;
+                            else if (rt == 1 && acc < enter) rt = 0, back = true;
+                        }
+                    } else {
+                        unsigned long long top = 0;
+                        for (int r2 = 0; r2 < e->R; ++r2) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
+                        const double hottest = (double)top / (double)since;
+                        const bool was = e->n_route_clf > 0;
+                        const bool use = was ? hottest < leave : hottest < enter;
+                        back = use && !was;
+                        e->route.assign((size_t)e->R, use ? 0 : 1);
+                    }
+                    int cnt = 0;
+                    for (int v : e->route) cnt += v == 0;
+                    e->n_route_clf = cnt;
+                    if (back) e->fields_valid = false;  // somebody returns from the row kernels: fields are seeded anew
+                    e->auto_interval = std::min(32, e->auto_interval * 2);
+                    e->route_dirty = true;
+                }
+                e->auto_mark_acc.swap(now);
+                e->auto_mark_attempted = e->attempted;
+            }
+            n_clf = e->n_route_clf;
         }
-        clf = e->auto_use_clf;
+        clf = n_clf > 0;
     }
     if (clf) {
         rc = ensure_fields(e);
-        if (rc != SGA_OK) return rc;
+        if (rc == SGA_ERR_MEMORY && e->field_cache == SGA_FIELD_CACHE_AUTO) {
+            // AUTO promises a faster form where it is available, not a failure where the row-per-proposal kernels
+            // (which need none of this memory) would have run: the cache is "not available" for these replicas
+            e->auto_unavailable = true;
+            dev_free(e->fields);
+            e->fields_valid = false;
+            clf = false;
+            n_clf = 0;
+        } else if (rc != SGA_OK) {
+            return rc;
+        }
+    }
+    const bool mixed = clf && n_clf < R;
+    if (mixed) {
+        // replica lists on the device ([0, n_clf): cached-field kernel, [R, R + R - n_clf): row kernels), the second
+        // stream and the two events that fork / join it
+        if (!e->d_rep_lists) HIPCHK(hipMalloc(&e->d_rep_lists, sizeof(int) * 2 * (size_t)R));
+        if (e->route_dirty) {
+            std::vector<int> lists(2 * (size_t)R, 0);
+            int ia = 0, ib = 0;
+            for (int r2 = 0; r2 < R; ++r2) {
+                if (e->route[(size_t)r2] == 0) lists[(size_t)ia++] = r2;
+                else lists[(size_t)R + (size_t)ib++] = r2;
+            }
+            HIPCHK(hipMemcpyAsync(e->d_rep_lists, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            e->route_dirty = false;
+        }
+        if (!e->aux_stream) HIPCHK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+        if (!e->fork_ev) HIPCHK(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+        if (!e->join_ev) HIPCHK(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
+    }
+    if (clf && !mixed) {
         // no row streaming to bound the launch by: many sweeps per launch (a sweep is 0.1 ... 10 ms here:
         // at most 256 of them, so that a launch stays well under a few seconds)
         if (e->tune_spl <= 0) spl = std::min(n_sweeps, 256);
-    } else {
+    } else if (!clf) {
         e->fields_valid = false;  // the row-per-proposal kernels move the spins only
     }
+    e->last_mixed[0] = '\0';
 
     for (int k0 = 0; k0 < n_sweeps; k0 += spl) {
         const int ks = std::min(spl, n_sweeps - k0);
@@ -1697,8 +1898,10 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.csr_row_cap = (e->csr && e->max_row_len <= 256)
                             ? (int)std::max<long long>(e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len, 1) : 0;
         a.csr_pair_ahead = csr_updates_per_step(e);
-        // (SGA_NO_LOOK_AHEAD: A/B switch and the parity tests' cross-check)
-        a.look_ahead = std::getenv("SGA_NO_LOOK_AHEAD") == nullptr ? 1 : 0;
+        // (option "look_ahead" = 0: A/B switch and the parity tests' cross-check)
+        a.look_ahead = e->opt[OPT_LOOK_AHEAD] != 0 ? 1 : 0;
+        a.force_general = e->opt[OPT_FORCE_GENERAL] != 0 ? 1 : 0;
+        a.tsp_parallel = (int)e->opt[OPT_TSP_PARALLEL];
         a.cv = e->cv;
         a.h = e->h;
         a.diag = e->diag;
@@ -1741,21 +1944,61 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (e->timing) {
             HIPCHK(hipEventCreate(&ev0));
-            HIPCHK(hipEventCreate(&ev1));
+            const hipError_t ce = hipEventCreate(&ev1);
+            if (ce != hipSuccess) {
+                (void)hipEventDestroy(ev0);
+                HIPCHK(ce);
+            }
             HIPCHK(hipEventRecord(ev0, st));
         }
-        static const bool force_general = std::getenv("SGA_FORCE_GENERAL") != nullptr;
-        const bool lean = !force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
+        const bool lean = !a.force_general && site_mode == SGA_SITE_RANDOM && arith == SGA_ARITH_F64 &&
                           e->rule == SGA_RULE_METROPOLIS && !a.accept_trace && !a.dE_trace;
+        // the row-per-proposal kernel of a dense problem (all replicas, or the list in aa.rep_list)
+        auto launch_dense_rows = [&](sga::SweepArgs aa, hipStream_t s2) -> hipError_t {
+            if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
+                aa.J = e->J_bits;
+                aa.J_aux = e->J_packed;
+                aa.plane_row_bytes = t2_row_bits(e->n) / 8;
+                aa.plane_bytes = (long long)e->n * aa.plane_row_bytes;
+                aa.diag = e->row_nnz;
+                return sga::launch_sweep_dense_t2(aa, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2, s2);
+            }
+            return sga::launch_sweep_dense(aa, e->want_i8, e->acc64 ? (e->acc_canon ? 2 : 1) : 0, e->waves,
+                                           e->cpw > sga::MAX_CPW ? 0 : e->cpw, s2);
+        };
         hipError_t le;
         if (clf) {
+            sga::SweepArgs ac = a;
             if (e->clf_scale == 2)  // half-integer fields: dE = q for q <= 2 M, tabulated at twice the resolution
-                a.table_m = (int)std::min(2.0 * (double)e->row_abs_max, 2048.0);
-            a.fields = e->fields;
-            a.ldf = e->ldf;
-            a.field_bits = e->clf_bits;
-            a.field_scale = e->clf_scale;
-            le = sga::launch_sweep_clf(a, e->want_i8, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus), st);
+                ac.table_m = (int)std::min(2.0 * (double)e->row_abs_max, 2048.0);
+            ac.fields = e->fields;
+            ac.ldf = e->ldf;
+            ac.field_bits = e->clf_bits;
+            ac.field_scale = e->clf_scale;
+            ac.clf_solo = (int)e->opt[OPT_CLF_SOLO];
+            const int cw = sga::sweep_clf_waves(e->ldj, e->want_i8, mixed ? n_clf : e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]);
+            if (!mixed) {
+                le = sga::launch_sweep_clf(ac, e->want_i8, cw, st);
+            } else {
+                // two launches over disjoint replica lists, side by side: the cached-field kernel on the engine's
+                // stream, the row-per-proposal kernel on the second one, forked and joined by events
+                ac.rep_list = e->d_rep_lists;
+                ac.rep_count = n_clf;
+                a.rep_list = e->d_rep_lists + R;
+                a.rep_count = R - n_clf;
+                le = hipEventRecord(e->fork_ev, st);
+                if (le == hipSuccess) le = hipStreamWaitEvent(e->aux_stream, e->fork_ev, 0);
+                if (le == hipSuccess) le = sga::launch_sweep_clf(ac, e->want_i8, cw, st);
+                char first[200];
+                std::snprintf(first, sizeof(first), "%s", sga::last_sweep_kernel());
+                if (le == hipSuccess) le = launch_dense_rows(a, e->aux_stream);
+                if (le == hipSuccess) le = hipEventRecord(e->join_ev, e->aux_stream);
+                if (le == hipSuccess) le = hipStreamWaitEvent(st, e->join_ev, 0);
+                if (le != hipSuccess) (void)hipStreamSynchronize(e->aux_stream);
+                std::snprintf(e->last_mixed, sizeof(e->last_mixed), "mixed launch: %d replica(s) on %s || %d on %s", n_clf,
+                              first, R - n_clf, sga::last_sweep_kernel());
+                sga::note_sweep_kernel("%s", e->last_mixed);
+            }
         } else if (wolff) {
             const sga::WolffArgs wa{e->wolff_u, e->wolff_cap, e->wolff_cursor};
             le = sga::launch_sweep_wolff(a, wa, e->csr, e->want_i8, st);
@@ -1764,17 +2007,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             le = sga::launch_sweep_tsp(a, e->tsp_args, e->tsp_waves, e->tsp_passes, st);
         } else if (e->csr) {
             le = sga::launch_sweep_csr(a, e->waves, st);
-        } else if (e->use_t2 && lean) {  // production sweeps read the two bit-planes
-            a.J = e->J_bits;
-            a.J_aux = e->J_packed;
-            a.plane_row_bytes = t2_row_bits(e->n) / 8;
-            a.plane_bytes = (long long)e->n * a.plane_row_bytes;
-            a.diag = e->row_nnz;
-            le = sga::launch_sweep_dense_t2(a, e->waves_t2, e->cpw_t2 > sga::T2_MAX_CPW ? 0 : e->cpw_t2,
-                                            st);
         } else {
-            le = sga::launch_sweep_dense(a, e->want_i8, e->acc64 ? (e->acc_canon ? 2 : 1) : 0, e->waves,
-                                         e->cpw > sga::MAX_CPW ? 0 : e->cpw, st);
+            le = launch_dense_rows(a, st);
         }
         if (e->timing) {
             (void)hipEventRecord(ev1, st);
@@ -2438,7 +2672,7 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
                       e->use_t2 ? e->waves_t2 : e->waves, e->use_t2 ? e->cpw_t2 : e->cpw,
                       (e->use_t2 ? e->cpw_t2 > sga::T2_MAX_CPW : e->cpw > sga::MAX_CPW) ? "(streaming)" : "", e->ld,
                       e->use_t2 ? t2_row_bits(e->n) / 4 : e->ldj * (e->want_i8 ? 1 : 4), e->table_m,
-                      (e->table_m > 0 && std::getenv("SGA_NO_LOOK_AHEAD") == nullptr)
+                      (e->table_m > 0 && e->opt[OPT_LOOK_AHEAD] != 0)
                           ? sga::dense_look_ahead(e->use_t2, e->want_i8, e->acc64,
                                                   e->use_t2 ? e->cpw_t2 : e->cpw,
                                                   e->use_t2 ? e->waves_t2 : e->waves, e->R)
@@ -2458,11 +2692,12 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
         if (e->field_cache == SGA_FIELD_CACHE_ON)
             std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                           " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
-                          e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus));
+                          e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]));
         else
             std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
-                          " sweep=auto(cached local fields, int%d in LDS, while the hottest replica accepts < 10 %%; now: %s)",
-                          e->clf_bits, e->auto_use_clf ? "cached" : "one row per proposal");
+                          " sweep=auto(cached local fields, int%d in LDS, per replica by its own acceptance; now: %d of %d "
+                          "replica(s) cached, the rest one row per proposal)",
+                          e->clf_bits, e->auto_unavailable ? 0 : e->n_route_clf, e->R);
     }
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

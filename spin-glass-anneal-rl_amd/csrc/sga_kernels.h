@@ -73,12 +73,19 @@ struct SweepArgs {
                          // (opt-in), 4 | 8 = that many updates per step, one per row of 16 | 8 lanes (sweep_csr_rows.hip)
     int csr_row_cap;     // CSR: entries of the longest row when that is <= 64 (else 0): sweep_csr_rows.hip picks its build by it
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
+    int force_general;   // 1: the general kernel builds even for production arguments (engine option "force_general")
+    int tsp_parallel;    // implicit TSP form: updates per step (-1: by the number of cities, 0 | 1: one at a time)
+    // A launch over a SUBSET of the replicas (per-replica routing of SGA_FIELD_CACHE_AUTO): workgroup b works on
+    // local replica rep_list[b], the grid covers rep_count of them (null: all R, workgroup b = replica b)
+    const int *rep_list;
+    int rep_count;
     const void *J_aux;   // bit-plane form: the int8 copy [n][ld] (single couplings for the look-ahead)
     // cached-local-field sweep (sweep_clf_impl.h): resident fields F = field_scale * (J s + h)
     void *fields;        // [R][ldf] int16 | int32
     long long ldf;
     int field_bits;      // 16 | 32
     int field_scale;     // 1 | 2 (J integer, h a multiple of 1/2)
+    int clf_solo;        // (engine option "clf_solo": reserved for the one-evaluator form of the round)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -140,7 +147,7 @@ hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t 
 // cached-local-field sweep: dense integer-valued symmetric problems
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
-int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus);
+int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus, int forced);
 
 // Energies of all replicas of a CSR problem in one pass over the entries (fields_csr.hip)
 struct CsrEnergyArgs {

@@ -9,9 +9,7 @@ size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table
 
 // waves per replica: enough that a wave asks for its share of a row in one batch of loads, as long as
 // every replica stays resident (32 waves per CU)
-int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus) {
-    const char *env = std::getenv("SGA_CLF_WAVES");  // A/B switch, parity tests
-    const int forced = env ? std::atoi(env) : 0;
+int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus, int forced /* engine option "clf_waves" */) {
     if (forced >= 1) return std::min(forced, CLF_MAX_WAVES);
     const int epc = j_is_i8 ? 1024 : 256;
     const int chunks = (int)((ldj + epc - 1) / epc);
@@ -51,7 +49,7 @@ static hipError_t launch_clf(const SweepArgs &a, int waves, hipStream_t st) {
                            : sweep_clf_kernel<JT, FT, false, CLF_BATCH_MAX, false>);
     hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.rep_list ? a.rep_count : a.R), dim3(64 * waves), lds, st, a);
     note_sweep_kernel("sweep_clf_kernel<%s, %s, %s, BATCH=%d, TAIL=%d> x %d wave(s)", sizeof(JT) == 4 ? "float" : "int8_t",
                       sizeof(FT) == 2 ? "int16_t" : "int32_t", lean ? "LEAN" : "general", batch, (int)tail, waves);
     return hipGetLastError();

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = (int)(blockDim.x >> 6);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = blockIdx.x, n = a.n;
+    // (a launch over a subset of the replicas -- per-replica routing, sga_kernels.h -- names them in rep_list)
+    const int r = a.rep_list ? __builtin_amdgcn_readfirstlane(a.rep_list[blockIdx.x]) : (int)blockIdx.x, n = a.n;
     const int rule = LEAN ? SGA_RULE_METROPOLIS : a.rule;
     const int arith = LEAN ? SGA_ARITH_F64 : a.arith;
     const int sc = a.field_scale;
@@ -352,13 +353,19 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             // one round; true = the super-window is done
             auto round = [&](RowRegs &held, RowRegs &other) -> bool {
                 // this wave's window: first and second candidate that flip against the current state
-                Verdict vdA{0, 0.0, 1}, vdB{0, 0.0, 1};
-                bool fA, fB;
-                decide2(sA, uA, vA && gA >= pos, vdA, sB, uB, vB && gB >= pos, vdB, fA, fB);
-                unsigned long long mA = __ballot(fA), mB = __ballot(fB);
-                int p = first_of(mA, mB), p2 = NONE, site = 0, site2 = 0;
+                int p = NONE, p2 = NONE, site = 0, site2 = 0;
                 int s_old = 1;  // the spin at the first candidate's site, as evaluated (the state is stable here)
                 double dE = 0.0;
+                // (a wave whose whole window is decided already -- it lies before `pos` -- has nothing to evaluate:
+                //  it publishes "no accept" and goes on to its share of the field update)
+                Verdict vdA{0, 0.0, 1}, vdB{0, 0.0, 1};
+                unsigned long long mA = 0ull, mB = 0ull;
+                if ((w + 1) * CLF_WINDOW > pos) {  // wave-uniform
+                    bool fA, fB;
+                    decide2(sA, uA, vA && gA >= pos, vdA, sB, uB, vB && gB >= pos, vdB, fA, fB);
+                    mA = __ballot(fA), mB = __ballot(fB);
+                    p = first_of(mA, mB);
+                }
                 if (p < NONE) {
                     if (p & 1) mB &= mB - 1;
                     else mA &= mA - 1;

@@ -1,8 +1,6 @@
 // sweep_common.h -- pieces shared by the dense and CSR sweep kernels: where the site and the
 // uniform of an update come from, and the Metropolis accept rule.
 #pragma once
-#include <cstdlib>
-
 #include "sga.h"
 #include "sga_device.h"
 #include "sga_kernels.h"
@@ -24,8 +22,7 @@ struct UpdatePair {
 // variant that also serves the replay / sequential / fp32-operator / traced modes.  The accept
 // table and the look-ahead form are Metropolis only.
 inline bool sweep_args_are_lean(const SweepArgs &a) {
-    static const bool force_general = std::getenv("SGA_FORCE_GENERAL") != nullptr;  // A/B switch
-    return !force_general && a.site_mode == SGA_SITE_RANDOM && a.arith == SGA_ARITH_F64 &&
+    return !a.force_general && a.site_mode == SGA_SITE_RANDOM && a.arith == SGA_ARITH_F64 &&
            !a.accept_trace && !a.dE_trace;  // any rule: it stays a wave-uniform run-time value
 }
 

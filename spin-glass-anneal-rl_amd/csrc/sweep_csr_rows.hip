@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         st.h = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.h) + off);
     };
     auto stage_heads = [&](Step &st) {
-        // (64 zeroed entries follow the array: lanes past the row's end read what lies behind it)
+        // (256 zeroed entries follow the array -- CSR_TAIL_PAD, sga_engine.cpp: a row of the wave reaches up to
+        //  LPR * EPL <= 256 entries past its first one; lanes past the row's end read what lies behind it)
         unsigned int off = (unsigned int)(st.beg + EPL * j) * 8u;
         asm volatile("" : "+v"(off));
         const unsigned char *cv = reinterpret_cast<const unsigned char *>(a.cv);

@@ -133,7 +133,8 @@ __global__ void __launch_bounds__((SINGLE ? 64 : dense_max_threads<JT, CPW, BATC
     const int W = SINGLE ? 1 : (int)(blockDim.x >> 6);
     const int w = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int r = blockIdx.x;
+    // (a launch over a subset of the replicas -- per-replica routing, sga_kernels.h -- names them in rep_list)
+    const int r = a.rep_list ? __builtin_amdgcn_readfirstlane(a.rep_list[blockIdx.x]) : (int)blockIdx.x;
     const int n = a.n;
 
     if constexpr (BITS) {  // int8 spins in HBM -> one bit per spin in LDS (1 = spin down)
@@ -753,7 +754,7 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         // not want more than that (n = 1024 fp32: +31 % at 1024 replicas, -5 % at 8192)
         constexpr bool fat = dense_max_threads<JT, CPW, true>() < 1024;
         if (lean && a.rule == SGA_RULE_METROPOLIS && a.table_m > 0 && a.look_ahead && (!BITS || a.J_aux) &&
-            (!fat || (waves <= 4 && (long long)a.R * waves <= 3 * 1024))) {
+            (!fat || (waves <= 4 && (long long)(a.rep_list ? a.rep_count : a.R) * waves <= 3 * 1024))) {
             kern = waves == 1 ? sweep_dense_kernel<JT, CPW, ACC64, true, true, true>
                               : sweep_dense_kernel<JT, CPW, ACC64, true, true>;
             is_batch = true;
@@ -780,7 +781,7 @@ static hipError_t launch_one(const SweepArgs &a, int waves, hipStream_t st) {
         hipError_t e = ensure_lds_limit(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.R), dim3(64 * waves), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.rep_list ? a.rep_count : a.R), dim3(64 * waves), lds, st, a);
     note_sweep_kernel("sweep_dense_kernel<%s, CPW=%d, ACC64=%d, LEAN=%d, BATCH=%d, SINGLE=%d, CANON=%d> x %d wave(s)",
                       BITS ? "Tern2" : (sizeof(JT) == 4 ? "float" : "int8_t"), CPW, (int)ACC64, (int)is_lean,
                       (int)is_batch, (int)is_single, (int)(CANON && !is_batch), waves);

@@ -478,9 +478,9 @@ static hipError_t launch_tsp_np(const SweepArgs &a, const TspArgs &t, int waves,
 
 // updates per step of the several-updates form for n cities (0: the one-update form): a pair of updates is
 // independent with probability 1 - 4/n
-int tsp_parallel_updates(int n_cities, int npad) {
+int tsp_parallel_updates(int n_cities, int npad, int forced /* engine option "tsp_updates_per_step", -1: auto */) {
     int want = n_cities >= 256 ? 8 : n_cities >= 64 ? 4 : n_cities >= 24 ? 2 : 0;
-    if (const char *env = std::getenv("SGA_TSP_PARALLEL")) want = std::atoi(env);  // A/B switch, parity tests
+    if (forced >= 0) want = forced;  // A/B switch, parity tests
     if (want < 2 || npad > 1024) return 0;  // (builds for rows of up to 4 passes per wave)
     return std::min(want, TSP_MAX_WAVES);
 }
@@ -498,7 +498,7 @@ static hipError_t launch_tsp_par(const SweepArgs &a, const TspArgs &t, int waves
 
 hipError_t launch_sweep_tsp(const SweepArgs &a, const TspArgs &t, int waves, int passes, hipStream_t st) {
     if (waves < 1 || waves > TSP_MAX_WAVES || 256 * waves * passes != t.npad) return hipErrorInvalidValue;
-    const int par = sweep_args_are_lean(a) ? tsp_parallel_updates(t.n_cities, t.npad) : 0;
+    const int par = sweep_args_are_lean(a) ? tsp_parallel_updates(t.n_cities, t.npad, a.tsp_parallel) : 0;
     if (par >= 2) {
         switch (t.npad / 256) {
             case 1: return launch_tsp_par<1>(a, t, par, st);

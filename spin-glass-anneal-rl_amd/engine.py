@@ -133,6 +133,21 @@ class AnnealEngine:
         N.check(self._lib.sga_set_tuning(self._h, int(waves_per_replica), int(sweeps_per_launch)),
                 "sga_set_tuning")
 
+    def set_option(self, key: str, value: int):
+        """A form-selection option of this engine by name (sga_set_option; keys in include/sga.h).  No option
+        changes a result: every form walks the same chain."""
+        N.check(self._lib.sga_set_option(self._h, key.encode(), int(value)), "sga_set_option")
+
+    def set_options(self, options=None, **kw):
+        """Several options at once: a dict and / or keywords."""
+        for k, v in {**(options or {}), **kw}.items():
+            self.set_option(k, v)
+
+    def get_option(self, key: str) -> int:
+        out = C.c_int64(0)
+        N.check(self._lib.sga_get_option(self._h, key.encode(), C.byref(out)), "sga_get_option")
+        return int(out.value)
+
     def set_csr_storage(self, storage: str = "auto"):
         """Entry storage of the long-row CSR sweep forms: "auto" (one dword per entry where the problem
         allows: integer couplings, |J| <= 127, n < 2^24), "f32" (column + fp32 value), "packed" (required)."""
@@ -498,6 +513,14 @@ class AnnealEngine:
         buf = C.create_string_buffer(512)
         N.check(self._lib.sga_describe(self._h, buf, 512))
         return buf.value.decode()
+
+
+def option_names():
+    """Every key sga_set_option accepts."""
+    names, buf = [], C.create_string_buffer(64)
+    while N.lib().sga_option_name(len(names), buf, 64) == N.OK:
+        names.append(buf.value.decode())
+    return names
 
 
 def last_kernel() -> str:

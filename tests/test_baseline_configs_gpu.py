@@ -235,11 +235,12 @@ def test_tsp_implicit_form_equals_stored_couplings_and_oracle(sg, n_cities, inte
 
 @pytest.mark.parametrize("integer", [True, False])
 @pytest.mark.parametrize("n_cities", [3, 6, 17, 40, 260])
-def test_tsp_implicit_form_several_updates_per_step(sg, n_cities, integer, monkeypatch):
+def test_tsp_implicit_form_several_updates_per_step(sg, n_cities, integer):
     """The production sweep of the implicit TSP form works on 2 | 4 | 8 consecutive updates at once, one per
     wave, and replays a step one update at a time when an accepted update shares its city or a neighbouring
     position with a later one (always, at a handful of cities; a few per cent of the steps at hundreds):
     every setting walks the oracle's chain."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     from spin_glass_anneal_rl_amd import encoders as enc
     from spin_glass_anneal_rl_amd.engine import last_kernel
     dist = _tsp_distances(n_cities, 300 + n_cities, integer)
@@ -252,10 +253,11 @@ def test_tsp_implicit_form_several_updates_per_step(sg, n_cities, integer, monke
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
     for par in ("0", "2", "4", "8", None):
         if par is None:
-            monkeypatch.delenv("SGA_TSP_PARALLEL")
+            opts.pop("tsp_updates_per_step", None)
         else:
-            monkeypatch.setenv("SGA_TSP_PARALLEL", par)
+            opts["tsp_updates_per_step"] = int(par)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tsp(d32, A, B, h)
             e.init_replicas(R, seed=seed)
             e.set_temperatures(temps)
@@ -459,13 +461,14 @@ def test_real_valued_chain_does_not_depend_on_the_geometry(sg, n, geometries):
 
 
 @pytest.mark.parametrize("forced", [False, True])
-def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced, monkeypatch):
+def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced):
     """Real-valued couplings whose set bits span few binary places (distances on a 2^-12 grid,
     weights with a few decimals): the fp64 sum of a row is exact, so the kernels keep one tree per
     update in whatever order the geometry gives -- and still equal the oracle's canonical sum bit for
     bit under every geometry.  `forced`: the same problem through the canonical-order build."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if forced:
-        monkeypatch.setenv("SGA_FORCE_DENSE_CANON", "1")
+        opts["force_dense_canonical"] = 1
     n, R, ns, seed = 2600, 3, 2, 404
     rng = np.random.RandomState(n)
     J = np.triu(np.rint(rng.rand(n, n) * 141.0 * 1024.0) / 1024.0 / 4.0 * (rng.rand(n, n) < 0.7), 1).astype(np.float32)
@@ -477,6 +480,7 @@ def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
     for g in (1, 3, 4, 11):
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tuning(waves_per_replica=g)
             e.set_dense(J, h)
             e.init_replicas(R, seed=seed)
@@ -494,11 +498,12 @@ def test_real_valued_dense_with_exact_fp64_sums_takes_the_cheap_order(sg, forced
 
 
 @pytest.mark.parametrize("big", [False, True])
-def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big, monkeypatch):
+def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big):
     """Same for CSR rows of a few hundred real-valued entries dealt to 1, 2, 4 or 8 waves (a
     request for 3 runs as 4: the canonical order's wide builds exist per power of two)."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if big:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     n, R, ns, seed = 1200, 4, 3, 515
     rng = np.random.RandomState(8)
     J = (np.triu(rng.rand(n, n) < 0.5, 1) * rng.randn(n, n)).astype(np.float32)
@@ -512,6 +517,7 @@ def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big, monkey
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=R)
     for waves, runs_as in ((1, 1), (2, 2), (3, 4), (4, 4), (8, 8)):
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tuning(waves_per_replica=waves)
             e.set_csr(*csr, h)
             e.init_replicas(R, seed=seed)
@@ -532,14 +538,15 @@ def test_real_valued_csr_chain_does_not_depend_on_the_wave_count(sg, big, monkey
 
 @pytest.mark.parametrize("big", [False, True])
 @pytest.mark.parametrize("kind", ["integer", "half_integer_h", "fixed_point", "gaussian"])
-def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
+def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big):
     """How a CSR row sum is formed is chosen at set time from what is exact: fp32 (+ accept table)
     for integer problems, fp32 without the table when only h is fractional (BASELINE configs[3]),
     fp64 in any order when the values' binary exponents span few enough places (TSP distances),
     the canonical fp64 order otherwise.  Each form, and each slower form forced onto the same
     problem, gives the oracle's chain bit for bit at 1 to 8 waves per replica."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if big:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     n, R, ns, seed = 1100, 4, 2, 99
     rng = np.random.RandomState(4)
     mask = np.triu(rng.rand(n, n) < 0.45, 1)
@@ -564,9 +571,10 @@ def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
     first = {"integer": 0, "half_integer_h": 1, "fixed_point": 2, "gaussian": 3}[kind]
     for force in range(first, 4):
         if force > first:
-            monkeypatch.setenv("SGA_FORCE_CSR_ACC", str(force))
+            opts["force_csr_acc"] = int(force)
         for waves in (1, 2, 3, 8):
             with sg.AnnealEngine(0) as e:
+                e.set_options(opts)
                 e.set_tuning(waves_per_replica=waves)
                 e.set_csr(*csr, h)
                 e.init_replicas(R, seed=seed)
@@ -584,18 +592,19 @@ def test_csr_row_sum_forms_all_reproduce_the_oracle(sg, kind, big, monkeypatch):
                 out = e.sweep(ns, trace=True)                     # general (traced) variant
                 assert np.array_equal(out["accept_trace"], ref["accept_trace"]), d
                 assert np.array_equal(out["dE_trace"], ref["dE_trace"]), d
-    monkeypatch.delenv("SGA_FORCE_CSR_ACC", raising=False)
+    opts.pop("force_csr_acc", None)
 
 
 @pytest.mark.parametrize("kind", ["integer", "fixed_point"])
 @pytest.mark.parametrize("n,dens", [(901, 0.4), (257, 0.9), (4001, 0.05)])
-def test_csr_wide_bit_forms_on_awkward_shapes(sg, kind, n, dens, monkeypatch):
+def test_csr_wide_bit_forms_on_awkward_shapes(sg, kind, n, dens):
     """The bit-spin wide builds on shapes the other CSR tests do not hit: odd n (the last Philox pair
     of a sweep is half used), nearly dense rows (consecutive sites are neighbours most of the time),
     tiny n (the same site twice in a row ~ once per 257 updates), rows beyond the eight head slots
     (n = 4001 at one wave).  (Written for a two-update look-ahead form that was measured slower and
     dropped, profiles/r02_experiments.md; `SGA_NO_LOOK_AHEAD` is a no-op for CSR problems.)"""
-    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
+    opts["force_csr_bits"] = 1
     rng = np.random.RandomState(n)
     mask = np.triu(rng.rand(n, n) < dens, 1)
     vals = rng.randint(-3, 4, (n, n)).astype(np.float64) if kind == "integer" else \
@@ -613,10 +622,11 @@ def test_csr_wide_bit_forms_on_awkward_shapes(sg, kind, n, dens, monkeypatch):
         got = {}
         for look in (True, False):
             if look:
-                monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+                opts.pop("look_ahead", None)
             else:
-                monkeypatch.setenv("SGA_NO_LOOK_AHEAD", "1")
+                opts["look_ahead"] = 0
             with sg.AnnealEngine(0) as e:
+                e.set_options(opts)
                 e.set_tuning(waves_per_replica=waves)
                 e.set_csr(*csr, h)
                 e.init_replicas(R, seed=seed)
@@ -628,7 +638,7 @@ def test_csr_wide_bit_forms_on_awkward_shapes(sg, kind, n, dens, monkeypatch):
                 assert np.array_equal(out["energy_trace"], ref["energy_trace"]), (e.describe(), look)
                 assert np.array_equal(e.stats()[0], ref["n_accepted"])
         assert all(np.array_equal(x, y) for x, y in zip(got[True], got[False]))
-    monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+    opts.pop("look_ahead", None)
 
 
 def test_single_site_operators_use_the_canonical_order_dense(sg):

@@ -61,9 +61,10 @@ CLF_CASES = [
 
 
 @pytest.mark.parametrize("n,R,storage,waves", CLF_CASES)
-def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves, monkeypatch):
+def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if waves:
-        monkeypatch.setenv("SGA_CLF_WAVES", str(waves))
+        opts["clf_waves"] = int(waves)
     J = pm1(n, 10 + n)
     h = np.random.RandomState(n).randint(-1, 2, n).astype(np.float32)
     prob = oracle.Problem(J=J, h=h)
@@ -73,6 +74,7 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves, monkeypatch)
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_field_cache("on")
         e.set_dense(J, h, storage=storage)
         e.init_replicas(R, seed=seed)
@@ -317,35 +319,107 @@ def test_cached_fields_need_an_integer_symmetric_problem(sg):
             sg._native.check(e._lib.sga_set_field_cache(e._h, 7), "sga_set_field_cache")
 
 
-def test_auto_takes_the_cached_field_sweep_only_while_the_run_is_cold(sg):
+def test_auto_routes_every_replica_by_its_own_acceptance(sg):
     """SGA_FIELD_CACHE_AUTO starts on the row-per-proposal kernels, looks at the acceptance counters every few
-    sweeps and runs the cached-field sweep while the hottest replica accepts less than ~10 % -- with the chain
-    of "off" either way."""
+    sweeps and then routes each replica by ITS OWN acceptance: a cold ladder ends on the cached-field sweep, a hot
+    one stays on the row kernels, and a ladder with a hot end runs as a MIXED launch -- the cached-field kernel and
+    the row-per-proposal kernel side by side over disjoint replica lists -- with the chain of "off" in every case.
+    Option "replica_routing" = 0 keeps one launch, decided by the hottest replica."""
     from spin_glass_anneal_rl_amd.engine import last_kernel
     n, R, seed = 1500, 48, 99
     J = pm1(n, 4)
     h = np.zeros(n, np.float32)
+    rt = np.sqrt(n)
+
+    def kind(k):
+        return "mixed" if k.startswith("mixed launch") else k.split("<")[0]
+
     runs = {}
-    for name, temps in (("cold", ladder(R, 0.05 * np.sqrt(n), 0.002 * np.sqrt(n))),
-                        ("hot", ladder(R, 4.0 * np.sqrt(n), 1.0 * np.sqrt(n)))):
-        for cache in ("auto", "off"):
+    for name, temps in (("cold", ladder(R, 0.05 * rt, 0.002 * rt)), ("hot", ladder(R, 40.0 * rt, 10.0 * rt)),
+                        ("mixed", ladder(R, 20.0 * rt, 0.002 * rt))):
+        for cache in ("auto", "off", "auto-one-launch"):
             with sg.AnnealEngine(0) as e:
-                e.set_field_cache(cache)
+                e.set_field_cache(cache.split("-")[0])
+                if cache == "auto-one-launch":
+                    e.set_option("replica_routing", 0)
                 e.set_dense(J, h)
                 e.init_replicas(R, seed=seed)
                 e.set_ladder(temps)
                 kernels, trace = [], []
                 for _ in range(12):
                     trace.append(e.sweep(2, energy_trace=True)["energy_trace"])
-                    kernels.append(last_kernel().split("<")[0])
+                    kernels.append(kind(last_kernel()))
                     e.exchange(count=False)
-                runs[name, cache] = (np.vstack(trace), e.spins(), kernels, e.describe())
-        assert np.array_equal(runs[name, "auto"][0], runs[name, "off"][0])
-        assert np.array_equal(runs[name, "auto"][1], runs[name, "off"][1])
+                tracked = e.energies()
+                e.recompute_energies()
+                assert np.array_equal(e.energies(), tracked), (name, cache)
+                runs[name, cache] = (np.vstack(trace), e.spins(), kernels, e.describe(), last_kernel(), e.stats()[0])
+        for cache in ("auto", "auto-one-launch"):
+            assert np.array_equal(runs[name, cache][0], runs[name, "off"][0]), (name, cache)
+            assert np.array_equal(runs[name, cache][1], runs[name, "off"][1]), (name, cache)
+            assert np.array_equal(runs[name, cache][5], runs[name, "off"][5]), (name, cache)
         assert set(runs[name, "off"][2]) == {"sweep_dense_kernel"}
     assert runs["cold", "auto"][2][0] == "sweep_dense_kernel"          # until the acceptance is known
-    assert runs["cold", "auto"][2][-1] == "sweep_clf_kernel" and "now: cached" in runs["cold", "auto"][3]
-    assert set(runs["hot", "auto"][2]) == {"sweep_dense_kernel"} and "now: one row per proposal" in runs["hot", "auto"][3]
+    assert runs["cold", "auto"][2][-1] == "sweep_clf_kernel" and f"now: {R} of {R} replica(s) cached" in runs["cold", "auto"][3]
+    assert set(runs["hot", "auto"][2]) == {"sweep_dense_kernel"} and f"now: 0 of {R} replica(s)" in runs["hot", "auto"][3]
+    # the ladder with a hot end: both kernels in one sweep call, each on its own replicas
+    assert runs["mixed", "auto"][2][-1] == "mixed", runs["mixed", "auto"][2]
+    last = runs["mixed", "auto"][4]
+    assert "sweep_clf_kernel" in last and "sweep_dense_kernel" in last and "||" in last, last
+    import re
+    m = re.search(r"now: (\d+) of", runs["mixed", "auto"][3])
+    assert m and 0 < int(m.group(1)) < R, runs["mixed", "auto"][3]
+    # one launch for all: the hot end keeps everybody on the row kernels
+    assert set(runs["mixed", "auto-one-launch"][2]) == {"sweep_dense_kernel"}, runs["mixed", "auto-one-launch"][2]
+
+
+def test_field_cache_request_after_a_sparse_matrix_was_taken_as_csr(sg):
+    """sga_set_dense keeps a sparse integer matrix as CSR while the field cache is OFF (the C ABI's default) and
+    releases the dense source: asking for the cached-field sweep afterwards fails AT THE REQUEST, with the order
+    spelled out -- not at every later sweep."""
+    n = 4200
+    rng = np.random.RandomState(n)
+    J = np.zeros((n, n), np.float32)
+    for i in range(0, n - 1, 2):
+        J[i, i + 1] = J[i + 1, i] = float(rng.choice([-3.0, 2.0]))
+    h = np.zeros(n, np.float32)
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, h)                       # field cache OFF: taken as CSR
+        assert "source=dense-matrix" in e.describe()
+        with pytest.raises(sg.AnnealingError, match="before sga_set_dense"):
+            e.set_field_cache("on")
+        e.set_field_cache("auto")               # AUTO may fall back: accepted, sweeps run on the CSR forms
+        e.init_replicas(4, seed=1)
+        e.set_temperatures(np.full(4, 2.0))
+        e.sweep(2)
+        e.set_field_cache("on")                 # the request first, then the matrix: the dense forms
+        e.set_dense(J, h)
+        e.init_replicas(4, seed=1)
+        e.set_temperatures(np.full(4, 2.0))
+        e.sweep(2)
+        assert "sweep=cached-local-fields" in e.describe()
+
+
+def test_all_replica_field_pass_in_tiles(sg):
+    """The scratch of the all-replica pass (Y = S J^T) is bounded (option "fields_scratch_mb"): beyond it the
+    replicas go through in tiles of whole 128-replica blocks -- energies and seeded fields as in one pass."""
+    n, R, seed = 1000, 300, 5
+    J = int_couplings(n, n, 3)
+    h = np.random.RandomState(1).randint(-2, 3, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    s0 = oracle.init_spins(n, R, seed)
+    want = oracle.energy(prob, s0)
+    temps = ladder(R, 30.0, 1.0)
+    ref = oracle.sweeps(prob, s0.copy(), temps, 2, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_option("fields_scratch_mb", 1)    # 256 replicas of 1024 fp32 per tile: two tiles
+        e.set_field_cache("on")
+        e.set_dense(J, h, storage="i8")
+        e.init_replicas(R, seed=seed)
+        assert np.array_equal(e.energies(), want)
+        e.set_temperatures(temps)
+        out = e.sweep(2, energy_trace=True)
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"])
 
 
 # ----------------------------------------------------------------------------- BASELINE configs[1]
@@ -433,9 +507,10 @@ def test_matrix_core_energies_match_oracle(sg, n, R, kind):
 
 @pytest.mark.parametrize("kind", ["pm1", "int", "gauss"])
 @pytest.mark.parametrize("n,deg,R", [(300, 8, 64), (1000, 40, 130), (2000, 200, 70), (65, 64, 97)])
-def test_csr_energies_of_many_replicas_in_one_pass(sg, n, deg, R, kind, monkeypatch):
+def test_csr_energies_of_many_replicas_in_one_pass(sg, n, deg, R, kind):
     """64 and more replicas of a CSR problem: spins transposed to a bit matrix, every entry read once for 32
     replicas per lane (csrc/fields_csr.hip) -- against the oracle and against the per-replica kernel."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     rng = np.random.RandomState(n + deg)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -453,8 +528,9 @@ def test_csr_energies_of_many_replicas_in_one_pass(sg, n, deg, R, kind, monkeypa
     got = {}
     for one_pass in (True, False):
         if not one_pass:
-            monkeypatch.setenv("SGA_NO_MFMA_ENERGY", "1")
+            opts["batched_energy"] = 0
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_csr(rowptr, col, val, h)
             e.init_replicas(R, seed=321)
             got[one_pass] = e.energies()

@@ -36,9 +36,10 @@ def run_both(sg, prob_args, setter, n, R, temps, ns, seed, rule=0, recompute=Fal
 
 @pytest.mark.parametrize("bits", [False, True])
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
-def test_tiny_problems_dense_and_csr(sg, n, bits, monkeypatch):
+def test_tiny_problems_dense_and_csr(sg, n, bits):
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if bits:  # the CSR case through the bit-spin form (several replicas per workgroup)
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rng = np.random.RandomState(n)
     J = np.triu(rng.randint(-2, 3, (n, n)), 1).astype(np.float32)
     J = J + J.T
@@ -48,14 +49,15 @@ def test_tiny_problems_dense_and_csr(sg, n, bits, monkeypatch):
     rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
     col = np.concatenate([np.nonzero(J[i])[0] for i in range(n)] + [np.zeros(0, int)]).astype(np.int32)
     val = np.concatenate([J[i][J[i] != 0] for i in range(n)] + [np.zeros(0)]).astype(np.float32)
-    run_both(sg, dict(J=J, h=h), lambda e: e.set_csr(rowptr, col, val, h), n, 3, temps, 7, seed=n)
+    run_both(sg, dict(J=J, h=h), lambda e: (e.set_options(opts), e.set_csr(rowptr, col, val, h)), n, 3, temps, 7, seed=n)
 
 
 @pytest.mark.parametrize("bits", [False, True])
-def test_fields_only_and_empty_rows(sg, bits, monkeypatch):
+def test_fields_only_and_empty_rows(sg, bits):
     """J == 0 almost everywhere (nearly every CSR row empty); `bits`: the bit-spin CSR form."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     n = 70
     J = np.zeros((n, n), np.float32)
     J[3, 40] = J[40, 3] = 2.0          # a single bond; every other row is empty
@@ -65,7 +67,7 @@ def test_fields_only_and_empty_rows(sg, bits, monkeypatch):
     col = np.asarray([40, 3], np.int32)
     val = np.asarray([2.0, 2.0], np.float32)
     a = run_both(sg, dict(J=J, h=h), lambda e: e.set_dense(J, h), n, 2, temps, 20, seed=5)
-    b = run_both(sg, dict(J=J, h=h), lambda e: e.set_csr(rowptr, col, val, h), n, 2, temps, 20, seed=5)
+    b = run_both(sg, dict(J=J, h=h), lambda e: (e.set_options(opts), e.set_csr(rowptr, col, val, h)), n, 2, temps, 20, seed=5)
     assert np.array_equal(a["trace"], b["trace"])
     # cold replica ends aligned with its field wherever the field dominates
     cold = a["spins"][1]

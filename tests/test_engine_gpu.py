@@ -430,11 +430,12 @@ def test_sequential_order_matches_oracle(sg):
 # ----------------------------------------------------------------------------- CSR
 @pytest.mark.parametrize("bits", [False, True])
 @pytest.mark.parametrize("n,deg,R", [(200, 6, 9), (3000, 32, 10), (1500, 100, 3)])
-def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
+def test_csr_sweeps_match_oracle(sg, n, deg, R, bits):
     """Short rows: one replica per wave, several replicas per workgroup; `bits` = the same with the
     spins as bits in LDS (the form for 53k < n <= 1.3M spins)."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rng = np.random.RandomState(n)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -449,6 +450,7 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
         d = e.describe()
@@ -477,13 +479,14 @@ def test_csr_sweeps_match_oracle(sg, n, deg, R, bits, monkeypatch):
     (400, 6, 1, False, False),    # lattice-like degree: one entry per lane in the several-updates-per-step builds
     (120, 30, 2, False, False),   # rows of 17..32 entries
 ])
-def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h, dups, bits, monkeypatch):
+def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h, dups, bits):
     """Narrow table form (integer problems, rows of <= 64 entries): the two updates of a Philox pair are
     reduced together and the chain replayed on scalars (fix-up by the entries of row B at site A).  Against
     the oracle and against the one-update-at-a-time form of the same kernel.  (Opt-in, SGA_CSR_PAIR_AHEAD:
     measured -1 ... +3 % on BASELINE configs[2], so the default stays one update at a time.)"""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rng = np.random.RandomState(7 * n + deg)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -517,10 +520,11 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     # at a time when an accepted update touches a later one of the step) -- the default where it applies (None)
     for ahead in ("1", "2", "4", "8", None, "0"):
         if ahead is not None:
-            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
+            opts["csr_updates_per_step"] = int(ahead)
         else:
-            monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
+            opts.pop("csr_updates_per_step", None)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_csr(*csr, h)
             e.init_replicas(R, seed=seed)
             assert "fast" in e.describe(), e.describe()
@@ -547,12 +551,13 @@ def test_csr_pair_look_ahead_equals_one_update_at_a_time(sg, n, deg, amp, half_h
     (300, 100, 60, False),   # penalties: moves beyond the accept table's 2048 entries (computed, not looked up)
     (144, 22, 120, True),
 ])
-def test_csr_several_updates_per_step_medium_rows(sg, n, deg, amp, half_h, bits, monkeypatch):
+def test_csr_several_updates_per_step_medium_rows(sg, n, deg, amp, half_h, bits):
     """Integer problems whose rows hold 65 ... 256 entries (assignment / small scheduling instances) run four
     updates per step with 8 | 16 entries per lane: the oracle's chain, equal to the one-update form."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     from spin_glass_anneal_rl_amd.engine import last_kernel
     if bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rng = np.random.RandomState(3 * n + deg)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -570,10 +575,11 @@ def test_csr_several_updates_per_step_medium_rows(sg, n, deg, amp, half_h, bits,
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
     for ahead in ("4", None, "0"):
         if ahead is not None:
-            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
+            opts["csr_updates_per_step"] = int(ahead)
         else:
-            monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
+            opts.pop("csr_updates_per_step", None)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_csr(*csr, h)
             e.init_replicas(R, seed=seed)
             e.set_temperatures(temps)
@@ -596,14 +602,15 @@ def test_csr_several_updates_per_step_medium_rows(sg, n, deg, amp, half_h, bits,
     (300, 24, True),     # couplings on a 2^-10 grid (the fp64-exact row-sum class), rows of up to ~40 entries
     (150, 60, False),    # rows of up to 64 entries
 ])
-def test_csr_several_updates_per_step_with_real_valued_couplings(sg, n, deg, grid, bits, monkeypatch):
+def test_csr_several_updates_per_step_with_real_valued_couplings(sg, n, deg, grid, bits):
     """The several-updates-per-step form without the accept table: fp64 row sums in the canonical order (a lane's
     consecutive entries are one subtree of the 64-lane adjacent-pairs tree, the DPP steps over the row's lanes
     continue it), energies added in chain order -- bit for bit the oracle's chain, for 4 and 8 rows per step, on
     int8 and on bit spins, and equal to the one-update-at-a-time form."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     from spin_glass_anneal_rl_amd.engine import last_kernel
     if bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rng = np.random.RandomState(11 * n + deg)
     J = np.zeros((n, n), np.float32)
     for i in range(n):
@@ -621,10 +628,11 @@ def test_csr_several_updates_per_step_with_real_valued_couplings(sg, n, deg, gri
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
     for ahead in ("4", "8", None, "0"):
         if ahead is not None:
-            monkeypatch.setenv("SGA_CSR_PAIR_AHEAD", ahead)
+            opts["csr_updates_per_step"] = int(ahead)
         else:
-            monkeypatch.delenv("SGA_CSR_PAIR_AHEAD")
+            opts.pop("csr_updates_per_step", None)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_csr(*csr, h)
             e.init_replicas(R, seed=seed)
             e.set_temperatures(temps)
@@ -639,11 +647,12 @@ def test_csr_several_updates_per_step_with_real_valued_couplings(sg, n, deg, gri
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("integer", [True, False])
 @pytest.mark.parametrize("big", [False, True])
-def test_csr_wide_rows_match_oracle(sg, waves, integer, big, monkeypatch):
+def test_csr_wide_rows_match_oracle(sg, waves, integer, big):
     """Rows of a few hundred entries dealt to several waves per replica (C4/C5 shape); `big`
     sends the same case through the form for n > 160k (spins as bits in LDS, 64-bit extents)."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     if big:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     n, R = 900, 5
     rng = np.random.RandomState(17)
     mask = np.triu(rng.rand(n, n) < 0.35, 1)
@@ -658,6 +667,7 @@ def test_csr_wide_rows_match_oracle(sg, waves, integer, big, monkeypatch):
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_tuning(waves_per_replica=waves)
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
@@ -679,12 +689,13 @@ def test_csr_wide_rows_match_oracle(sg, waves, integer, big, monkeypatch):
 
 @pytest.mark.parametrize("every", [1, 7, 64])
 @pytest.mark.parametrize("waves,integer", [(2, True), (4, False), (8, False)])
-def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, every, monkeypatch):
+def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, every):
     """Head slots past a row's end read an all-zero slot; layouts beyond 1 GB carry such slots INSIDE
     (one per 2^21 slots).  SGA_ZERO_SLOT_EVERY puts them into a small layout: rows of very different
     lengths (empty ones too), so that most head slots are redirected, against the oracle."""
-    monkeypatch.setenv("SGA_ZERO_SLOT_EVERY", str(every))
-    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
+    opts["zero_slot_every"] = int(every)
+    opts["force_csr_bits"] = 1
     n, R = 700, 4
     rng = np.random.RandomState(5 + every)
     dens = rng.choice([0.0, 0.02, 0.2, 0.9], n)[:, None]
@@ -700,6 +711,7 @@ def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, eve
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_tuning(waves_per_replica=waves)
         e.set_csr(*csr, h)
         e.init_replicas(R, seed=seed)
@@ -713,13 +725,14 @@ def test_csr_wide_rows_with_zero_slots_inside_the_layout(sg, waves, integer, eve
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("every", [0, 3])
-def test_csr_packed_entries_run_the_same_chain(sg, waves, every, monkeypatch):
+def test_csr_packed_entries_run_the_same_chain(sg, waves, every):
     """Integer couplings with |J| <= 127: the bit-spin wide forms keep one dword per entry (24-bit column,
     8-bit value) and accumulate integers -- the chain of the (column, fp32 value) entries and of the
     oracle; larger values and real values keep the unpacked entries; "packed" demanded for them fails."""
-    monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
+    opts["force_csr_bits"] = 1
     if every:
-        monkeypatch.setenv("SGA_ZERO_SLOT_EVERY", str(every))
+        opts["zero_slot_every"] = int(every)
     n, R = 1200, 4
     rng = np.random.RandomState(40 + waves)
     dens = rng.choice([0.0, 0.3, 0.6, 0.95], n)[:, None]   # long rows (mean degree > 192), empty ones too
@@ -735,6 +748,7 @@ def test_csr_packed_entries_run_the_same_chain(sg, waves, every, monkeypatch):
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     for storage in ("auto", "f32", "packed"):
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tuning(waves_per_replica=waves)
             e.set_csr_storage(storage)
             e.set_csr(*csr, h)
@@ -753,6 +767,7 @@ def test_csr_packed_entries_run_the_same_chain(sg, waves, every, monkeypatch):
         s2 = oracle.init_spins(n, R, seed)
         r2 = oracle.sweeps(p2, s2, temps, 1, seed=seed, n_threads=8)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tuning(waves_per_replica=waves)
             e.set_csr(*c2, h)
             e.init_replicas(R, seed=seed)
@@ -761,6 +776,7 @@ def test_csr_packed_entries_run_the_same_chain(sg, waves, every, monkeypatch):
             e.sweep(1)
             assert np.array_equal(e.spins(), s2)
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             e.set_tuning(waves_per_replica=waves)
             e.set_csr_storage("packed")
             e.set_csr(*c2, h)
@@ -1189,11 +1205,12 @@ def test_ternary_bit_plane_storage_matches_oracle(sg, n, R, waves, density):
     # five / six chunks per wave (three / four for bit-planes): two updates per batch
     (1500, 3, "f32", 1), (2600, 2, "f32", 2), (5000, 2, "i8", 1), (20000, 2, "t2", 1), (25000, 2, "t2", 1),
 ])
-def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, monkeypatch):
+def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves):
     """Integer problems with short rows reduce four consecutive updates together and replay the
     chain on scalars (sweep_dense_impl.h).  Same spins, energies, counters and best states as the
     oracle's strictly sequential chain and as the kernel's own one-at-a-time form -- including
     repeated sites inside a batch (tiny n), odd n, fields, and several waves per replica."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     rng = np.random.RandomState(n)
     J = pm1(n, 100 + n)
     if storage == "t2":
@@ -1209,10 +1226,11 @@ def test_look_ahead_form_equals_one_update_at_a_time(sg, n, R, storage, waves, m
     got = {}
     for look in (True, False):
         if look:
-            monkeypatch.delenv("SGA_NO_LOOK_AHEAD", raising=False)
+            opts.pop("look_ahead", None)
         else:
-            monkeypatch.setenv("SGA_NO_LOOK_AHEAD", "1")
+            opts["look_ahead"] = 0
         with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
             if waves:
                 e.set_tuning(waves_per_replica=waves)
             e.set_dense(J, h, storage=storage)
@@ -1275,3 +1293,84 @@ def test_bit_plane_storage_needs_ternary_couplings(sg):
         e.set_dense(pm1(5000, 1), np.zeros(5000, np.float32))       # auto: ternary and n >= 4096
         e.init_replicas(2, seed=1)
         assert "storage=t2" in e.describe()
+
+
+
+def test_two_engines_of_one_process_run_different_forms(sg):
+    """sga_set_option is per engine: the same CSR problem swept by two engines side by side -- several updates per
+    step on int8 spins in one, one update at a time on bit spins in the other -- gives the same chain; unknown
+    keys and values out of range are refused."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel, option_names
+    n, R, ns, seed = 700, 8, 4, 2024
+    rng = np.random.RandomState(n)
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rng.choice(n, 5, replace=False):
+            if i != j:
+                J[i, j] = J[j, i] = float(rng.choice([-2.0, -1.0, 1.0, 2.0]))
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    csr = csr_of(J)
+    temps = ladder(R, 6.0, 0.3)
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
+    with sg.AnnealEngine(0) as a, sg.AnnealEngine(0) as b:
+        assert a.get_option("csr_updates_per_step") == -1 and a.get_option("look_ahead") == 1
+        b.set_options(csr_updates_per_step=0, force_csr_bits=1)
+        assert b.get_option("csr_updates_per_step") == 0 and a.get_option("csr_updates_per_step") == -1
+        kernels = []
+        for e in (a, b):
+            e.set_csr(*csr, h)
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+        for e in (a, b):      # interleaved calls: nothing is latched per process
+            out = e.sweep(ns, energy_trace=True)
+            kernels.append(last_kernel())
+            assert np.array_equal(out["energy_trace"], ref["energy_trace"]), kernels[-1]
+            assert np.array_equal(e.spins(), s)
+        assert "sweep_csr_rows_kernel" in kernels[0] and "sweep_csr_rows_kernel" not in kernels[1], kernels
+        assert "spins=lds-bits" in b.describe() and "spins=lds-int8" in a.describe()
+        with pytest.raises(sg.AnnealingError, match="unknown option"):
+            a.set_option("no_such_option", 1)
+        with pytest.raises(sg.AnnealingError, match="outside"):
+            a.set_option("clf_waves", 99)
+        assert set(option_names()) >= {"look_ahead", "clf_waves", "sparse_route", "batched_energy"}
+
+
+@pytest.mark.parametrize("longest", [100, 200, 256])
+def test_csr_medium_rows_with_a_short_last_row(sg, longest):
+    """Rows of 65 ... 256 entries run four updates per step with 8 | 16 entries per lane, every lane of a row loading
+    its entries without a bounds test: a row that starts within the last 255 entries of the layout reaches past the
+    array -- into the 256 zeroed entries the engine keeps behind it.  The LAST row here holds one entry, the rows
+    before it few, the first one `longest`: every update at the late sites reads beyond the last entry."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    n = longest + 40
+    rng = np.random.RandomState(longest)
+    J = np.zeros((n, n), np.float32)
+    hub = 0                                    # one long row (and its column)
+    for j in rng.choice(np.arange(1, n - 1), longest - 1, replace=False):
+        J[hub, j] = J[j, hub] = float(rng.choice([-2.0, -1.0, 1.0, 3.0]))
+    J[hub, n - 1] = J[n - 1, hub] = 1.0        # the last row: exactly this one entry
+    for i in range(1, n - 1, 7):               # a few more short rows
+        j = (i * 5) % (n - 2) + 1
+        if i != j:
+            J[i, j] = J[j, i] = -1.0
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    csr = csr_of(J)
+    lens = np.diff(csr[0])
+    assert lens.max() == longest and lens[-1] == 1
+    R, ns, seed = 5, 8, 31 + longest
+    temps = ladder(R, 6.0, 0.5)
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        e.set_temperatures(temps)
+        out = e.sweep(ns, energy_trace=True)
+        k = last_kernel()
+        assert "sweep_csr_rows_kernel" in k and ("16 entries per lane" if longest > 128 else "8 entries per lane") in k, k
+        assert np.array_equal(out["energy_trace"], ref["energy_trace"]), k
+        assert np.array_equal(e.spins(), s)
+        assert np.array_equal(e.stats()[0], ref["n_accepted"])

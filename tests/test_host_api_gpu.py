@@ -514,15 +514,16 @@ def test_c4_shaped_instance_full_size(sg):
 
 
 @pytest.mark.parametrize("n_cities,force_bits", [(40, False), (420, False), (60, True)])
-def test_c5_tsp_rows_written_on_the_device(sg, n_cities, force_bits, monkeypatch):
+def test_c5_tsp_rows_written_on_the_device(sg, n_cities, force_bits):
     """BASELINE configs[4] shape (TSP QUBO, n = cities^2, degree 4(cities - 1), 32 ladders): the
     structured CSR is produced on the GPU with 64-bit extents and handed over as device pointers.
     420 cities = 176 400 spins is past the int8 LDS capacity: spins live as bits (the form the
     1000-city instance runs in).  First sweep == oracle on the same rows; exchanges stay inside
     their ladders."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     from spin_glass_anneal_rl_amd import encoders as enc
     if force_bits:
-        monkeypatch.setenv("SGA_FORCE_CSR_BIG", "1")
+        opts["force_csr_bits"] = 1
     rs = np.random.RandomState(n_cities)
     xy = rs.rand(n_cities, 2) * 100.0
     d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
@@ -532,6 +533,7 @@ def test_c5_tsp_rows_written_on_the_device(sg, n_cities, force_bits, monkeypatch
     bits = force_bits or n > 160_000
     temps = np.tile(np.asarray(sg.temperature_ladder(R // n_ladders, 2.0, 200.0)), n_ladders)
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_csr(rowptr, col, val, h)
         e.init_replicas(R, seed=seed)
         assert ("spins=lds-bits" in e.describe()) == bits and "recomputed" not in e.describe()
@@ -570,12 +572,13 @@ def test_scheduler_result_does_not_depend_on_autotune(sg):
 
 
 @pytest.mark.parametrize("cache", ["off", "on", "sparse"])
-def test_c2b_assignment_instance_full_size(sg, cache, monkeypatch):
+def test_c2b_assignment_instance_full_size(sg, cache):
     """BASELINE configs[1] parity instance: 100 agents x 100 tasks one-hot
     penalties (lambda = 100), 10 000 spins dense, 1024 replicas -- with one coupling-row read per
     proposal, with the cached-local-field sweep (a hot ladder: most proposals are accepted), and as the
     engine takes the matrix by itself: 198 of 10 000 couplings per row are non-zero, so `sga_set_dense`
     keeps it as CSR and the sweeps work on four updates per step ("sparse")."""
+    opts = {}  # engine options (sga_set_option): which kernel form runs, never what it computes
     from spin_glass_anneal_rl_amd import encoders as enc
     from spin_glass_anneal_rl_amd.engine import last_kernel
     b = enc.assignment_ising(100, 100, weight=100.0)
@@ -583,8 +586,9 @@ def test_c2b_assignment_instance_full_size(sg, cache, monkeypatch):
     n, R, seed = 10000, 1024, 77
     temps = np.asarray(sg.temperature_ladder(R, 1.0, 400.0))
     if cache == "off":
-        monkeypatch.setenv("SGA_NO_SPARSE_ROUTE", "1")
+        opts["sparse_route"] = 0
     with sg.AnnealEngine(0) as e:
+        e.set_options(opts)
         e.set_field_cache("off" if cache == "sparse" else cache)
         e.set_dense(J, h)
         if cache == "sparse":

@@ -34,6 +34,28 @@ def test_library_exports_every_declared_symbol():
     assert sg._native.lib().sga_version() >= 100
 
 
+def test_engine_options_are_documented_and_the_environment_is_read_in_one_place():
+    """sga_set_option: the keys the library accepts are exactly the keys include/sga.h documents, and the
+    library consults the environment at ONE site (the defaults, in sga_create)."""
+    import glob
+    import re
+    from spin_glass_anneal_rl_amd.engine import option_names
+    names = option_names()          # sga_option_name needs neither an engine nor a GPU
+    assert len(names) >= 14 and len(set(names)) == len(names)
+    text = open(os.path.join(ROOT, "include", "sga.h")).read()
+    doc = re.search(r"/\* Form-selection options of ONE engine.*?\*/", text, re.S).group(0)
+    documented = re.findall(r'^ \*   "(\w+)"', doc, re.M)
+    assert sorted(documented) == sorted(names), (sorted(documented), sorted(names))
+    csrc = os.path.join(ROOT, "spin-glass-anneal-rl_amd", "csrc")
+    sites = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")) +
+                       glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc"))):
+        for no, line in enumerate(open(path), 1):
+            if "getenv(" in line.split("//")[0]:
+                sites.append(f"{os.path.basename(path)}:{no}")
+    assert len(sites) == 1 and sites[0].startswith("sga_engine.cpp"), sites
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_gpu_means_device_error_not_fallback():
     with pytest.raises(sg.DeviceError):
@@ -216,3 +238,22 @@ def test_spin_dynamics_diagnostics_equal_reference():
             assert dyn.thermal_equilibrium_check(win) == bool(g[f"{name}__equilibrium_w{win}"]), (name, win)
     with pytest.raises(ValueError):
         dyn.get_autocorrelation_time("susceptibility")
+    # without scipy the reference assigns p_value = 0.05 | 0.01 and returns p_value > 0.05: False either way
+    # (core/spin_dynamics.py:414-421), also for two windows of equal variance
+    import builtins
+    import sys
+    real_import = builtins.__import__
+
+    def no_scipy(name, *a, **k):
+        if name == "scipy" or name.startswith("scipy."):
+            raise ImportError(name)
+        return real_import(name, *a, **k)
+
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "scipy" or k.startswith("scipy.")}
+    builtins.__import__ = no_scipy
+    try:
+        dyn.energy_history = [1.0, 2.0] * 100
+        assert dyn.thermal_equilibrium_check(100) is False
+    finally:
+        builtins.__import__ = real_import
+        sys.modules.update(saved)
