@@ -324,7 +324,7 @@ int sga_set_field_cache(sga_engine *e, int mode);
  * [sweep] at the next sga_sweep / sga_recompute_energies.
  *   "look_ahead"            0 | 1 (default)   dense integer problems: several updates reduced together  [sweep; SGA_NO_LOOK_AHEAD]
  *   "force_general"         0 (default) | 1   general kernel builds even for production arguments       [sweep; SGA_FORCE_GENERAL]
- *   "clf_waves"             0 = measured table (default), 1 ... 8: waves per replica of the cached-field sweep [sweep; SGA_CLF_WAVES]
+ *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the cached-field sweep [sweep; SGA_CLF_WAVES]
  *   "clf_solo"              -1 = adaptive (default), 0 | 1: cached-field sweep, one wave evaluates the candidates
  *                           of a round (busy replicas) instead of every wave its own window            [sweep; SGA_CLF_SOLO]
  *   "replica_routing"       0 | 1 (default)   SGA_FIELD_CACHE_AUTO routes each replica by its own acceptance (two

@@ -41,7 +41,7 @@ struct OptDef {
 };
 constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"look_ahead", "SGA_NO_LOOK_AHEAD", 1, 0, 1, 0, 1},
-    {"clf_waves", "SGA_CLF_WAVES", 0, 0, 0, 0, 8},
+    {"clf_waves", "SGA_CLF_WAVES", 0, 0, 0, 0, 16},
     {"sparse_route", "SGA_NO_SPARSE_ROUTE", 1, 0, 1, 0, 1},
     {"batched_energy", "SGA_NO_MFMA_ENERGY", 1, 0, 1, 0, 2},
     {"force_general", "SGA_FORCE_GENERAL", 1, 1, 0, 0, 1},
@@ -440,7 +440,11 @@ int fields_pass(sga_engine *e, int r0, int count, double *energy, void *fields) 
 // fields and spin bits fit LDS, any single-site rule.  why: the reason when it does not.
 bool clf_possible(const sga_engine *e, const char **why) {
     const char *reason = nullptr;
-    if (e->csr || e->tsp) reason = "cached local fields: dense couplings only";
+    if (e->csr && e->from_dense)
+        // (the request may precede the NEXT sga_set_dense, so it is accepted; what cannot be served says why)
+        reason = "cached local fields: this sparse matrix was kept as CSR because the field cache was OFF when "
+                 "sga_set_dense ran, and its dense source is released -- call sga_set_field_cache before sga_set_dense";
+    else if (e->csr || e->tsp) reason = "cached local fields: dense couplings only";
     else if (!e->clf_problem)
         reason = "cached local fields need one model with integer-valued symmetric J, zero diagonal, h in "
                  "multiples of 1/2 and row sums below 2^24";
@@ -722,12 +726,6 @@ int sga_set_field_cache(sga_engine *e, int mode) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (mode != SGA_FIELD_CACHE_OFF && mode != SGA_FIELD_CACHE_ON && mode != SGA_FIELD_CACHE_AUTO)
         return fail(SGA_ERR_INVALID, "bad field-cache mode");
-    // A sparse matrix handed over dense with the cache OFF was kept as CSR and its dense source released: the
-    // cached-field sweep (a dense form) cannot serve it any more.  Said here, not at every later sga_sweep.
-    if (mode == SGA_FIELD_CACHE_ON && e->csr && e->from_dense)
-        return fail(SGA_ERR_UNSUPPORTED, "sga_set_field_cache(ON) after sga_set_dense: this sparse matrix was kept as CSR "
-                                         "because the field cache was OFF when it was set -- call sga_set_field_cache "
-                                         "before sga_set_dense (or hand the matrix over with an explicit storage)");
     e->field_cache = mode;
     return SGA_OK;
 }

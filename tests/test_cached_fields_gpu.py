@@ -375,8 +375,8 @@ def test_auto_routes_every_replica_by_its_own_acceptance(sg):
 
 def test_field_cache_request_after_a_sparse_matrix_was_taken_as_csr(sg):
     """sga_set_dense keeps a sparse integer matrix as CSR while the field cache is OFF (the C ABI's default) and
-    releases the dense source: asking for the cached-field sweep afterwards fails AT THE REQUEST, with the order
-    spelled out -- not at every later sweep."""
+    releases the dense source.  A later request for the cached-field sweep is accepted (it may precede the NEXT
+    sga_set_dense), and a sweep of the problem it cannot serve says exactly that -- the order of the two calls."""
     n = 4200
     rng = np.random.RandomState(n)
     J = np.zeros((n, n), np.float32)
@@ -386,14 +386,14 @@ def test_field_cache_request_after_a_sparse_matrix_was_taken_as_csr(sg):
     with sg.AnnealEngine(0) as e:
         e.set_dense(J, h)                       # field cache OFF: taken as CSR
         assert "source=dense-matrix" in e.describe()
-        with pytest.raises(sg.AnnealingError, match="before sga_set_dense"):
-            e.set_field_cache("on")
-        e.set_field_cache("auto")               # AUTO may fall back: accepted, sweeps run on the CSR forms
         e.init_replicas(4, seed=1)
         e.set_temperatures(np.full(4, 2.0))
+        e.set_field_cache("auto")               # AUTO may fall back: sweeps run on the CSR forms
         e.sweep(2)
-        e.set_field_cache("on")                 # the request first, then the matrix: the dense forms
-        e.set_dense(J, h)
+        e.set_field_cache("on")
+        with pytest.raises(sg.AnnealingError, match="before sga_set_dense"):
+            e.sweep(1)
+        e.set_dense(J, h)                       # the request first, then the matrix: the dense forms
         e.init_replicas(4, seed=1)
         e.set_temperatures(np.full(4, 2.0))
         e.sweep(2)

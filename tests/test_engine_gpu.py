@@ -1333,7 +1333,7 @@ def test_two_engines_of_one_process_run_different_forms(sg):
         with pytest.raises(sg.AnnealingError, match="unknown option"):
             a.set_option("no_such_option", 1)
         with pytest.raises(sg.AnnealingError, match="outside"):
-            a.set_option("clf_waves", 99)
+            a.set_option("clf_waves", 99)  # (beyond the documented range)
         assert set(option_names()) >= {"look_ahead", "clf_waves", "sparse_route", "batched_energy"}
 
 
