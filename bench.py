@@ -95,7 +95,7 @@ def host_cores():
 
 
 def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=None, h=None, eng=None,
-                 t_range=(10.0, 0.1)):
+                 t_range=(10.0, 0.1), scale=1.0):
     """Time the CPU port on a bounded sample and, with `eng` (already loaded with the same
     couplings), replay the identical sample -- same seed, replica ids, temperatures -- on the GPU:
     the energy gap between the two is the metric's "best-energy gap vs ref" (0 = bit-identical)."""
@@ -104,7 +104,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
     R = max(cores * budget_replicas_per_core, 1)
     if csr is not None:
         # sparse sweeps are cheap: scale the sample to seconds of CPU work
-        sweeps = max(1, int(sweeps * 100 * 32 * n / max(len(csr[1]), 1) * 10000 / n))
+        sweeps = max(1, int(scale * sweeps * 100 * 32 * n / max(len(csr[1]), 1) * 10000 / n))
         prob = oracle.Problem(csr=csr, h=np.zeros(n, np.float32) if h is None else h)
     else:
         prob = oracle.Problem(J=J_host, h=np.zeros(n, np.float32))
@@ -143,6 +143,84 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
 
 
+def build_workload(name, a, dev, world=1, dist=None, backend="nccl"):
+    """The problem of one BASELINE config, ready to load: {"n", "R", "n_ladders", "t_hot", "t_cold", "label",
+    "J" (dense device matrix | None), "csr" (host arrays | (None, length-only, None) | None), "h", "load": f(engine)}.
+    c2a: BASELINE configs[1] roofline instance; c3: configs[2]; c4: configs[3] (one rank's 1024 replicas);
+    c5: configs[4] (TSP QUBO, n = cities^2; 100 cities unless --cities)."""
+    from spin_glass_anneal_rl_amd import encoders as enc
+    n = a.spins
+    default_R = {"c2a": 1024, "c3": 4096, "c4": 1024, "c5": 2048}[name]
+    R = (a.replicas if name == a.workload else 0) or default_R
+    cities = a.cities if name == a.workload else 100
+    implicit = bool(a.implicit) and name == a.workload
+    storage = a.storage if name == a.workload else "f32"
+    out = {"n_ladders": 1, "t_hot": 10.0, "t_cold": 0.1, "label": "", "J": None, "csr": None, "implicit": implicit,
+           "cities": cities, "storage": storage}
+    bld = tsp = None
+    if name == "c4":  # BASELINE configs[3]: 500 tasks x 100 slots, cardinality penalties
+        bld = enc.scheduling_ising(np.full(500, 1.0), n_agents=1, time_horizon=100.0, time_discretization=100,
+                                   objective="total_time", penalty_weights={"assignment": 100.0, "capacity": 50.0})
+        out.update(t_hot=500.0, t_cold=5.0, label="C4: 50000-spin scheduling Ising (500 tasks x 100 slots)")
+        n = bld.n
+    elif name == "c5":  # BASELINE configs[4]: n = cities^2, degree 4(cities - 1)
+        rs = np.random.RandomState(5)
+        xy = rs.rand(cities, 2) * 100.0
+        dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+        out["dmat"] = dmat
+        tsp = None if implicit else enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
+        # BASELINE configs[4]: 32 ladders x 64 temperatures over 8 GPUs = 4 ladders per GPU; a smaller
+        # replica count keeps the 64-temperature ladders (256 replicas on one GPU = one rank's share)
+        out["n_ladders"] = (R * world) // 64 if (R * world) % 64 == 0 else 32
+        out.update(t_hot=200.0, t_cold=2.0, label=f"C5: {cities}-city TSP QUBO ({cities ** 2} spins)")
+        n = cities ** 2
+    h = torch.zeros(n, device=dev)
+    if name == "c2a":
+        J = make_sk_instance(n, 2, dev)
+        if dist is not None and backend == "nccl":
+            # J is replicated: rank 0's matrix goes to everybody over RCCL (400 MB, once, untimed) instead
+            # of trusting eight device generators to agree; the checksum below still verifies it
+            dist.broadcast(J, src=0)
+        out["J"] = J
+        load = lambda eng: eng.set_dense(J, h, storage=storage)  # noqa: E731
+    elif name == "c3":
+        csr = make_sparse_instance(n, 16, 3)
+        out["csr"] = csr
+        load = lambda eng: eng.set_csr(*csr, h)  # noqa: E731
+    elif bld is not None:
+        csr = bld.to_csr()
+        h = torch.from_numpy(bld.fields()).to(dev)
+        out["csr"] = csr
+
+        def load(eng):
+            eng.set_csr_storage("f32")  # the graded figure: (column int32, value fp32) entries, B = deg * 8 + 8
+            eng.set_csr(*csr, h)
+    elif implicit:  # the couplings are never stored: distances + penalty weights + fields
+        d32, w_city, w_pos, h_np, _ = enc.tsp_structure(dmat, 200.0, 200.0)
+        h = torch.from_numpy(h_np).to(dev)
+        d32_dev = torch.from_numpy(d32).to(dev)
+        load = lambda eng: eng.set_tsp(d32_dev, w_city, w_pos, h)  # noqa: E731
+    else:  # rows written on the device (int64 extents); host copy only while it is small
+        h = tsp[3]
+        nnz = int(tsp[1].numel())
+        if nnz <= 200_000_000:
+            out["csr"] = (tsp[0].cpu().numpy().astype(np.int32), tsp[1].cpu().numpy(), tsp[2].cpu().numpy())
+        else:
+            out["csr"] = (None, np.broadcast_to(np.int32(0), (nnz,)), None)  # length only
+        holder = [tsp]
+
+        def load(eng):
+            t = holder[0]
+            eng.set_csr(t[0], t[1], t[2], t[3])
+            if nnz > 200_000_000:  # 32 GB: the caller's arrays are released once the engine holds its layout
+                holder[0] = None
+                del t
+                torch.cuda.empty_cache()
+    out.update(n=n, R=R, h=h, load=load)
+    return out
+
+
+
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
     """Device stream-copy rate (read + write bytes / s) on this box, GB/s -- the practical HBM
     ceiling next to the 8 TB/s spec figure (SURVEY.md 8d asks for both denominators)."""
@@ -175,6 +253,178 @@ def pmc_traffic(tag, kernel):
         except (OSError, ValueError, KeyError):
             continue
     return None, None
+
+
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9   # MI355X: 256 CUs x 4 SIMD-32, 2.4 GHz (MI355X_MICROARCH.md)
+VALU_CYCLES = 2.0                  # a wave64 vector instruction holds its SIMD-32 for 2 cycles (same guide)
+
+
+def pmc_counters(tag, kernel):
+    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r*_<tag>_pmc.json)."""
+    import glob
+    if tag is None:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for name, e in d["kernels"].items():
+                if kernel in name:
+                    return e, os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def roofline_block(wl, name, R, avg_launch_s, launches, kernel_inst, copy_gbs=None, read_gbs=None):
+    """The `roofline` object of one bench line: algorithmic bytes per launch (one coupling row per
+    attempt) over the HIP-event-timed launch duration, against the HBM spec peak -- unless the committed PMC pass of
+    this configuration shows that the bytes never leave the caches (traffic < 0.2 x algorithmic): then the line
+    reports the bound the kernel really has (vector-instruction issue / the per-update dependent chain), with the
+    issue fraction from the committed instruction counts, and keeps the byte rate as `cache_served_GBs`."""
+    n, csr, implicit, cities, storage = wl["n"], wl["csr"], wl["implicit"], wl["cities"], wl["storage"]
+    elem = {"f32": 4, "i8": 1, "t2": 0.25}[storage]
+    per_launch_attempts = float(R) * n  # one sweep per launch on this rank
+    if implicit:
+        bytes_per_attempt = 8.0 * cities + 8.0       # two fp32 distance rows + the field (its own byte model)
+    elif csr is None:
+        bytes_per_attempt = float(n * elem)          # one coupling row (SURVEY.md 8d)
+    else:
+        bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
+    algo = per_launch_attempts * bytes_per_attempt
+    achieved = algo / avg_launch_s / 1e9 if launches else 0.0
+    # the committed PMC passes were taken on exactly these configurations
+    pmc_tag = None
+    if name == "c2a" and (n, R) == (10000, 1024):
+        pmc_tag = f"c2a_{storage}"
+    elif name == "c3" and (n, R) == (10000, 4096):
+        pmc_tag = "c3_csr"
+    elif name == "c4" and R == 1024:
+        pmc_tag = "c4_csr"
+    elif name == "c5" and (cities, R) in ((100, 2048), (1000, 256)):
+        pmc_tag = "c5_csr" if cities == 100 else "c5_1000_csr"
+    kernel_name = "sweep_tsp_kernel" if implicit else ("sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
+    if kernel_inst.startswith("sweep_csr_rows_kernel"):  # several updates per step (short integer rows: C3)
+        kernel_name = "sweep_csr_rows_kernel"
+    elif kernel_inst.startswith("sweep_tsp_par_kernel"):  # implicit TSP form, one update per wave
+        kernel_name = "sweep_tsp_par_kernel"
+    if implicit:
+        pmc_tag = f"c5_{cities}_implicit"
+    traffic, traffic_src = pmc_traffic(pmc_tag, kernel_name)
+    counters, counters_src = pmc_counters(pmc_tag, kernel_name)
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+         "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+         "traffic_source": traffic_src,
+         "algorithmic_bytes_per_launch": algo,
+         "kernel": kernel_name, "kernel_instantiation": kernel_inst,
+         "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+         "algorithmic_bytes_per_attempt": bytes_per_attempt}
+    if copy_gbs:
+        r["measured_stream_copy_GBs"] = copy_gbs
+        r["frac_of_measured_stream_copy"] = achieved / copy_gbs
+    if read_gbs:
+        r["measured_stream_read_GBs"] = read_gbs
+        r["frac_of_measured_stream_read"] = achieved / read_gbs
+    nbytes = None if csr is None else float(len(csr[1])) * 8.0
+    cache_resident = (traffic is not None and traffic < 0.2 * algo) or (traffic is None and implicit) or \
+                     (traffic is None and nbytes is not None and nbytes < 3.0e7)
+    if cache_resident:
+        # not an HBM-bound kernel: the bytes are served by L2 / the Infinity Cache.  What bounds it is how fast the
+        # SIMDs issue its (dependent) instruction stream: report the vector-issue fraction from the committed
+        # instruction counts of the same configuration -- wave-instructions x 2 cycles over SIMD-cycles of the launch
+        r["cache_served_GBs"] = achieved
+        r["bound"] = "valu-issue" if kernel_name in ("sweep_csr_rows_kernel",) else "latency"
+        valu = (counters or {}).get("SQ_INSTS_VALU")
+        issue_peak = SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9   # G wave-instructions / s
+        if valu and launches:
+            rate = valu / avg_launch_s / 1e9
+            r.update(achieved=rate, peak=issue_peak, unit="G wave-instr/s (VALU)", frac=min(rate / issue_peak, 1.0),
+                     issue_counters_source=counters_src, valu_wave_instructions_per_launch=valu,
+                     salu_wave_instructions_per_launch=(counters or {}).get("SQ_INSTS_SALU"),
+                     lds_wave_instructions_per_launch=(counters or {}).get("SQ_INSTS_LDS"),
+                     frac_at_4_cycles_per_instruction=min(2.0 * rate / issue_peak, 1.0))
+        else:
+            r.update(achieved=None, peak=issue_peak, unit="G wave-instr/s (VALU)", frac=None)
+        r["note"] = ("cache resident (PMC traffic far below the algorithmic bytes): paced by " +
+                     ("vector-instruction issue (several updates per step, one per row of lanes: sweep_csr_rows.hip)"
+                      if r["bound"] == "valu-issue" else
+                      "the dependent chain of one update (reduction, barrier, decision)") +
+                     ", not by HBM; `frac` = VALU wave-instructions x 2 cycles / SIMD-cycles of the launch (SIMD-32: a "
+                     "wave64 instruction issues over 2 cycles), `cache_served_GBs` = algorithmic bytes / launch time")
+        if implicit:
+            r["note"] += ("; different byte model from the graded CSR figure: the couplings are never stored, an attempt "
+                          f"reads two {4 * cities}-byte rows of the scaled distance table "
+                          f"({8 * cities ** 2 / 1e6:.0f} MB); the same chain as the CSR form, bit for bit")
+    elif csr is not None:
+        r["note"] = (f"CSR structure = {nbytes / 1e6:.0f} MB: streamed from HBM (up to 256 MB partly re-served by the "
+                     "Infinity Cache); bandwidth bound, DESIGN.md 4.2")
+    elif name == "c2a":
+        r["note"] = (
+            f"{n * n * elem / 1e6:.0f} MB of couplings against a 256 MB Infinity Cache: part of every pass is re-served "
+            "on chip, so this algorithmic rate is a fabric figure and can touch the HBM spec number; the HBM-bound "
+            "figure on a matrix beyond every cache is roofline_beyond_cache")
+    if r["frac"] is not None and r["frac"] > 1.0:   # (a byte rate above the HBM spec: cache served in part)
+        r["cache_served_GBs"] = achieved
+        r["frac"] = 1.0
+        r["frac_note"] = "algorithmic rate above the HBM spec figure (part of the matrix is re-served on chip): capped at 1"
+    return r
+
+
+def config_line(name, a, dev, local_rank, comm_dev, warmup=5, steps=10):
+    """A short line of another BASELINE config, run after the headline in the default invocation: the same engine
+    calls as `--workload <name>` (5 warm-up + 10 timed sweeps, exchange every 10), with a small CPU-oracle sample
+    replayed on the GPU (energy gap) beside it."""
+    import spin_glass_anneal_rl_amd as sg
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    from spin_glass_anneal_rl_amd.sharded import ShardedTempering
+    t_setup = time.perf_counter()
+    wl = build_workload(name, a, dev, 1)
+    n, R, n_ladders = wl["n"], wl["R"], wl["n_ladders"]
+    eng = sg.AnnealEngine(local_rank)
+    eng.use_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_tuning(waves_per_replica=0, sweeps_per_launch=1)
+    wl["load"](eng)
+    eng.set_field_cache("off")  # the graded form: one coupling-row read per proposal
+    ladder = np.tile(geometric_ladder(R // n_ladders, wl["t_hot"], wl["t_cold"]), n_ladders)
+    pt = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=n_ladders,
+                          dist=None, device=comm_dev)
+    done = 0
+
+    def step():
+        nonlocal done
+        pt.sweep(1)
+        done += 1
+        if a.exchange_interval > 0 and done % a.exchange_interval == 0:
+            pt.exchange(count=False)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.enable_timing(True)
+    eng.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = eng.kernel_time(reset=True)
+    eng.enable_timing(False)
+    kernel_inst = last_kernel()
+    line = {"workload": (wl["label"] or f"C3: {n}-spin CSR +-1 Ising") +
+                        f", CSR mean degree {len(wl['csr'][1]) / n:.1f}, {R} replicas/GPU, {n_ladders} geometric ladder(s) T "
+                        f"{wl['t_hot']:g}->{wl['t_cold']:g}, exchange every {a.exchange_interval}",
+            "value": float(R) * n * steps / dt, "unit": "attempts/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "kernel_ms_total": kernel_ms, "geometry": eng.describe(),
+            "kernel_instantiation": kernel_inst,
+            "roofline": roofline_block(wl, name, R, (kernel_ms / max(launches, 1)) * 1e-3, launches, kernel_inst),
+            "best_energy": eng.best(with_spins=False)[0]}
+    if not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(None, n, 42, csr=wl["csr"], h=wl["h"].cpu().numpy(), eng=eng,
+                                            t_range=(wl["t_hot"], wl["t_cold"]), budget_replicas_per_core=2, scale=0.25)
+    eng.close()
+    line["wall_s_with_setup"] = time.perf_counter() - t_setup
+    return line
 
 
 def spawn_ranks(n_ranks):
@@ -245,6 +495,8 @@ def main():
                          "(sga_autotune: part of the set-up, results unaffected)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short C3 / C4 / C5 lines that follow the headline in the default run")
     ap.add_argument("--no-beyond-cache", action="store_true",
                     help="skip the second roofline block (same kernel, 4.3 GB matrix beyond every cache)")
     ap.add_argument("--beyond-cache-spins", type=int, default=32768)
@@ -295,63 +547,16 @@ def main():
     import spin_glass_anneal_rl_amd as sg
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
 
-    n = a.spins
-    R = a.replicas or {"c2a": 1024, "c3": 4096, "c4": 1024, "c5": 2048}[a.workload]
-    n_ladders, t_hot, t_cold, label = 1, 10.0, 0.1, ""
-    if a.workload in ("c4", "c5"):
-        from spin_glass_anneal_rl_amd import encoders as enc
-        if a.workload == "c4":  # BASELINE configs[3]: 500 tasks x 100 slots, cardinality penalties
-            bld = enc.scheduling_ising(np.full(500, 1.0), n_agents=1, time_horizon=100.0,
-                                       time_discretization=100, objective="total_time",
-                                       penalty_weights={"assignment": 100.0, "capacity": 50.0})
-            t_hot, t_cold, label = 500.0, 5.0, "C4: 50000-spin scheduling Ising (500 tasks x 100 slots)"
-        else:                   # BASELINE configs[4]: n = cities^2, degree 4(cities - 1)
-            rs = np.random.RandomState(5)
-            xy = rs.rand(a.cities, 2) * 100.0
-            dmat = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
-            bld = None
-            tsp = None if a.implicit else enc.tsp_csr(dmat, city_visit=200.0, position_fill=200.0, device=dev)
-            # BASELINE configs[4]: 32 ladders x 64 temperatures over 8 GPUs = 4 ladders per GPU; a smaller
-            # replica count keeps the 64-temperature ladders (256 replicas on one GPU = one rank's share)
-            n_ladders = (R * world) // 64 if (R * world) % 64 == 0 else 32
-            t_hot, t_cold = 200.0, 2.0
-            label = f"C5: {a.cities}-city TSP QUBO ({a.cities ** 2} spins)"
-        n = bld.n if bld is not None else a.cities ** 2
+    wl = build_workload(a.workload, a, dev, world, dist=dist, backend=a.backend)
+    n, R, n_ladders, t_hot, t_cold, label = wl["n"], wl["R"], wl["n_ladders"], wl["t_hot"], wl["t_cold"], wl["label"]
+    J, csr, h = wl["J"], wl["csr"], wl["h"]
+    dmat = wl.get("dmat")
+    from spin_glass_anneal_rl_amd import encoders as enc
     Rg = R * world
-    h = torch.zeros(n, device=dev)
     eng = sg.AnnealEngine(local_rank)
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(waves_per_replica=a.waves, sweeps_per_launch=1)
-    J = csr = None
-    if a.workload == "c2a":
-        J = make_sk_instance(n, 2, dev)
-        if dist is not None and a.backend == "nccl":
-            # J is replicated: rank 0's matrix goes to everybody over RCCL (400 MB, once, untimed) instead
-            # of trusting eight device generators to agree; the checksum below still verifies it
-            dist.broadcast(J, src=0)
-        eng.set_dense(J, h, storage=a.storage)
-    elif a.workload == "c3":
-        csr = make_sparse_instance(n, 16, 3)
-        eng.set_csr(*csr, h)
-    elif bld is not None:
-        csr = bld.to_csr()
-        h = torch.from_numpy(bld.fields()).to(dev)
-        eng.set_csr_storage("f32")  # the graded figure: (column int32, value fp32) entries, B = deg * 8 + 8
-        eng.set_csr(*csr, h)
-    elif a.implicit:  # the couplings are never stored: distances + penalty weights + fields
-        d32, w_city, w_pos, h_np, _ = enc.tsp_structure(dmat, 200.0, 200.0)
-        h = torch.from_numpy(h_np).to(dev)
-        eng.set_tsp(torch.from_numpy(d32).to(dev), w_city, w_pos, h)
-    else:  # rows written on the device (int64 extents); host copy only while it is small
-        h = tsp[3]
-        eng.set_csr(tsp[0], tsp[1], tsp[2], h)
-        nnz = int(tsp[1].numel())
-        if nnz <= 200_000_000:
-            csr = (tsp[0].cpu().numpy().astype(np.int32), tsp[1].cpu().numpy(), tsp[2].cpu().numpy())
-        else:
-            csr = (None, np.broadcast_to(np.int32(0), (nnz,)), None)  # length only
-        del tsp
-        torch.cuda.empty_cache()
+    wl["load"](eng)
     ladder = np.tile(geometric_ladder(Rg // n_ladders, t_hot, t_cold), n_ladders)
     eng.set_field_cache("off")  # the graded figure: one coupling-row read per proposal
 
@@ -431,6 +636,7 @@ def main():
     eng.enable_timing(os.environ.get("SGA_BENCH_NOEVENTS") is None)
     eng.kernel_time(reset=True)
     pt.gather_calls, pt.gather_ms = 0, 0.0
+    pt.time_collectives = True
     debug = os.environ.get("SGA_BENCH_DEBUG") is not None
     marks = []
     t0 = time.perf_counter()
@@ -461,34 +667,10 @@ def main():
     elem = {"f32": 4, "i8": 1, "t2": 0.25}[a.storage]
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
-    if implicit:
-        bytes_per_attempt = 8.0 * a.cities + 8.0     # two fp32 distance rows + the field (its own byte model)
-    elif csr is None:
-        bytes_per_attempt = float(n * elem)          # one coupling row
-    else:
-        bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
-    achieved = per_launch_attempts * bytes_per_attempt / avg_launch_s / 1e9 if launches else 0.0
     best_e, _, _ = eng.best(with_spins=False)
     from spin_glass_anneal_rl_amd.engine import last_kernel
     kernel_inst = last_kernel()  # template arguments of what the timed steps launched
-    # the committed PMC passes were taken on exactly these configurations
-    pmc_tag = None
-    if a.workload == "c2a" and (n, R) == (10000, 1024):
-        pmc_tag = f"c2a_{a.storage}"
-    elif a.workload == "c3" and (n, R) == (10000, 4096):
-        pmc_tag = "c3_csr"
-    elif a.workload == "c4" and R == 1024:
-        pmc_tag = "c4_csr"
-    elif a.workload == "c5" and (a.cities, R) in ((100, 2048), (1000, 256)):
-        pmc_tag = "c5_csr" if a.cities == 100 else "c5_1000_csr"
-    kernel_name = "sweep_tsp_kernel" if implicit else ("sweep_dense_kernel" if csr is None else "sweep_csr_kernel")
-    if kernel_inst.startswith("sweep_csr_rows_kernel"):  # several updates per step (short integer rows: C3)
-        kernel_name = "sweep_csr_rows_kernel"
-    elif kernel_inst.startswith("sweep_tsp_par_kernel"):  # implicit TSP form, one update per wave
-        kernel_name = "sweep_tsp_par_kernel"
-    if implicit:
-        pmc_tag = f"c5_{a.cities}_implicit"
-    traffic, traffic_src = pmc_traffic(pmc_tag, kernel_name)
+    roof = roofline_block(wl, a.workload, R, avg_launch_s, launches, kernel_inst, copy_gbs, read_gbs)
 
     out = {
         "metric": "spin-flip attempts/s (replicas x spins x sweeps / s)",
@@ -507,8 +689,10 @@ def main():
         "ranks_seen": dist.get_world_size() if dist is not None else 1,
         "backend": (dist.get_backend() if dist is not None else None),
         "couplings_checksum_agree": checksum_agree, "couplings_checksum": f"{checksum:016x}",
-        "exchange": {"rounds_timed": pt.gather_calls, "allgather_ms_per_round":
-                     (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
+        # all-gather of the energies: device time between two events on the shared stream (RCCL), not the host
+        # time of the asynchronous enqueue; `enqueue_ms_per_round` is that host share
+        "exchange": {"rounds_timed": pt.gather_calls, "allgather_ms_per_round": pt.gather_device_ms_per_round(),
+                     "enqueue_ms_per_round": (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
                      "bytes_per_rank": 8 * R},
         "config": {"workload": ((label + ", couplings implicit (TSP structure: 2 distance rows per attempt)")
                                 if implicit else f"C2a: {n}-spin dense +-1 SK Ising" if csr is None else
@@ -522,42 +706,8 @@ def main():
                    "geometry": geometry,
                    "geometry_autotuned": autotuned,
                    "best_energy_rank0": best_e},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "measured_stream_copy_GBs": copy_gbs,
-                     "measured_stream_read_GBs": read_gbs,
-                     "frac_of_measured_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
-                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + "
-                                     "WRITE_SIZE, separate --pmc passes)",
-                     "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": per_launch_attempts * bytes_per_attempt,
-                     "kernel": kernel_name, "kernel_instantiation": kernel_inst,
-                     "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
-                     "algorithmic_bytes_per_attempt": bytes_per_attempt},
+        "roofline": roof,
     }
-    if implicit:
-        out["roofline"]["bound"] = "hbm"
-        out["roofline"]["note"] = (
-            "different byte model from the graded CSR figure: the couplings are never stored; an attempt reads "
-            f"two {4 * a.cities}-byte rows of the scaled distance table ({8 * a.cities ** 2 / 1e6:.0f} MB, cache "
-            "resident), so the kernel is bound by the per-update chain (reduction, barrier, decision), not by HBM; "
-            "the same chain as the CSR form, bit for bit")
-        out["roofline"]["cache_resident"] = True  # (its frac compares a cache-served rate with the HBM number)
-    if csr is not None:
-        nbytes = float(len(csr[1])) * 8.0
-        out["roofline"]["note"] = (
-            f"CSR structure = {nbytes / 1e6:.0f} MB: " +
-            ("cache resident (PMC traffic far below the algorithmic bytes): the sweep is paced by " +
-             ("vector-instruction issue (several updates per step, one per row of lanes: sweep_csr_rows.hip), not by HBM"
-              if kernel_name == "sweep_csr_rows_kernel" else "the dependent chain of one update, not by HBM")
-             if nbytes < 2.0e8 else
-             "streamed from HBM (up to 256 MB partly re-served by the Infinity Cache); bandwidth bound, "
-             "DESIGN.md 4.2"))
-    elif a.workload == "c2a" and not implicit:
-        out["roofline"]["note"] = (
-            f"{n * n * elem / 1e6:.0f} MB of couplings against a 256 MB Infinity Cache: part of every pass is re-served "
-            "on chip, so this algorithmic rate is a fabric figure and can touch the HBM spec number; the HBM-bound "
-            "figure on a matrix beyond every cache is roofline_beyond_cache")
     # the same workload with the couplings held as int8 / as two bit-planes (what
     # coupling_storage="auto" picks for integer / ternary J; exact arithmetic, identical
     # chain): reported beside the fp32 headline
@@ -742,6 +892,13 @@ def main():
                                            t_range=(t_hot, t_cold))
     else:
         out["cpu_baseline"] = None
+    # BASELINE configs[2], [3], [4] in the line the driver runs: short runs of the same engine calls as
+    # `--workload c3 | c4 | c5` (5 warm-up + 10 timed sweeps each), each with its own roofline and a small CPU sample
+    if a.workload == "c2a" and world == 1 and rank == 0 and not a.no_configs and not a.no_variants:
+        eng.close()
+        del J
+        torch.cuda.empty_cache()
+        out["configs"] = {name: config_line(name, a, dev, local_rank, comm_dev) for name in ("c3", "c4", "c5")}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

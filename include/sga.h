@@ -281,7 +281,7 @@ int sga_get_geometry(sga_engine *e, int *waves_per_replica, int *chunks_per_wave
 /* Measurement aid: the kernel instantiation (template arguments, waves per replica) that the calling
  * thread's last sga_sweep launched -- what a rocprofv3 trace of the same command must show. */
 int sga_last_kernel(char *buf, int buflen);
-/* Measurement aid: GB/s of a plain streaming read (16 bytes per lane) of a fresh `bytes`-byte
+/* Measurement aid: GB/s of a plain streaming read (every workgroup its own segment, eight non-temporal 16-byte loads per lane in flight) of a fresh `bytes`-byte
  * device buffer, `reps` passes -- the practical bandwidth of this device beside its spec figure. */
 int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per_s);
 /* Storage of CSR entries in the one-replica-per-workgroup bit-spin sweep forms (long rows; call before

@@ -1801,8 +1801,15 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                 if (since > 0) {
                     // (enter, leave): acceptance below which a replica is taken onto the cached-field kernel, above
                     // which it is given back (hysteresis)
-                    const double enter = e->use_t2 ? 0.16 : (e->want_i8 ? 0.50 : 0.90);
-                    const double leave = e->use_t2 ? 0.24 : (e->want_i8 ? 0.66 : 2.0);
+                    // Break-even acceptance of ONE replica = (what an update costs its chain on the row kernel) / (what
+                    // an accept costs it on the cached-field kernel).  Both kernels are paced by a replica's serial
+                    // chain, not by the chip, whenever only part of the replicas is hot: ~1.5 us per accept (1.15 alone
+                    // on its CU ... 1.7 with busy neighbours), and per update 0.38 us on bit-planes / 0.58 us on int8
+                    // rows at n = 10^4, ~0.3 us on short rows (profiles/r04_routing.py; fp32 rows: estimate).
+                    const double kn = (double)n / 1000.0;
+                    const double t_upd = e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
+                    const double theta = t_upd / 1.5;
+                    const double enter = 0.8 * theta, leave = 1.2 * theta;
                     bool back = false;
                     if (e->opt[OPT_REPLICA_ROUTING] != 0) {
                         for (int r2 = 0; r2 < e->R; ++r2) {

@@ -1082,20 +1082,28 @@ hipError_t launch_op_exchange(float *spins, float *tmp_rows, float *energies, co
 namespace sga {
 // ---------------------------------------------------------------------------------------
 // Streaming-read probe: what this box delivers to a plain 16-byte-per-lane read of a buffer far
-// larger than the caches -- the practical denominator beside the 8 TB/s spec figure.  (Eight
-// loads in flight per lane and half the workgroups measured 2-4 % lower.)
+// larger than the caches -- the practical denominator beside the 8 TB/s spec figure.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) probe_read_kernel(const float4 *__restrict__ x, long long n4,
+// Round 4 (profiles/src/probe_bw.hip, profiles/r04_probe_bw.txt: 56 patterns on one box): every workgroup streams
+// its own contiguous segment with eight independent NON-TEMPORAL 16-byte loads in flight per lane -- 7.1-7.2 TB/s;
+// the same with plain loads 6.4-6.5 TB/s; round 3's grid-stride pattern with four plain loads 5.8 TB/s, below what
+// the dense sweep kernel itself sustains beyond the caches (6.65 TB/s), i.e. not a ceiling.
+__global__ void __launch_bounds__(256) probe_read_kernel(const float4 *__restrict__ x, long long n4, long long seg4,
                                                          float *sink) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long long base = (long long)blockIdx.x * seg4;
+    const long long end = base + seg4 < n4 ? base + seg4 : n4;
+    const long long step = blockDim.x;
     float acc = 0.0f;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent loads in flight per lane
-        const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
-        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) +
-               (d.x + d.y + d.z + d.w);
+    long long i = base + threadIdx.x;
+    for (; i + 7 * step < end; i += 8 * step) {
+        f4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(&x[i + q * step]));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += (v[q].x + v[q].y) + (v[q].z + v[q].w);
     }
-    for (; i < n4; i += stride) {
+    for (; i < end; i += step) {
         const float4 a = x[i];
         acc += a.x + a.y + a.z + a.w;
     }
@@ -1127,14 +1135,16 @@ hipError_t launch_checksum(const void *buf, long long bytes, unsigned long long 
 }
 
 hipError_t launch_probe_read(const void *buf, long long bytes, float *sink, hipStream_t st) {
-    hipLaunchKernelGGL(probe_read_kernel, dim3(256 * 32), dim3(256), 0, st,
-                       static_cast<const float4 *>(buf), bytes / 16, sink);
+    const long long n4 = bytes / 16;
+    const int blocks = 256 * 128;  // 128 segments per CU
+    hipLaunchKernelGGL(probe_read_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float4 *>(buf), n4,
+                       (n4 + blocks - 1) / blocks, sink);
     return hipGetLastError();
 }
 }  // namespace sga
 
 namespace sga {
-static thread_local char g_sweep_kernel[192] = "";
+static thread_local char g_sweep_kernel[448] = "";
 void note_sweep_kernel(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

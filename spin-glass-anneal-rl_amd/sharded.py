@@ -43,7 +43,9 @@ class ShardedTempering:
             if t.size != self.R_global:
                 raise ValueError("slot_temps must cover the global replica set")
             engine.set_ladder(t, n_ladders)
-        self.gather_calls, self.gather_ms = 0, 0.0  # all-gather rounds and their host wall time
+        self.gather_calls, self.gather_ms = 0, 0.0  # all-gather rounds and the host time of their (asynchronous) enqueue
+        self.time_collectives = False               # bracket every stream-ordered all-gather by two events
+        self._gather_events = []
         self._local_E = torch.zeros(self.R_local, dtype=torch.float64, device=self.device)
         self._all_E = torch.zeros(self.R_global, dtype=torch.float64, device=self.device)
 
@@ -67,11 +69,25 @@ class ShardedTempering:
         if self.dist is None:
             self._all_E.copy_(self._local_E)
             return self._all_E
+        timed = self.time_collectives and self._all_E.is_cuda
+        if timed:  # device time of the collective: two events on the stream that carries it
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self._all_E.device))
         t0 = time.perf_counter()
         self._all_gather(ordered)
         self.gather_calls += 1
         self.gather_ms += (time.perf_counter() - t0) * 1e3
+        if timed:
+            ev[1].record(torch.cuda.current_stream(self._all_E.device))
+            self._gather_events.append(ev)
         return self._all_E
+
+    def gather_device_ms_per_round(self):
+        """Mean device time of the timed all-gathers (events on the collective's stream), None without any."""
+        if not self._gather_events:
+            return None
+        self._gather_events[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._gather_events) / len(self._gather_events)
 
     def _all_gather(self, ordered: bool = False):
         if self.dist.get_backend() == "nccl":
