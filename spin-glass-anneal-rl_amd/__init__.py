@@ -19,7 +19,7 @@ from .parallel_tempering import ParallelTempering, ParallelTemperingConfig
 from .kernel_manager import CUDAKernelManager, GPUMemoryOptimizer, HIPKernelManager
 from .scheduler import SpinGlassScheduler
 from .sharded import LocalShardedTempering, ShardedTempering
-from .multi_gpu import MultiGPUAnnealer, MultiGPUConfig
+from .multi_gpu import LoadBalancer, MultiGPUAnnealer, MultiGPUConfig
 from .batch import BatchConfig, BatchProcessor
 from . import encoders
 from .encoders import IsingBuilder
@@ -31,7 +31,7 @@ __all__ = [
     "AnnealingResult", "IsingModel", "IsingModelConfig", "SpinDynamics", "UpdateRule",
     "GPUAnnealer", "GPUAnnealerConfig", "ParallelTempering", "ParallelTemperingConfig",
     "HIPKernelManager", "CUDAKernelManager", "GPUMemoryOptimizer", "SpinGlassScheduler",
-    "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig",
+    "ShardedTempering", "LocalShardedTempering", "MultiGPUAnnealer", "MultiGPUConfig", "LoadBalancer",
     "encoders", "IsingBuilder", "BatchConfig", "BatchProcessor", "EnergyComputer", "ComputeMode",
     "EnergyStats",
 ]

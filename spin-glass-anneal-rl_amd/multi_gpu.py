@@ -43,7 +43,8 @@ class MultiGPUConfig:
     load_balancing: bool = True
     fault_tolerance: bool = True
     max_retries: int = 3
-    replicas_per_gpu: int = 64  # build-specific: replica_exchange shard size
+    replicas_per_gpu: int = 64  # build-specific: replica_exchange shard size when n_replicas is not given
+    n_ladders: int = 1          # build-specific: independent temperature ladders (BASELINE configs[4]: 32)
 
     def __post_init__(self):
         if not self.gpu_ids:
@@ -53,6 +54,8 @@ class MultiGPUConfig:
                              "'replica_exchange']")
         if self.communication_backend not in ("nccl", "gloo", "mpi"):
             raise ValueError("Backend must be one of ['nccl', 'gloo', 'mpi']")
+        if self.n_ladders < 1:
+            raise ValueError("n_ladders must be positive")
 
 
 def _dist():
@@ -110,51 +113,148 @@ class MultiGPUAnnealer:
         cfg = GPUAnnealerConfig(**{**self.annealer_config.__dict__, "device_index": gpu})
         return GPUAnnealer(cfg).anneal(model)
 
-    def anneal_replica_exchange(self, model: IsingModel) -> AnnealingResult:
+    # engine construction is a seam: the gloo tests on CPU put the oracle-backed test double here
+    def _make_engine(self, gpu: int, model: IsingModel):
+        eng = AnnealEngine(gpu)
+        eng.set_field_cache(self.annealer_config.field_cache)
+        model.load_into(eng, storage=self.annealer_config.coupling_storage)
+        return eng
+
+    def anneal_replica_exchange(self, model: IsingModel, n_replicas: Optional[int] = None) -> AnnealingResult:
+        """Parallel tempering with the replicas sharded over the GPUs (reference annealing/multi_gpu.py:233-308).
+
+        n_replicas: replicas over ALL GPUs (the reference's default is one per device; here
+        `replicas_per_gpu` per device -- a GPU sweeps thousands for the price of one).  Under
+        torch.distributed every rank calls this with the same arguments: the ranks verify that they hold the
+        same couplings (sga_problem_checksum, all-gathered) before the first sweep, the exchange step
+        all-gathers the energies on the stream the engine launches on (no host synchronisation in a round), and
+        `energy_history` is the GLOBAL best (all-reduce MIN) after every synchronisation interval."""
         cfg, acfg = self.config, self.annealer_config
         dist = _dist()
-        Rl = cfg.replicas_per_gpu
         world = dist.get_world_size() if dist is not None else len(cfg.gpu_ids)
+        if n_replicas is None:
+            Rl = cfg.replicas_per_gpu
+        else:
+            if n_replicas < world or n_replicas % world != 0:
+                raise ValueError(f"n_replicas ({n_replicas}) must be a positive multiple of the number of GPUs ({world})")
+            Rl = n_replicas // world
         Rg = Rl * world
-        temps = np.asarray(temperature_ladder(Rg, acfg.final_temp, acfg.initial_temp, "geometric")
-                           if Rg > 1 else [acfg.final_temp])
+        n_ladders = cfg.n_ladders
+        if Rg % n_ladders != 0:
+            raise ValueError(f"{Rg} replicas do not split into {n_ladders} ladders")
+        L = Rg // n_ladders
+        one = np.asarray(temperature_ladder(L, acfg.final_temp, acfg.initial_temp, "geometric")
+                         if L > 1 else [acfg.final_temp])
+        temps = np.tile(one, n_ladders)
         seed = fresh_seed(acfg.random_seed)
+        side = None
         if dist is not None:
             rank = dist.get_rank()
             gpu = int(os.environ.get("LOCAL_RANK", rank))
-            seed_t = torch.tensor([seed], dtype=torch.int64,
-                                  device=torch.device("cuda", gpu) if dist.get_backend() == "nccl"
-                                  else torch.device("cpu"))
+            on_gpu = dist.get_backend() == "nccl"
+            comm_dev = torch.device("cuda", gpu) if on_gpu else torch.device("cpu")
+            seed_t = torch.tensor([seed], dtype=torch.int64, device=comm_dev)
             dist.broadcast(seed_t, src=0)  # all ranks must share the Philox key
-            eng = AnnealEngine(gpu)
-            eng.set_field_cache(acfg.field_cache)
-            model.load_into(eng, storage=acfg.coupling_storage)
-            pt = ShardedTempering(eng, Rl, rank, world, int(seed_t.item()), temps, 1, dist,
-                                  torch.device("cuda", gpu))
+            eng = self._make_engine(gpu, model)
+            if on_gpu:
+                # ONE stream for the engine's kernels and the collectives: energies copy -> all-gather -> exchange
+                # kernel are ordered by it (ShardedTempering._stream_ordered), no host synchronisation in a round
+                side = torch.cuda.Stream(comm_dev)
+                torch.cuda.set_stream(side)
+                eng.use_stream(side.cuda_stream)
+            self._same_couplings_everywhere([eng], dist, comm_dev)
+            pt = ShardedTempering(eng, Rl, rank, world, int(seed_t.item()), temps, n_ladders, dist, comm_dev)
             engines = [eng]
         else:
-            engines = [AnnealEngine(g) for g in cfg.gpu_ids]
+            engines = [self._make_engine(g, model) for g in cfg.gpu_ids]
+            self._same_couplings_everywhere(engines, None, None)
+            pt = LocalShardedTempering(engines, Rl, seed, temps, n_ladders)
+        self._engines = engines
+        done, history, rounds = 0, [], 0
+        try:
+            while done < acfg.n_sweeps:
+                step = min(cfg.synchronization_interval, acfg.n_sweeps - done)
+                pt.sweep(step)
+                done += step
+                if L > 1 and done < acfg.n_sweeps:
+                    # (sharded: no count read-back -- the round stays on the stream; the totals are read once below)
+                    pt.exchange(count=False) if dist is not None else pt.exchange()
+                    rounds += 1
+                best_here = float(min(e.best(with_spins=False)[0] for e in engines))
+                if dist is not None:  # the run's best so far, over all ranks
+                    t = torch.tensor([best_here], dtype=torch.float64, device=pt.device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    best_here = float(t.item())
+                history.append(best_here)
+            best_e, best_s, _ = pt.global_best()
+            attempts, accepts = (engines[0].exchange_stats() if rounds else (np.zeros(0), np.zeros(0)))
+        finally:
+            if side is not None:
+                side.synchronize()
+                torch.cuda.set_stream(torch.cuda.default_stream(side.device))
             for e in engines:
-                e.set_field_cache(acfg.field_cache)
-                model.load_into(e, storage=acfg.coupling_storage)
-            pt = LocalShardedTempering(engines, Rl, seed, temps, 1)
-        done, history = 0, []
-        while done < acfg.n_sweeps:
-            step = min(cfg.synchronization_interval, acfg.n_sweeps - done)
-            pt.sweep(step)
-            done += step
-            if Rg > 1 and done < acfg.n_sweeps:
-                pt.exchange()
-            history.append(float(min(e.best(with_spins=False)[0] for e in engines)))
-        best_e, best_s, _ = pt.global_best()
-        for e in engines:
-            e.close()
-        return AnnealingResult(
+                e.close()
+            self._engines = []
+        result = AnnealingResult(
             best_configuration=torch.from_numpy(best_s.astype(np.float32)), best_energy=best_e,
             energy_history=history, temperature_history=[float(temps.min())] * len(history),
             acceptance_rate_history=[], total_time=0.0, n_sweeps=acfg.n_sweeps,
             algorithm="replica_exchange", device=str(self.master_device),
             random_seed=acfg.random_seed)
+        # (the reference passes metadata= to AnnealingResult, which has no such field, multi_gpu.py:302-307;
+        #  the same facts as attributes of the returned record)
+        result.metadata = {"strategy": "replica_exchange", "n_replicas": Rg, "n_ladders": n_ladders,
+                           "exchange_rounds": rounds, "exchange_attempts": int(np.sum(attempts)),
+                           "exchanges": int(np.sum(accepts)), "world_size": world}
+        return result
+
+    @staticmethod
+    def _same_couplings_everywhere(engines, dist, comm_dev):
+        """Every shard must sweep the SAME problem (J is replicated per device, reference multi_gpu.py:110-132):
+        the engines' checksums of the couplings as the kernels read them are compared -- across the engines of
+        this process and, under torch.distributed, across all ranks -- and a disagreement stops the run."""
+        sums = [e.problem_checksum() for e in engines]
+        if any(c != sums[0] for c in sums):
+            raise AnnealingError(f"the GPUs hold different couplings (checksums {[f'{c:016x}' for c in sums]})")
+        if dist is None:
+            return
+        mine = torch.tensor([sums[0] - (1 << 64) if sums[0] >= (1 << 63) else sums[0]], dtype=torch.int64,
+                            device=comm_dev)
+        every = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=comm_dev)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(every, mine)
+        else:
+            dist.all_gather(list(every.chunk(dist.get_world_size())), mine)
+        if not bool((every == every[0]).all().item()):
+            raise AnnealingError("the ranks hold different couplings (checksums "
+                                 f"{[f'{int(c) & 0xFFFFFFFFFFFFFFFF:016x}' for c in every.tolist()]})")
+
+    # ------------------------------------------------------------------ reference :456-481
+    def get_device_utilization(self) -> dict:
+        """Memory of every configured GPU (reference multi_gpu.py:456-474): what the driver reports as in use on
+        the device -- the engine's HBM buffers are hipMalloc'ed outside torch's allocator, so
+        `torch.cuda.memory_allocated` alone would miss them -- beside torch's own figures."""
+        out = {}
+        for dev in self.devices:
+            free, total = torch.cuda.mem_get_info(dev)
+            out[f"gpu_{dev.index}"] = {
+                "memory_allocated": total - free,
+                "memory_reserved": torch.cuda.memory_reserved(dev),
+                "memory_allocated_by_torch": torch.cuda.memory_allocated(dev),
+                "memory_total": total,
+                "memory_utilization": (total - free) / total * 100.0,
+            }
+        return out
+
+    def cleanup(self):
+        """Release what a run may have left on the GPUs (reference multi_gpu.py:476-481): engines of an
+        interrupted run and torch's cached blocks."""
+        for e in getattr(self, "_engines", []):
+            e.close()
+        self._engines = []
+        for dev in self.devices:
+            with torch.cuda.device(dev):
+                torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ dispatch (reference :309-351)
     def anneal(self, models: Any) -> Any:
@@ -180,3 +280,35 @@ class MultiGPUAnnealer:
             return results
         except Exception as exc:  # noqa: BLE001 - mirrors the reference's wrapping
             raise AnnealingError(f"Multi-GPU annealing failed: {exc}") from exc
+
+
+class LoadBalancer:
+    """Greedy placement of workloads on the least loaded device, weighted by capability (reference
+    annealing/multi_gpu.py:484-549: capability = memory x compute units, normalised to the best device)."""
+
+    def __init__(self, devices: List[torch.device]):
+        self.devices = list(devices)
+        self.device_loads = {d: 0.0 for d in self.devices}
+        self.device_capabilities = self._assess_device_capabilities()
+
+    def _assess_device_capabilities(self):
+        cap = {}
+        for d in self.devices:
+            if torch.cuda.is_available() and d.type == "cuda":
+                props = torch.cuda.get_device_properties(d)
+                cap[d] = float(props.total_memory) * props.multi_processor_count
+            else:
+                cap[d] = 1.0
+        top = max(cap.values())
+        return {d: c / top for d, c in cap.items()}
+
+    def select_device(self, workload_size: float) -> torch.device:
+        best = min(self.devices, key=lambda d: self.device_loads[d] / self.device_capabilities[d])
+        self.device_loads[best] += workload_size
+        return best
+
+    def release_device(self, device: torch.device, workload_size: float):
+        self.device_loads[device] = max(0.0, self.device_loads[device] - workload_size)
+
+    def get_load_distribution(self):
+        return {str(d): load for d, load in self.device_loads.items()}

@@ -84,8 +84,8 @@ class ShardedTempering:
 
     def gather_device_ms_per_round(self):
         """Mean device time of the timed all-gathers (events on the collective's stream), None without any."""
-        if not self._gather_events:
-            return None
+        if not self._gather_events:  # host-side collectives (gloo on CPU tensors) are synchronous: their wall time
+            return (self.gather_ms / self.gather_calls) if self.gather_calls else None
         self._gather_events[-1][1].synchronize()
         return sum(a.elapsed_time(b) for a, b in self._gather_events) / len(self._gather_events)
 

@@ -94,5 +94,23 @@ class OracleEngine:
     def slot_map(self):
         return self.slot_to_rep.copy()
 
+    def exchange_stats(self):
+        return self.ex_att.copy(), self.ex_acc.copy()
+
+    def problem_checksum(self):
+        """What sga_problem_checksum stands for: a 64-bit digest of the couplings and fields this engine sweeps."""
+        import hashlib
+        d = hashlib.sha256()
+        for a in (self.prob.J, self.prob.h):
+            if a is not None:
+                d.update(np.ascontiguousarray(a).tobytes())
+        return int.from_bytes(d.digest()[:8], "little")
+
+    def shares_torch_stream(self):
+        return False
+
+    def use_stream(self, handle):
+        pass
+
     def close(self):
         pass

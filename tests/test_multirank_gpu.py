@@ -178,3 +178,53 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     q = json.loads(plain.stdout.splitlines()[0])
     assert q["backend"] is None and q["couplings_checksum"] == d["couplings_checksum"]
     assert q["config"]["best_energy_rank0"] == d["config"]["best_energy_rank0"]
+
+
+def _class_rank_main(with_dist, port, out_path):
+    """MultiGPUAnnealer.anneal (strategy replica_exchange) in a fresh process: under a one-rank RCCL group, or
+    without torch.distributed (one process owning the GPU)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    import torch.distributed as dist
+    import spin_glass_anneal_rl_amd as sg
+    torch.cuda.set_device(0)
+    if with_dist:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    rng = np.random.RandomState(5)
+    J = np.triu(rng.randint(0, 2, (N_SPINS, N_SPINS)) * 2 - 1, 1).astype(np.float32)
+    J, h = J + J.T, rng.randint(-1, 2, N_SPINS).astype(np.float32)
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=N_SPINS, use_sparse=False))
+    m.set_couplings_from_matrix(torch.from_numpy(J))
+    m.external_fields = torch.from_numpy(h)
+    ann = sg.MultiGPUAnnealer(sg.MultiGPUConfig(gpu_ids=[0], strategy="replica_exchange", synchronization_interval=2,
+                                                replicas_per_gpu=R_GLOBAL, n_ladders=2),
+                              sg.GPUAnnealerConfig(n_sweeps=12, initial_temp=6.0, final_temp=0.3, random_seed=SEED))
+    res = ann.anneal(m)
+    util = ann.get_device_utilization()
+    ann.cleanup()
+    np.savez(out_path, best=res.best_energy, cfg=res.best_configuration.numpy(), hist=np.asarray(res.energy_history),
+             exchanges=res.metadata["exchanges"], attempts=res.metadata["exchange_attempts"],
+             mem=util["gpu_0"]["memory_allocated"], total=util["gpu_0"]["memory_total"])
+    if with_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_multi_gpu_annealer_over_a_one_rank_rccl_group_equals_the_plain_call(tmp_path):
+    """The product's class path (MultiGPUAnnealer.anneal -> anneal_replica_exchange) under torch.distributed with
+    backend "nccl": couplings checksum all-gathered, engine on torch's side stream (exchange rounds without host
+    synchronisation), all-reduced energy history -- the same result as the call without a process group."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for with_dist in (False, True):
+        path = str(tmp_path / f"class_{int(with_dist)}.npz")
+        p = ctx.Process(target=_class_rank_main, args=(with_dist, _free_port(), path))
+        p.start()
+        p.join(timeout=600)
+        assert p.exitcode == 0
+        out[with_dist] = dict(np.load(path))
+    a, b = out[False], out[True]
+    assert a["best"] == b["best"] and np.array_equal(a["cfg"], b["cfg"]) and np.array_equal(a["hist"], b["hist"])
+    assert a["exchanges"] == b["exchanges"] > 0 and a["attempts"] == b["attempts"] and len(a["hist"]) == 6
+    assert 0 < a["mem"] <= a["total"]

@@ -120,3 +120,105 @@ def test_one_rank_group_with_the_collectives_forced_equals_the_plain_run():
         assert o["swaps"] == single["swaps"] and np.array_equal(o["energies"], single["energies"])
         assert np.array_equal(o["slot_map"], single["slot_map"]) and np.array_equal(o["spins"], single["spins"])
         assert o["best"][0] == single["best"][0] and np.array_equal(o["best"][1], single["best"][1])
+
+
+# ----------------------------------------------------------------------------- the class path (annealing/multi_gpu.py)
+def _annealer(corrupt_rank=None, n_ladders=1):
+    """MultiGPUAnnealer with the engine seam filled by the oracle-backed test double (no GPU here: the constructor's
+    device checks are skipped, everything else is the product's code)."""
+    import spin_glass_anneal_rl_amd as sg
+
+    class OracleBacked(sg.MultiGPUAnnealer):
+        def __init__(self, config, annealer_config):
+            self.config, self.annealer_config = config, annealer_config
+            self.devices = [torch.device("cpu")]
+            self.master_device = self.devices[0]
+
+        def _make_engine(self, gpu, model):
+            J = model.couplings.numpy().copy()
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            if corrupt_rank is not None and rank == corrupt_rank:
+                J[0, 1] = J[1, 0] = -J[0, 1] if J[0, 1] != 0 else 1.0   # one coupling differs on this rank
+            return OracleEngine(J=J, h=model.external_fields.numpy().copy())
+
+    cfg = sg.MultiGPUConfig(gpu_ids=[0], strategy="replica_exchange", communication_backend="gloo",
+                            synchronization_interval=2, replicas_per_gpu=R_GLOBAL, n_ladders=n_ladders)
+    acfg = sg.GPUAnnealerConfig(n_sweeps=14, initial_temp=6.0, final_temp=0.3, random_seed=SEED)
+    return OracleBacked(cfg, acfg)
+
+
+def _model():
+    import spin_glass_anneal_rl_amd as sg
+    J, h = _instance()
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=N_SPINS, use_sparse=False))
+    m.set_couplings_from_matrix(torch.from_numpy(J))
+    m.external_fields = torch.from_numpy(h)
+    return m
+
+
+def _class_worker(rank, world, port, q, corrupt_rank, n_ladders):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = _annealer(corrupt_rank, n_ladders).anneal_replica_exchange(_model(), n_replicas=R_GLOBAL)
+        q.put((rank, dict(best=res.best_energy, cfg=res.best_configuration.numpy(), hist=res.energy_history,
+                          meta=res.metadata)))
+    except Exception as exc:  # noqa: BLE001 - reported to the parent
+        q.put((rank, dict(error=f"{type(exc).__name__}: {exc}")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _class_ranks(world, corrupt_rank=None, n_ladders=1):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_class_worker, args=(r, world, port, q, corrupt_rank, n_ladders)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_multi_gpu_annealer_two_ranks_equal_one_process():
+    """MultiGPUAnnealer.anneal_replica_exchange(model, n_replicas) under a 2-rank process group == the same call in
+    one process: global best, configuration, the all-reduced energy history, the exchange totals; two ladders too."""
+    for n_ladders in (1, 2):
+        single = _annealer(None, n_ladders).anneal_replica_exchange(_model(), n_replicas=R_GLOBAL)
+        assert single.metadata["n_replicas"] == R_GLOBAL and single.metadata["exchanges"] > 0
+        got = _class_ranks(2, None, n_ladders)
+        for rank in (0, 1):
+            o = got[rank]
+            assert "error" not in o, o
+            assert o["best"] == single.best_energy and np.array_equal(o["cfg"], single.best_configuration.numpy())
+            assert o["hist"] == single.energy_history and len(o["hist"]) == 7
+            assert o["meta"]["exchanges"] == single.metadata["exchanges"] and o["meta"]["world_size"] == 2
+            assert o["meta"]["exchange_attempts"] == single.metadata["exchange_attempts"]
+
+
+def test_multi_gpu_annealer_refuses_ranks_with_different_couplings():
+    """One coupling flipped on rank 1: every rank stops before the first sweep, saying so."""
+    got = _class_ranks(2, corrupt_rank=1)
+    for rank in (0, 1):
+        assert "error" in got[rank] and "different couplings" in got[rank]["error"], got[rank]
+
+
+def test_multi_gpu_annealer_interface_of_the_reference():
+    """Signature and helpers of annealing/multi_gpu.py:234,456,476,484-549."""
+    import inspect
+    import spin_glass_anneal_rl_amd as sg
+    sig = inspect.signature(sg.MultiGPUAnnealer.anneal_replica_exchange)
+    assert list(sig.parameters) == ["self", "model", "n_replicas"] and sig.parameters["n_replicas"].default is None
+    for name in ("anneal", "anneal_data_parallel", "anneal_replica_exchange", "get_device_utilization", "cleanup"):
+        assert callable(getattr(sg.MultiGPUAnnealer, name))
+    with np.testing.assert_raises(ValueError):
+        _annealer().anneal_replica_exchange(_model(), n_replicas=0)
+    lb = sg.LoadBalancer([torch.device("cpu"), torch.device("cpu", 0)])
+    d0 = lb.select_device(2.0)
+    d1 = lb.select_device(1.0)
+    assert d0 != d1 or len({d0, d1}) == 1
+    lb.release_device(d0, 2.0)
+    assert set(lb.get_load_distribution().values()) <= {0.0, 1.0, 2.0} and lb.select_device(0.5) == d0
