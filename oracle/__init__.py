@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsg_oracle.so")
+# SG_ORACLE_LIBRARY: another build of the same source (oracle/Makefile `asan`: ASan + UBSan, tests/test_sanitizers.py)
+_SO = os.environ.get("SG_ORACLE_LIBRARY") or os.path.join(_HERE, "libsg_oracle.so")
 
 SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
@@ -22,7 +23,8 @@ def build(force=False):
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+        target = ["asan"] if _SO.endswith("_asan.so") else []
+        subprocess.run(["make", "-C", _HERE, "-B"] + target, check=True, capture_output=True)
     return _SO
 
 

@@ -299,10 +299,13 @@ def case_wire_formats(out):
     J = pm1_couplings(12, 21)
     g = torch.Generator().manual_seed(22)
     h = torch.randint(-2, 3, (12,), generator=g).float()
+    torch.manual_seed(23)                # the model draws its spins from the global generator: seeded HERE, so
+    np.random.seed(23)                   # that the case does not depend on what ran before it
     m = dense_model(J, h)
     ann = GPUAnnealer(GPUAnnealerConfig(n_sweeps=40, initial_temp=3.0, final_temp=0.2, record_interval=4,
                                         random_seed=5))
     res = ann.anneal(m)
+    res.total_time = 0.25                # (wall time of this run: pinned, so that regenerating changes nothing)
     path = os.path.join(out, "wire_result_reference.npz")
     res.save(path)                       # the reference's own writer
     back = type(res).load(path)          # and its own reader, as a sanity check of the file
@@ -470,8 +473,9 @@ def case_diagnostics(out):
     """SpinDynamics.get_autocorrelation_time / thermal_equilibrium_check (core/spin_dynamics.py:361-421)
     on recorded histories: a real run's energy / magnetisation series and synthetic ones (AR(1) series of
     several correlation lengths, a drifting series, short and constant ones)."""
+    torch.manual_seed(5)                 # before the model: its initial spins come from the global generator
+    np.random.seed(5)
     model = dense_model(pm1_couplings(48, 12))
-    torch.manual_seed(5)
     dyn = SpinDynamics(model, temperature=2.5)
     for _ in range(260):
         dyn.sweep()
@@ -511,6 +515,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--only", default="")
+    ap.add_argument("--compare", default="",
+                    help="after writing, compare every array of every .npz in --out with the same file under this "
+                         "directory (the committed fixtures): prints the differences, exit code 1 if there are any")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(1)
@@ -588,6 +595,31 @@ def main():
         case_encoders(a.out)
     if want("diagnostics"):
         case_diagnostics(a.out)
+    if a.compare:
+        sys.exit(compare_dirs(a.out, a.compare))
+
+
+def compare_dirs(new, old):
+    """Content comparison of two fixture directories (npz archives carry time stamps: bytes differ, arrays must not)."""
+    import glob
+    bad = 0
+    names = sorted({os.path.basename(p) for d in (new, old) for p in glob.glob(os.path.join(d, "*.npz"))})
+    for name in names:
+        pa, pb = os.path.join(new, name), os.path.join(old, name)
+        if not (os.path.exists(pa) and os.path.exists(pb)):
+            print(f"DIFF {name}: only in {new if os.path.exists(pa) else old}")
+            bad += 1
+            continue
+        a, b = np.load(pa, allow_pickle=True), np.load(pb, allow_pickle=True)
+        for k in sorted(set(a.files) | set(b.files)):
+            if k not in a.files or k not in b.files:
+                print(f"DIFF {name}[{k}]: only in {'new' if k in a.files else 'old'}")
+                bad += 1
+            elif a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or not np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"):
+                print(f"DIFF {name}[{k}]")
+                bad += 1
+    print(f"compared {len(names)} fixtures: {bad} difference(s)")
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
