@@ -717,3 +717,51 @@ def test_checkpoint_resume_is_bit_exact(sg):
         other.import_state(blob)
     for e in (a, b, other):
         e.close()
+
+
+def test_integration_md_binding_stub_runs_as_written(sg):
+    """INTEGRATION.md section 2 shows the ctypes binding a reference maintainer would add.  That code block is
+    executed here as it stands (only the library's file name is made absolute): the three operators against the
+    reference's operator fixture -- the energy of the reference's output spins, a sequential fp32 sweep equal to
+    the oracle's under the same Philox uniforms (seed 0, as the stub passes), and the exchange operator equal to
+    this package's HIPKernelManager with the same seed."""
+    import re
+    from conftest import ROOT
+    import os
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("## 2. Reference-side binding"):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    assert 'C.CDLL("libsga.so")' in code and "class CUDAKernelManager" in code
+    code = code.replace('C.CDLL("libsga.so")', f'C.CDLL({sg._native.library_path()!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    g = load_golden("operator_n48")
+    n, nu = 48, int(g["n_updates"])
+    dev = torch.device("cuda", 0)
+    mgr = ns["CUDAKernelManager"](dev)
+    J, h = torch.from_numpy(g["J"]).to(dev), torch.from_numpy(g["h"]).to(dev)
+    # compute_energy_optimized: the energy the reference computed for its own output spins
+    s_out = torch.from_numpy(g["s_out"].astype(np.float32)).to(dev)
+    assert mgr.compute_energy_optimized(s_out, J, h) == float(g["energy"])
+    # metropolis_update_optimized: sequential sites, fp32 arithmetic, Philox uniforms of seed 0 / replica 0
+    prob = oracle.Problem(J=g["J"], h=g["h"])
+    s = g["s0"].copy()[None, :]
+    u = np.asarray([[oracle.stream_u(0, 0, k, t) for k in range(nu) for t in range(n)]], np.float32)
+    ref = oracle.sweeps(prob, s, float(g["T"]), nu, site_mode=oracle.SITE_SEQUENTIAL, arith=oracle.ARITH_F32,
+                        replay_u=u, trace=True)   # (the engine's uniforms when none are handed over: Philox, seed 0)
+    spins = torch.from_numpy(g["s0"].astype(np.float32)).to(dev)
+    out, accepted, changes = mgr.metropolis_update_optimized(spins, J, h, float(g["T"]), n_updates=nu)
+    assert out is spins and accepted == int(ref["accept_trace"].sum())
+    assert np.array_equal(spins.cpu().numpy().astype(np.int8), s[0])
+    assert np.array_equal(changes.cpu().numpy(), ref["dE_trace"][0].reshape(nu, n).sum(0).astype(np.float32))
+    # parallel_tempering_exchange_optimized: in place on fp32 tensors; the package's own manager, same seed
+    sp = torch.from_numpy(g["pt_spins_in"].astype(np.float32)).to(dev)
+    en = torch.from_numpy(g["pt_energies_in"].astype(np.float32)).to(dev)
+    tt = torch.from_numpy(g["pt_temps"]).to(dev)
+    k = mgr.parallel_tempering_exchange_optimized(sp, en, tt)
+    own = sg.CUDAKernelManager(dev, seed=0)
+    sp2 = torch.from_numpy(g["pt_spins_in"].astype(np.float32)).to(dev)
+    en2 = torch.from_numpy(g["pt_energies_in"].astype(np.float32)).to(dev)
+    k2 = own.parallel_tempering_exchange_optimized(sp2, en2, tt)
+    assert k == k2 and torch.equal(sp, sp2) and torch.equal(en, en2)
+    assert sorted(en.tolist()) == sorted(g["pt_energies_in"].tolist())
