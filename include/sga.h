@@ -324,9 +324,13 @@ int sga_set_field_cache(sga_engine *e, int mode);
  * [sweep] at the next sga_sweep / sga_recompute_energies.
  *   "look_ahead"            0 | 1 (default)   dense integer problems: several updates reduced together  [sweep; SGA_NO_LOOK_AHEAD]
  *   "force_general"         0 (default) | 1   general kernel builds even for production arguments       [sweep; SGA_FORCE_GENERAL]
- *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the cached-field sweep [sweep; SGA_CLF_WAVES]
- *   "clf_solo"              -1 = adaptive (default), 0 | 1: cached-field sweep, one wave evaluates the candidates
- *                           of a round (busy replicas) instead of every wave its own window            [sweep; SGA_CLF_SOLO]
+ *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the windowed cached-field
+ *                           sweep (a value selects that form)                                       [sweep; SGA_CLF_WAVES]
+ *   "clf_chain"             0 (default) | 1   cached-field sweep under production arguments in the chain-wave form: one
+ *                           wave walks the chain over the few candidates that can accept within a window's flip
+ *                           budget, three waves keep the field array up to date (csrc/sweep_clfc_impl.h).  Same
+ *                           chain; measured no faster than the windowed form, hence opt-in            [sweep; SGA_CLF_CHAIN]
+ *   "clf_flips"             12 (default), 1 ... 64: accepted proposals per window of that form      [sweep; SGA_CLF_FLIPS]
  *   "replica_routing"       0 | 1 (default)   SGA_FIELD_CACHE_AUTO routes each replica by its own acceptance (two
  *                           concurrent launches) instead of the whole launch by the hottest replica    [sweep; SGA_NO_REPLICA_ROUTING]
  *   "batched_energy"        0 = one pass over the couplings per replica, 1 (default) = all replicas in one pass where

@@ -30,7 +30,7 @@ int fail(int code, const std::string &msg) {
 enum Opt {
     OPT_LOOK_AHEAD, OPT_CLF_WAVES, OPT_SPARSE_ROUTE, OPT_BATCHED_ENERGY, OPT_FORCE_GENERAL, OPT_CSR_UPDATES_PER_STEP,
     OPT_TSP_PARALLEL, OPT_FORCE_CSR_BITS, OPT_CSR_BITS, OPT_CSR_SLOTS, OPT_HALF_TABLE, OPT_FORCE_CSR_ACC,
-    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_SOLO, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_COUNT
+    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_CHAIN, OPT_CLF_FLIPS, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_COUNT
 };
 struct OptDef {
     const char *key;
@@ -54,7 +54,8 @@ constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"force_csr_acc", "SGA_FORCE_CSR_ACC", 0, 0, 0, 0, 3},
     {"force_dense_canonical", "SGA_FORCE_DENSE_CANON", 1, 1, 0, 0, 1},
     {"zero_slot_every", "SGA_ZERO_SLOT_EVERY", 0, 0, 0, 0, 1ll << 21},
-    {"clf_solo", "SGA_CLF_SOLO", 0, 0, -1, -1, 1},
+    {"clf_chain", "SGA_CLF_CHAIN", 1, 1, 0, 0, 1},
+    {"clf_flips", "SGA_CLF_FLIPS", 0, 0, 12, 1, 64},
     {"replica_routing", "SGA_NO_REPLICA_ROUTING", 1, 0, 1, 0, 1},
     {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536},
 };
@@ -213,6 +214,7 @@ struct sga_engine {
     bool from_dense = false;  // CSR problem built from a sparse matrix handed over dense (sga_set_dense, SGA_J_AUTO)
     bool clf_problem = false;  // dense, one model, J and h integer valued, symmetric, zero diagonal, sums < 2^24
     float row_abs_max = 0.0f;  // max_i(sum_j |J_ij| + |h_i|)
+    int j_abs_max = 0;         // ceil(max |J_ij|): the most one flip moves another site's field (chain-wave form)
     int clf_scale = 1, clf_bits = 16;
     void *fields = nullptr;    // [R][ldf] int16 | int32: clf_scale * (J s + h), valid while fields_valid
     long long ldf = 0;
@@ -991,8 +993,8 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // symmetric with a zero diagonal (dE of the rule == energy change)?
     int *flags = e->d_flags;  // [0..3] value scans, [4] symmetry / diagonal
     unsigned int *uflags = reinterpret_cast<unsigned int *>(flags) + 2;
-    int hflags[7] = {1, 1, 0, 1, 1, 0, 0};
-    HIPCHK(hipMemsetAsync(flags, 0, 7 * sizeof(int), e->stream));
+    int hflags[8] = {1, 1, 0, 1, 1, 0, 0, 0};  // ([7]: max |J_ij| as float bits, launch_dense_row_abs_max)
+    HIPCHK(hipMemsetAsync(flags, 0, 8 * sizeof(int), e->stream));
     HIPCHK(sga::launch_scan_values(src, rows, n, ld_src, flags, e->stream));
     HIPCHK(sga::launch_dense_row_abs_max(src, ld_src, e->h, rows, n, uflags, e->stream));
     HIPCHK(sga::launch_check_symmetric(src, ld_src, rows, n, flags + 4, e->stream));
@@ -1030,6 +1032,11 @@ int sga_set_dense_batch(sga_engine *e, const float *J, int64_t ldJ, const float 
     // cached-local-field sweep: exact integer fields, dE of the rule == energy change, one model
     // (h a multiple of 1/2 -- the penalty encodings of 0/1 variables -- keeps 2 F an integer: scale 2)
     e->row_abs_max = m;
+    {
+        float jm;
+        std::memcpy(&jm, &hflags[7], sizeof(float));
+        e->j_abs_max = (int)std::min(std::ceil((double)jm), 16777216.0);
+    }
     e->clf_scale = (nonint & 2u) ? 2 : 1;
     e->clf_problem = (nonint & 5u) == 0u && (double)m * e->clf_scale < 16777216.0 && e->consistent_dE && n_models == 1;
     e->clf_bits = (double)m * e->clf_scale < 32768.0 ? 16 : 32;
@@ -1980,10 +1987,19 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             ac.ldf = e->ldf;
             ac.field_bits = e->clf_bits;
             ac.field_scale = e->clf_scale;
-            ac.clf_solo = (int)e->opt[OPT_CLF_SOLO];
+            ac.clf_chain = (int)e->opt[OPT_CLF_CHAIN];
+            ac.clf_flips = (int)e->opt[OPT_CLF_FLIPS];
+            ac.clf_jmax = e->j_abs_max;
             const int cw = sga::sweep_clf_waves(e->ldj, e->want_i8, mixed ? n_clf : e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]);
+            // option "clf_chain": production arguments take the chain-wave form (one wave walks the chain, three keep
+            // the fields up to date: sweep_clfc_impl.h) -- the same chain; measured no faster than the windowed form
+            // (profiles/r04_experiments.md 3), hence opt-in
+            const bool chain = e->opt[OPT_CLF_WAVES] == 0 && sga::sweep_clfc_applies(ac);
+            auto launch_cached = [&](const sga::SweepArgs &aa, hipStream_t s2) -> hipError_t {
+                return chain ? sga::launch_sweep_clfc(aa, e->want_i8, s2) : sga::launch_sweep_clf(aa, e->want_i8, cw, s2);
+            };
             if (!mixed) {
-                le = sga::launch_sweep_clf(ac, e->want_i8, cw, st);
+                le = launch_cached(ac, st);
             } else {
                 // two launches over disjoint replica lists, side by side: the cached-field kernel on the engine's
                 // stream, the row-per-proposal kernel on the second one, forked and joined by events
@@ -1993,7 +2009,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                 a.rep_count = R - n_clf;
                 le = hipEventRecord(e->fork_ev, st);
                 if (le == hipSuccess) le = hipStreamWaitEvent(e->aux_stream, e->fork_ev, 0);
-                if (le == hipSuccess) le = sga::launch_sweep_clf(ac, e->want_i8, cw, st);
+                if (le == hipSuccess) le = launch_cached(ac, st);
                 char first[200];
                 std::snprintf(first, sizeof(first), "%s", sga::last_sweep_kernel());
                 if (le == hipSuccess) le = launch_dense_rows(a, e->aux_stream);

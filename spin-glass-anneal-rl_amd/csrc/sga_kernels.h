@@ -85,7 +85,9 @@ struct SweepArgs {
     long long ldf;
     int field_bits;      // 16 | 32
     int field_scale;     // 1 | 2 (J integer, h a multiple of 1/2)
-    int clf_solo;        // (engine option "clf_solo": reserved for the one-evaluator form of the round)
+    int clf_chain;       // 1: the chain-wave form (sweep_clfc_impl.h) where the arguments are the production ones
+    int clf_flips;       // chain-wave form: accepted proposals per window (the candidate filter's flip budget K)
+    int clf_jmax;        // max |J_ij| (integer): the most one flip moves another site's field, in units of 2 scale
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -146,6 +148,9 @@ hipError_t launch_fields_dense(const FieldsArgs &a, int mode, hipStream_t st);
 hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t st);
 // cached-local-field sweep: dense integer-valued symmetric problems
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
+hipError_t launch_sweep_clfc(const SweepArgs &a, bool j_is_i8, hipStream_t st);  // chain-wave form, production arguments
+bool sweep_clfc_applies(const SweepArgs &a);
+size_t sweep_clfc_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus, int forced);
 

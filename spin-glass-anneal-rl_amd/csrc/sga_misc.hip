@@ -90,11 +90,16 @@ __global__ void __launch_bounds__(256) dense_row_abs_max_kernel(const float *__r
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double acc = 0.0;
     int nonint = 0;
+    float big = 0.0f;
     for (int j = tid; j < n; j += 256) {
         const float x = J[(long long)i * ldJ + j];
         acc += (double)__builtin_fabsf(x);
         nonint |= (x != __builtin_rintf(x));
+        big = __builtin_fmaxf(big, __builtin_fabsf(x));
     }
+    // out[5]: max |J_ij| over the matrix (non-negative floats: bit order = value order; one atomic per wave)
+    for (int sft = 32; sft >= 1; sft >>= 1) big = __builtin_fmaxf(big, __shfl_xor(big, sft));
+    if (lane == 0 && big > 0.0f) atomicMax(&out[5], __builtin_bit_cast(unsigned int, big));
     const double ws = wave_sum(acc);
     const int wb = wave_sum(nonint);
     if (lane == 0) {

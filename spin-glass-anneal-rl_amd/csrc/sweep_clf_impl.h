@@ -86,6 +86,64 @@ __device__ __forceinline__ int add_pair(int pair, int d_lo, int d_hi) {
     return (int)(((p + (unsigned int)d_lo) & 0xFFFFu) | ((p + ((unsigned int)d_hi << 16)) & 0xFFFF0000u));
 }
 
+// F_j -= 2 scale J_ij s_i for the EPL = 16 / sizeof(JT) couplings x = J[i][j0 .. j0 + EPL) of one lane.  NEG = the
+// amount is subtracted (mult < 0): a compile-time constant, the caller branches once per accept on the wave-uniform
+// sign (left to the compiler the select costs two more VALU per int16 pair).  mult = -2 scale s_i(old).
+template <typename JT, typename FT, bool NEG, typename VEC>
+__device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j0, int mult, int sc) {
+    constexpr int FB = (int)sizeof(FT);
+    if constexpr (sizeof(JT) == 4) {
+        const int d0 = mult * (int)x.x, d1 = mult * (int)x.y, d2 = mult * (int)x.z, d3 = mult * (int)x.w;
+        if constexpr (FB == 2) {
+            int2 f = *reinterpret_cast<int2 *>(F + j0);
+            f.x = add_pair(f.x, d0, d1);
+            f.y = add_pair(f.y, d2, d3);
+            *reinterpret_cast<int2 *>(F + j0) = f;
+        } else {
+            int4 f = *reinterpret_cast<int4 *>(F + j0);
+            f.x += d0, f.y += d1, f.z += d2, f.w += d3;
+            *reinterpret_cast<int4 *>(F + j0) = f;
+        }
+    } else {
+        const int wds[4] = {x.x, x.y, x.z, x.w};
+        if constexpr (FB == 2) {
+            // Four couplings per dword -> two dwords of int16 pairs, in packed 16-bit arithmetic:
+            // v_perm_b32 puts a coupling into the HIGH byte of each half (b << 8), one packed
+            // arithmetic shift right by 8 - log2 |mult| makes it |mult| * b, one packed add or subtract
+            // applies it: 3 instructions per pair.  |mult| = 2 scale is 2 or 4.
+            typedef short short2v __attribute__((ext_vector_type(2)));
+            int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
+            int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
+            const short sh = (short)(sc == 1 ? 7 : 6);
+            const short2v shv = {sh, sh};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned int t01 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x050c040cu);
+                const unsigned int t23 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x070c060cu);
+                const short2v v01 = __builtin_bit_cast(short2v, t01) >> shv;
+                const short2v v23 = __builtin_bit_cast(short2v, t23) >> shv;
+                short2v lo = __builtin_bit_cast(short2v, *fp[2 * d]), hi = __builtin_bit_cast(short2v, *fp[2 * d + 1]);
+                if constexpr (NEG) lo -= v01, hi -= v23;
+                else lo += v01, hi += v23;
+                *fp[2 * d] = __builtin_bit_cast(int, lo);
+                *fp[2 * d + 1] = __builtin_bit_cast(int, hi);
+            }
+            *reinterpret_cast<int4 *>(F + j0) = f0;
+            *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
+                f.x += mult * (int)(int8_t)(wds[d]);
+                f.y += mult * (int)(int8_t)(wds[d] >> 8);
+                f.z += mult * (int)(int8_t)(wds[d] >> 16);
+                f.w += mult * (wds[d] >> 24);
+                *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
+            }
+        }
+    }
+}
+
 // LDS of one replica: fields [ldf] FT | spin bits [sstride / 8 bytes] | accept table [table_m + 1] floats
 __host__ __device__ constexpr long long clf_bits_offset(long long ldf, int fbytes) {
     return (ldf * fbytes + 15) & ~15ll;
@@ -164,61 +222,8 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
         }
         return o;
     };
-    // F_j -= 2 scale J_ij s_i for the EPL couplings x = J[i][j0 .. j0 + EPL).  NEG = the amount is
-    // subtracted (mult < 0): a compile-time constant here, the caller branches once per accept on the
-    // wave-uniform sign (left to the compiler the select costs two more VALU per int16 pair).
     auto apply_chunk = [&](const vec_t &x, long long j0, int mult /* -2 scale s_i(old) */, auto neg) {
-        constexpr bool NEG = decltype(neg)::value;
-        if constexpr (sizeof(JT) == 4) {
-            const int d0 = mult * (int)x.x, d1 = mult * (int)x.y, d2 = mult * (int)x.z, d3 = mult * (int)x.w;
-            if constexpr (FB == 2) {
-                int2 f = *reinterpret_cast<int2 *>(F + j0);
-                f.x = add_pair(f.x, d0, d1);
-                f.y = add_pair(f.y, d2, d3);
-                *reinterpret_cast<int2 *>(F + j0) = f;
-            } else {
-                int4 f = *reinterpret_cast<int4 *>(F + j0);
-                f.x += d0, f.y += d1, f.z += d2, f.w += d3;
-                *reinterpret_cast<int4 *>(F + j0) = f;
-            }
-        } else {
-            const int wds[4] = {x.x, x.y, x.z, x.w};
-            if constexpr (FB == 2) {
-                // Four couplings per dword -> two dwords of int16 pairs, in packed 16-bit arithmetic:
-                // v_perm_b32 puts a coupling into the HIGH byte of each half (b << 8), one packed
-                // arithmetic shift right by 8 - log2 |mult| makes it |mult| * b, one packed add or subtract
-                // applies it: 3 instructions per pair.  |mult| = 2 scale is 2 or 4.
-                typedef short short2v __attribute__((ext_vector_type(2)));
-                int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
-                int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
-                const short sh = (short)(sc == 1 ? 7 : 6);
-                const short2v shv = {sh, sh};
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned int t01 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x050c040cu);
-                    const unsigned int t23 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x070c060cu);
-                    const short2v v01 = __builtin_bit_cast(short2v, t01) >> shv;
-                    const short2v v23 = __builtin_bit_cast(short2v, t23) >> shv;
-                    short2v lo = __builtin_bit_cast(short2v, *fp[2 * d]), hi = __builtin_bit_cast(short2v, *fp[2 * d + 1]);
-                    if constexpr (NEG) lo -= v01, hi -= v23;
-                    else lo += v01, hi += v23;
-                    *fp[2 * d] = __builtin_bit_cast(int, lo);
-                    *fp[2 * d + 1] = __builtin_bit_cast(int, hi);
-                }
-                *reinterpret_cast<int4 *>(F + j0) = f0;
-                *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
-            } else {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
-                    f.x += mult * (int)(int8_t)(wds[d]);
-                    f.y += mult * (int)(int8_t)(wds[d] >> 8);
-                    f.z += mult * (int)(int8_t)(wds[d] >> 16);
-                    f.w += mult * (wds[d] >> 24);
-                    *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
-                }
-            }
-        }
+        clf_apply_chunk<JT, FT, decltype(neg)::value>(F, x, j0, mult, sc);
     };
     auto apply_row_signed = [&](const RowRegs &rr, int site, int mult, auto neg) {
 #pragma unroll

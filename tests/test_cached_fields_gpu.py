@@ -73,15 +73,19 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
     seed = 0xC1F0000 + n
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
-    with sg.AnnealEngine(0) as e:
-        e.set_options(opts)
-        e.set_field_cache("on")
-        e.set_dense(J, h, storage=storage)
-        e.init_replicas(R, seed=seed)
-        assert "sweep=cached-local-fields" in e.describe(), e.describe()
-        e.set_temperatures(temps)
-        out = e.sweep(ns, energy_trace=True)
-        check_against(e, ref, s, out)
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    forms = [opts] if waves else [opts, {"clf_chain": 1}]   # (the opt-in chain-wave form on the same cases)
+    for form in forms:
+        with sg.AnnealEngine(0) as e:
+            e.set_options(form)
+            e.set_field_cache("on")
+            e.set_dense(J, h, storage=storage)
+            e.init_replicas(R, seed=seed)
+            assert "sweep=cached-local-fields" in e.describe(), e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            assert last_kernel().startswith("sweep_clfc_kernel" if form.get("clf_chain") else "sweep_clf_kernel")
+            check_against(e, ref, s, out)
 
 
 @pytest.mark.parametrize("amp,n,bits", [(3, 500, 16), (100, 1000, 32), (127, 2000, 32)])
@@ -142,6 +146,34 @@ def oracle_spins_after(prob, R, n, seed, temps, ns):
     s = oracle.init_spins(n, R, seed)
     oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=R)
     return s
+
+
+@pytest.mark.parametrize("n,R,amp,hot", [(97, 6, 1, 3.0), (700, 9, 1, 0.6), (2100, 5, 3, 2.0), (5000, 4, 1, 0.3)])
+def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(sg, n, R, amp, hot):
+    """Option clf_chain = 1: production arguments take the chain-wave form (csrc/sweep_clfc_impl.h): candidates that
+    cannot accept within the window's flip budget K are dropped, the rest followed in registers by one wave.  Every
+    budget -- 1 (a window ends at each accept), the default, 64 (the filter lets nearly everything through) -- and
+    the windowed form (the default) give the oracle's chain; small n: every site is proposed several times per window."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    J = int_couplings(n, 7 * n, amp, density=0.8) if amp > 1 else pm1(n, 3 * n)
+    h = np.random.RandomState(n).randint(-amp, amp + 1, n).astype(np.float32)
+    prob = oracle.Problem(J=J, h=h)
+    ns, seed = 6, 0xC4A1 + n
+    temps = ladder(R, hot * amp * np.sqrt(n), 0.02 * amp * np.sqrt(n))
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    assert ref["n_accepted"].max() > n // 2         # a hot end: several accepts per window there
+    for opts in ({"clf_chain": 1, "clf_flips": 1}, {"clf_chain": 1}, {"clf_chain": 1, "clf_flips": 64}, {}):
+        with sg.AnnealEngine(0) as e:
+            e.set_options(opts)
+            e.set_field_cache("on")
+            e.set_dense(J, h)
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            k = last_kernel()
+            assert k.startswith("sweep_clfc_kernel" if opts.get("clf_chain") else "sweep_clf_kernel"), k
+            check_against(e, ref, s, out)
 
 
 # ----------------------------------------------------------------------------- golden replay
