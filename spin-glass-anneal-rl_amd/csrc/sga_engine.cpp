@@ -215,6 +215,11 @@ struct sga_engine {
     bool clf_problem = false;  // dense, one model, J and h integer valued, symmetric, zero diagonal, sums < 2^24
     float row_abs_max = 0.0f;  // max_i(sum_j |J_ij| + |h_i|)
     int j_abs_max = 0;         // ceil(max |J_ij|): the most one flip moves another site's field (chain-wave form)
+    // ... of CSR problems (sweep_clf_csr.hip): integer J, rows strictly sorted, max_i sum_j |J_ij| < 2^15, the accept
+    // table applies, dE of the rule == energy change; the fields are then D = J s as int16, h stays outside
+    bool clf_csr_problem = false;
+    float row_j_abs_max = 0.0f;  // max_i sum_j |J_ij|
+    int *hq = nullptr;           // [n] table_scale * h_i as integers (built with the first cached sweep)
     int clf_scale = 1, clf_bits = 16;
     void *fields = nullptr;    // [R][ldf] int16 | int32: clf_scale * (J s + h), valid while fields_valid
     long long ldf = 0;
@@ -288,6 +293,8 @@ struct sga_engine {
         dev_free(diag);
         dev_free(nd4);
         dev_free(nd4t);
+        dev_free(hq);
+        clf_csr_problem = false;
         tsp = false;
         dev_free(epart);
         epart_bytes = 0;
@@ -442,11 +449,21 @@ int fields_pass(sga_engine *e, int r0, int count, double *energy, void *fields) 
 // fields and spin bits fit LDS, any single-site rule.  why: the reason when it does not.
 bool clf_possible(const sga_engine *e, const char **why) {
     const char *reason = nullptr;
-    if (e->csr && e->from_dense)
-        // (the request may precede the NEXT sga_set_dense, so it is accepted; what cannot be served says why)
-        reason = "cached local fields: this sparse matrix was kept as CSR because the field cache was OFF when "
-                 "sga_set_dense ran, and its dense source is released -- call sga_set_field_cache before sga_set_dense";
-    else if (e->csr || e->tsp) reason = "cached local fields: dense couplings only";
+    if (e->csr && !e->tsp) {
+        // sparse couplings: the dynamic part of the fields as int16 in LDS (sweep_clf_csr.hip)
+        const long long ldf = ((long long)e->n + 127) / 128 * 128;
+        if (!e->clf_csr_problem)
+            reason = e->from_dense
+                         ? "cached local fields: this sparse matrix was kept as CSR because the field cache was OFF when "
+                           "sga_set_dense ran (its dense source is released), and as CSR it does not qualify (integer J in "
+                           "strictly sorted rows, sum_j |J_ij| < 2^15, h in multiples of 1/2) -- call sga_set_field_cache "
+                           "before sga_set_dense"
+                         : "cached local fields over CSR couplings need integer-valued symmetric J in strictly sorted rows "
+                           "(no duplicates), zero diagonal, max_i sum_j |J_ij| < 2^15 and h in multiples of 1/2";
+        else if (e->R > 0 && (sga::sweep_clf_csr_lds_bytes(ldf, e->sstride, e->table_m) > 160 * 1024 ||
+                              (e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len) > 4 * 64 * 8))
+            reason = "cached local fields: fields and spins of a replica do not fit LDS (or a row is longer than 2048 entries)";
+    } else if (e->tsp) reason = "cached local fields: stored couplings only";
     else if (!e->clf_problem)
         reason = "cached local fields need one model with integer-valued symmetric J, zero diagonal, h in "
                  "multiples of 1/2 and row sums below 2^24";
@@ -462,6 +479,22 @@ bool clf_active(const sga_engine *e) {
 // resident fields of every replica, from the all-replica pass (the tracked energies are left alone)
 int ensure_fields(sga_engine *e) {
     if (e->fields_valid && e->fields) return SGA_OK;
+    if (e->csr) {  // D = J s of every replica (int16), eight replicas per pass over the entries; scale * h once
+        e->ldf = ((long long)e->n + 127) / 128 * 128;
+        if (!e->fields && hipMalloc(&e->fields, (size_t)e->R * (size_t)e->ldf * 2) != hipSuccess) {
+            (void)hipGetLastError();
+            e->fields = nullptr;
+            return fail(SGA_ERR_MEMORY, "no memory for the resident local fields of the cached-field sweep");
+        }
+        if (!e->hq) {
+            HIPCHK(hipMalloc(&e->hq, sizeof(int) * (size_t)e->n));
+            HIPCHK(sga::launch_scaled_fields(e->h, e->n, e->table_scale, e->hq, e->stream));
+        }
+        HIPCHK(sga::launch_csr_fields_seed(e->rowptr64, e->cv, e->spins, e->sstride, e->n, e->R,
+                                           static_cast<short *>(e->fields), e->ldf, e->stream));
+        e->fields_valid = true;
+        return SGA_OK;
+    }
     e->ldf = (e->ldj + 127) / 128 * 128;
     if (!e->fields && hipMalloc(&e->fields, (size_t)e->R * (size_t)e->ldf * (size_t)(e->clf_bits / 8)) != hipSuccess) {
         (void)hipGetLastError();
@@ -1315,6 +1348,14 @@ static int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, 
         e->table_m = (int)std::min(2.0f * m, 2048.0f);
         e->table_scale = 2;
     }
+    {
+        float mj;
+        std::memcpy(&mj, &flags[sga::CSR_ROW_J_ABS_MAX], sizeof(mj));
+        e->row_j_abs_max = mj;
+        // cached-field sweep over CSR: exact int16 dynamic fields, table arithmetic, every entry its own column
+        e->clf_csr_problem = (flags[sga::CSR_NOT_INTEGRAL] & 5) == 0 && e->table_m > 0 && e->consistent_dE && sorted &&
+                             mj < 32768.0f && n <= (1 << 30);
+    }
     HIPCHK(sga::launch_gather_diag_csr(e->rowptr64, ci, vv, n, e->diag, e->stream));
     std::vector<long long> src(np1);
     HIPCHK(hipMemcpyAsync(src.data(), e->rowptr64, sizeof(long long) * np1, hipMemcpyDeviceToHost, e->stream));
@@ -1814,11 +1855,12 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                     // on its CU ... 1.7 with busy neighbours), and per update 0.38 us on bit-planes / 0.58 us on int8
                     // rows at n = 10^4, ~0.3 us on short rows (profiles/r04_routing.py; fp32 rows: estimate).
                     const double kn = (double)n / 1000.0;
-                    const double t_upd = e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
+                    const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
+                                         : e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
                     const double theta = t_upd / 1.5;
                     const double enter = 0.8 * theta, leave = 1.2 * theta;
                     bool back = false;
-                    if (e->opt[OPT_REPLICA_ROUTING] != 0) {
+                    if (e->opt[OPT_REPLICA_ROUTING] != 0 && !e->csr) {  // (the CSR row kernels take no replica lists)
                         for (int r2 = 0; r2 < e->R; ++r2) {
                             const double acc = (double)(now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]) / (double)since;
                             int &rt = e->route[(size_t)r2];
@@ -1979,7 +2021,27 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                                            e->cpw > sga::MAX_CPW ? 0 : e->cpw, s2);
         };
         hipError_t le;
-        if (clf) {
+        bool clf_now = clf;
+        if (clf && e->csr) {
+            // sparse couplings: D = J s as int16 in LDS, the row's entries read on accept (sweep_clf_csr.hip);
+            // production arguments only -- traced / replayed / sequential sweeps take the row-per-proposal kernels
+            // (the same chain) and the fields are seeded anew afterwards
+            sga::SweepArgs ac = a;
+            ac.fields = e->fields;
+            ac.ldf = e->ldf;
+            ac.clf_hq = e->hq;
+            ac.clf_row_max = (int)std::min<long long>(e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len, 1 << 20);
+            const int cw = ac.clf_row_max > 256 || e->n > 20000 ? 8 : 4;
+            if (sga::sweep_clf_csr_applies(ac, cw)) {
+                le = sga::launch_sweep_clf_csr(ac, cw, st);
+            } else {
+                clf_now = false;
+                e->fields_valid = false;
+            }
+        }
+        if (clf_now && e->csr) {
+            // (launched above)
+        } else if (clf_now) {
             sga::SweepArgs ac = a;
             if (e->clf_scale == 2)  // half-integer fields: dE = q for q <= 2 M, tabulated at twice the resolution
                 ac.table_m = (int)std::min(2.0 * (double)e->row_abs_max, 2048.0);
@@ -2709,7 +2771,15 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     if (e->csr && e->big_form == 1 && e->cvp && e->csr_storage_latched != SGA_CSR_STORAGE_F32)
         std::strncat(tmp, " entries=packed-32bit", sizeof(tmp) - std::strlen(tmp) - 1);
     if (!e->consistent_dE) std::strncat(tmp, " energy=recomputed-per-sweep", sizeof(tmp) - std::strlen(tmp) - 1);
-    if (clf_active(e)) {
+    if (clf_active(e) && e->csr) {
+        if (e->field_cache == SGA_FIELD_CACHE_ON)
+            std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                          " sweep=cached-local-fields(int16 dynamic fields in LDS, row entries read on accept only)");
+        else
+            std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
+                          " sweep=auto(cached local fields while the hottest replica accepts little; now: %s)",
+                          (!e->auto_unavailable && e->n_route_clf > 0) ? "cached" : "one row per proposal");
+    } else if (clf_active(e)) {
         if (e->field_cache == SGA_FIELD_CACHE_ON)
             std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                           " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",

@@ -88,6 +88,9 @@ struct SweepArgs {
     int clf_chain;       // 1: the chain-wave form (sweep_clfc_impl.h) where the arguments are the production ones
     int clf_flips;       // chain-wave form: accepted proposals per window (the candidate filter's flip budget K)
     int clf_jmax;        // max |J_ij| (integer): the most one flip moves another site's field, in units of 2 scale
+    // cached-field sweep of CSR problems (sweep_clf_csr.hip): fields = D [R][ldf] int16, D_i = sum_j J_ij s_j
+    const int *clf_hq;   // [n] table_scale * h_i as integers (the static part of the local field)
+    int clf_row_max;     // entries of the longest row of the layout (slot padding included)
     uint32_t seed_lo, seed_hi, sweep0, replica0;
 };
 
@@ -150,6 +153,13 @@ hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t 
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
 hipError_t launch_sweep_clfc(const SweepArgs &a, bool j_is_i8, hipStream_t st);  // chain-wave form, production arguments
 bool sweep_clfc_applies(const SweepArgs &a);
+// ... and of CSR problems with integer couplings (rows sorted, |sum_j J_ij s_j| < 2^15)
+hipError_t launch_sweep_clf_csr(const SweepArgs &a, int waves, hipStream_t st);
+bool sweep_clf_csr_applies(const SweepArgs &a, int waves);
+size_t sweep_clf_csr_lds_bytes(long long ldf, int sstride, int table_m);
+hipError_t launch_csr_fields_seed(const long long *rowptr, const int2 *cv, const int8_t *spins, int sstride, int n, int R,
+                                  short *D, long long ldf, hipStream_t st);
+hipError_t launch_scaled_fields(const float *h, int n, int scale, int *hq, hipStream_t st);
 size_t sweep_clfc_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus, int forced);
@@ -246,7 +256,7 @@ hipError_t launch_narrow_rowptr(const long long *src, int32_t *dst, long long co
 //  [7] 1024 + highest binary exponent of a non-zero J   [8] 1024 - exponent of the lowest set bit
 //  ([2]: bit 0 = some J, bit 1 = some h not an integer)
 enum { CSR_BAD_ROWPTR = 0, CSR_BAD_COLUMN, CSR_NOT_INTEGRAL, CSR_UNSORTED, CSR_DIAGONAL,
-       CSR_ASYMMETRIC, CSR_ROW_ABS_MAX, CSR_EXP_HI, CSR_EXP_LO, CSR_FLAG_COUNT = 10 };
+       CSR_ASYMMETRIC, CSR_ROW_ABS_MAX, CSR_EXP_HI, CSR_EXP_LO, CSR_ROW_J_ABS_MAX, CSR_FLAG_COUNT = 10 };
 // how the CSR sweep kernels form a row sum
 enum { CSR_ACC_F32_TABLE = 0,   // integer J and h, few distinct uphill moves: fp32 (exact) + accept table
        CSR_ACC_F32 = 1,         // integer J with row sums below 2^24: fp32 accumulation is exact

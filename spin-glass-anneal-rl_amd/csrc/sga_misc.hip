@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
     const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
     int bad_col = 0, non_int = 0, unsorted = 0, diag = 0;
     int exp_hi = 0, exp_lo = 0;  // 1024 + highest exponent | 1024 - lowest set bit's exponent (0: no value yet)
-    float row_max = 0.0f;
+    float row_max = 0.0f, row_j_max = 0.0f;
     for (int i = wave; i < n; i += n_waves) {
         const long long beg = rowptr[i], end = rowptr[i + 1];
         double acc = 0.0;
@@ -416,8 +416,10 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
         if (hi != rintf(hi)) non_int |= 2;
         if (2.0f * hi != rintf(2.0f * hi)) non_int |= 4;
         // an upper bound is all the table needs; fp32 rounds it up or down by < 1 ulp
-        const float tot = (float)(wave_sum(acc) + (double)fabsf(hi));
+        const double jsum = wave_sum(acc);
+        const float tot = (float)(jsum + (double)fabsf(hi));
         row_max = fmaxf(row_max, tot);
+        row_j_max = fmaxf(row_j_max, (float)jsum);  // sum_j |J_ij| alone: the range of the dynamic part of a field
     }
     if (bad_col) flags[CSR_BAD_COLUMN] = 1;
     if (non_int) atomicOr(&flags[CSR_NOT_INTEGRAL], non_int);  // bit 0: some J, bit 1: some h, bit 2: some 2 h
@@ -426,6 +428,7 @@ __global__ void __launch_bounds__(256) csr_scan_kernel(const long long *rowptr, 
     if (unsorted) flags[CSR_UNSORTED] = 1;
     if (diag) flags[CSR_DIAGONAL] = 1;
     if (lane == 0) atomicMax(&flags[CSR_ROW_ABS_MAX], __float_as_int(row_max));  // >= 0: bits order
+    if (lane == 0) atomicMax(&flags[CSR_ROW_J_ABS_MAX], __float_as_int(row_j_max));
 }
 hipError_t launch_csr_scan(const long long *rowptr, const int32_t *colidx, const float *val,
                            const float *h, int n, int *flags, hipStream_t st) {
