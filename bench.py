@@ -371,6 +371,62 @@ def roofline_block(wl, name, R, avg_launch_s, launches, kernel_inst, copy_gbs=No
     return r
 
 
+def cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev, exchange_interval, warm=20, steps=10):
+    """The cached-local-field sweep over CSR couplings (sga_set_field_cache ON, csrc/sweep_clf_csr.hip) on the workload
+    the engine holds: the same chain bit for bit, a row's entries read only when a proposal is ACCEPTED.  A variant with
+    its own byte model -- B = acceptance rate x (deg x 8 + 8) bytes per attempt (last sentence) --
+    reported beside the graded one-row-per-proposal figure, never instead of it."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    from spin_glass_anneal_rl_amd.sharded import ShardedTempering
+    n, csr = wl["n"], wl["csr"]
+    eng.set_field_cache("on")
+    eng.set_tuning(waves_per_replica=0, sweeps_per_launch=0)
+    pt = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=n_ladders, dist=None,
+                          device=comm_dev)
+    done = 0
+
+    def run(k):  # sweeps between two exchange rounds go into one launch, as the tempering classes drive the engine
+        nonlocal done
+        while k > 0:
+            chunk = min(k, exchange_interval - done % exchange_interval) if exchange_interval > 0 else k
+            pt.sweep(chunk)
+            done += chunk
+            k -= chunk
+            if exchange_interval > 0 and done % exchange_interval == 0:
+                pt.exchange(count=False)
+
+    try:
+        run(warm)
+    except Exception as exc:  # noqa: BLE001 - the problem does not qualify: the line says so
+        eng.set_field_cache("off")
+        return {"available": False, "reason": str(exc)}
+    torch.cuda.synchronize()
+    acc0 = int(eng.stats()[0].sum())
+    eng.enable_timing(True)
+    eng.kernel_time(reset=True)
+    t1 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    launches, ms = eng.kernel_time(reset=True)
+    eng.enable_timing(False)
+    rate = (int(eng.stats()[0].sum()) - acc0) / (float(R) * n * steps)
+    row_bytes = float(len(csr[1])) / n * 8.0 + 8.0
+    val = float(R) * n * steps / dt
+    out = {"available": True, "value": val, "unit": "attempts/s", "ms_per_step": dt / steps * 1e3,
+           "kernel_ms_per_step": ms / steps, "sweeps": f"{warm}..{warm + steps}", "sweeps_per_launch": exchange_interval,
+           "acceptance_rate": rate, "algorithmic_bytes_per_attempt": rate * row_bytes,
+           "achieved_GBs": val * rate * row_bytes / 1e9, "kernel_instantiation": last_kernel(), "geometry": eng.describe(),
+           "roofline": {"bound": "latency (one serial chain per replica: evaluation rounds + one row fetch per accept)",
+                        "byte_model": "B = acceptance rate x (deg x 8 + 8) bytes per attempt", "row_bytes": row_bytes,
+                        "achieved": val * rate * row_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": val * rate * row_bytes / 1e9 / HBM_PEAK_GBS},
+           "note": "bit-identical chain to the graded kernel (same Philox sites and uniforms, same accept rule; "
+                   "tests/test_cached_fields_gpu.py): the dynamic part of the local fields (J s) resident in LDS as int16"}
+    eng.set_field_cache("off")
+    return out
+
+
 def config_line(name, a, dev, local_rank, comm_dev, warmup=5, steps=10):
     """A short line of another BASELINE config, run after the headline in the default invocation: the same engine
     calls as `--workload <name>` (5 warm-up + 10 timed sweeps, exchange every 10), with a small CPU-oracle sample
@@ -422,6 +478,9 @@ def config_line(name, a, dev, local_rank, comm_dev, warmup=5, steps=10):
     if not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(None, n, 42, csr=wl["csr"], h=wl["h"].cpu().numpy(), eng=eng,
                                             t_range=(wl["t_hot"], wl["t_cold"]), budget_replicas_per_core=2, scale=0.25)
+    if name == "c4" and not a.no_variants:
+        line["variants"] = {"cached_local_fields": cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev,
+                                                                      a.exchange_interval)}
     eng.close()
     line["wall_s_with_setup"] = time.perf_counter() - t_setup
     return line
@@ -745,7 +804,10 @@ def main():
     # bytes per attempt (last sentence) -- reported beside the graded one-row-per-proposal
     # figure, never instead of it.  Storage = what the engine picks by itself for these couplings.
     if a.workload == "c2a" and world == 1 and not a.no_variants:
-        eng.set_tuning(waves_per_replica=0, sweeps_per_launch=1)
+        # (sweeps between two exchange rounds go into ONE launch, as ParallelTempering.run / SpinGlassScheduler.anneal
+        #  drive the engine: a launch of this variant lasts as long as its hottest replica's chain, and ten sweeps
+        #  average that chain's fluctuations; `one_sweep_per_launch` is the figure of rounds 3's line)
+        eng.set_tuning(waves_per_replica=0, sweeps_per_launch=0)
         eng.set_dense(J, h, storage="auto")
         eng.set_field_cache("on")
         pt3 = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=1,
@@ -753,21 +815,24 @@ def main():
         row_bytes = float(n if "storage=f32" not in eng.describe() else 4 * n)
         done = 0
 
-        def clf_steps(k):
+        def clf_steps(k, per_launch=None):
             nonlocal done
-            for _ in range(k):
-                pt3.sweep(1)
-                done += 1
+            while k > 0:
+                chunk = min(k, a.exchange_interval - done % a.exchange_interval) if a.exchange_interval > 0 else k
+                chunk = min(chunk, per_launch or chunk)
+                pt3.sweep(chunk)
+                done += chunk
+                k -= chunk
                 if a.exchange_interval > 0 and done % a.exchange_interval == 0:
                     pt3.exchange(count=False)
 
-        def clf_timed(k):
+        def clf_timed(k, per_launch=None):
             torch.cuda.synchronize()
             acc0 = int(eng.stats()[0].sum())
             eng.enable_timing(True)
             eng.kernel_time(reset=True)
             t1 = time.perf_counter()
-            clf_steps(k)
+            clf_steps(k, per_launch)
             torch.cuda.synchronize()
             dtv = time.perf_counter() - t1
             lv, msv = eng.kernel_time(reset=True)
@@ -775,7 +840,7 @@ def main():
             rate = (int(eng.stats()[0].sum()) - acc0) / (float(R) * n * k)
             val = float(R) * n * k / dtv
             return {"value": val, "unit": "attempts/s", "ms_per_step": dtv / k * 1e3,
-                    "kernel_ms_per_step": msv / max(lv, 1), "acceptance_rate": rate,
+                    "kernel_ms_per_step": msv / k, "launches": lv, "acceptance_rate": rate,
                     "algorithmic_bytes_per_attempt": rate * row_bytes,
                     "achieved_GBs": val * rate * row_bytes / 1e9}
 
@@ -783,11 +848,13 @@ def main():
         first = clf_timed(a.steps)          # the same sweeps the headline times
         clf_steps(max(0, 100 - done))
         later = clf_timed(a.steps)          # after 100 sweeps of the same ladder
+        later["one_sweep_per_launch"] = clf_timed(a.steps, per_launch=1)
         tracked = eng.energies()
         eng.recompute_energies()
         exact = bool(np.array_equal(tracked, eng.energies()))
         out.setdefault("variants", {})["cached_local_fields"] = {
             **first, "sweeps": f"{a.warmup}..{a.warmup + a.steps} (the headline's)",
+            "sweeps_per_launch": f"up to the next exchange round (interval {a.exchange_interval})",
             "after_100_sweeps": later,
             "tracked_energy_equals_recomputed": exact,
             "kernel_instantiation": last_kernel(), "geometry": eng.describe(),
@@ -821,13 +888,17 @@ def main():
         eng.enable_timing(False)
         bytes_per = float(len(csr[1])) / n * 4.0 + 8.0
         ach2 = per_launch_attempts * bytes_per / ((ms2 / max(l2, 1)) * 1e-3) / 1e9
-        out["variants"] = {"packed_entries": {
+        out["variants"] = {"cached_local_fields": None, "packed_entries": {
             "value": float(R) * n * 4 / dt2, "unit": "attempts/s", "ms_per_step": dt2 / 4 * 1e3,
             "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_attempt": bytes_per},
             "geometry": eng.describe(),
             "note": "integer couplings as one dword per entry (24-bit column, 8-bit value), integer row sums: "
                     "bit-identical chain to the (column, fp32 value) layout; the default for such problems"}}
+        out["variants"]["cached_local_fields"] = cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev,
+                                                                    a.exchange_interval)
+        eng.set_csr_storage("f32")
+        pt = tempering()  # back to the graded form (cpu_baseline replays on this engine)
     # The headline matrix (400 MB) is partly re-served by the 256 MB Infinity Cache, which the
     # fabric-side counters cannot tell from HBM.  The same kernel on a matrix far beyond every
     # cache (n = 32 768: 4.3 GB of fp32 couplings, same 1024 replicas, heuristic geometry) is the
