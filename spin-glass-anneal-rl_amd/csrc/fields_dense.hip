@@ -36,6 +36,18 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int FIELDS_TILE = 128;  // replicas x sites per workgroup (2 x 2 waves of 64 x 64)
 
+// Which (replica tile, site tile) a workgroup takes.  Workgroups are dealt to the 8 XCDs round robin by their linear
+// id, and every XCD has its own L2: with the replica tiles fastest in the id (round 3) the 8 workgroups that read the
+// SAME 128 coupling rows sat on 8 different XCDs and J left HBM 8 times per pass (3.55 GB for the 400 MB matrix of
+// BASELINE configs[1], 94.8 GB for 4.3 GB).  Here XCD x owns the site tiles it = x, x + 8, ... and runs a tile's
+// replica tiles back to back: the first of them pulls the rows through its L2, the others find them there.
+__device__ __forceinline__ void fields_tile_of(int n_rt, int n_it, int &rt, int &it) {
+    const int L = (int)blockIdx.x, x = L & 7, slot = L >> 3;  // (1-D grid of 8 * ceil(n_it / 8) * n_rt workgroups)
+    rt = slot % n_rt;
+    it = (slot / n_rt) * 8 + x;
+    if (it >= n_it) rt = -1;  // (a remainder slot of the last group of 8 site tiles)
+}
+
 // MODE 0: int8 J -> int32 Y; MODE 1: fp32 J, exact fp32 sums -> fp32 Y
 template <int MODE>
 __global__ void __launch_bounds__(256) fields_mfma_kernel(const FieldsArgs a) {
@@ -43,8 +55,11 @@ __global__ void __launch_bounds__(256) fields_mfma_kernel(const FieldsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 31, hh = lane >> 5;
-    const int r0 = blockIdx.x * FIELDS_TILE + (w >> 1) * 64;  // replica tiles fastest: the workgroups that
-    const int i0 = blockIdx.y * FIELDS_TILE + (w & 1) * 64;   // share a block of J rows run together
+    int rt, it;
+    fields_tile_of((a.R + FIELDS_TILE - 1) / FIELDS_TILE, (a.n + FIELDS_TILE - 1) / FIELDS_TILE, rt, it);
+    if (rt < 0) return;
+    const int r0 = rt * FIELDS_TILE + (w >> 1) * 64;
+    const int i0 = it * FIELDS_TILE + (w & 1) * 64;
     // rows past the end are clamped for the loads (their results are not stored)
     const int8_t *Sa[2];
     const unsigned char *Jb[2];
@@ -143,8 +158,11 @@ __global__ void __launch_bounds__(256) fields_mfma_f64_kernel(const FieldsArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 15, kk = lane >> 4;
-    const int r0 = blockIdx.x * 64 + (w >> 1) * 32;
-    const int i0 = blockIdx.y * 128 + (w & 1) * 64;
+    int rt, it;
+    fields_tile_of((a.R + 63) / 64, (a.n + 127) / 128, rt, it);
+    if (rt < 0) return;
+    const int r0 = rt * 64 + (w >> 1) * 32;
+    const int i0 = it * 128 + (w & 1) * 64;
     const int8_t *Sa[2];
     const float *Jb[4];
 #pragma unroll
@@ -197,12 +215,12 @@ __global__ void __launch_bounds__(256) fields_mfma_f64_kernel(const FieldsArgs a
 
 hipError_t launch_fields_dense(const FieldsArgs &a, int mode, hipStream_t st) {
     if (a.R <= 0 || a.n <= 0) return hipErrorInvalidValue;
+    auto grid_of = [](int n_rt, int n_it) { return dim3((unsigned)(8 * ((n_it + 7) / 8) * n_rt)); };  // fields_tile_of
     if (mode == 2) {
-        const dim3 grid((a.R + 63) / 64, (a.n + 127) / 128);
-        hipLaunchKernelGGL(fields_mfma_f64_kernel, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(fields_mfma_f64_kernel, grid_of((a.R + 63) / 64, (a.n + 127) / 128), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    const dim3 grid((a.R + FIELDS_TILE - 1) / FIELDS_TILE, (a.n + FIELDS_TILE - 1) / FIELDS_TILE);
+    const dim3 grid = grid_of((a.R + FIELDS_TILE - 1) / FIELDS_TILE, (a.n + FIELDS_TILE - 1) / FIELDS_TILE);
     if (mode == 0) hipLaunchKernelGGL(fields_mfma_kernel<0>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(fields_mfma_kernel<1>, grid, dim3(256), 0, st, a);
     return hipGetLastError();
