@@ -298,20 +298,27 @@ int sga_probe_read_bandwidth(int device, int64_t bytes, int reps, double *gb_per
 int sga_set_csr_storage(sga_engine *e, int storage);
 /* How sga_sweep evaluates a proposal.  OFF (default): the reference's way -- the local field of the
  * proposed site is formed from its coupling row (IsingModel.get_local_field, core/ising_model.py:176-185):
- * one row read per proposal.  ON / AUTO: the local fields of every replica stay resident (int16 / int32
- * in LDS; seeded by one pass over J on the matrix cores) and a row is read only when a proposal is
- * ACCEPTED, to update them -- the reference's incremental mode, core/energy_computer.py:166-173,262-265.
- * Same sites, uniforms and accept rule: the chain equals OFF's bit for bit.  Needs dense couplings of
- * one model, J integer valued and symmetric with a zero diagonal, h in multiples of 1/2,
- * max_i(sum_j |J_ij| + |h_i|) < 2^24 (2^23 with half-integer h),
- * n <= ~75 000 (int16 fields; ~37 000 with int32); any rule but SGA_RULE_WOLFF.  ON: sga_sweep fails with
- * SGA_ERR_UNSUPPORTED where that does not hold; AUTO: falls back to OFF's kernels there -- and while the
- * run is hot: it starts on OFF's kernels, reads the acceptance counters back every 4 ... 32 sweeps and takes
- * the cached-field sweep while the hottest replica accepts less than ~10 % of its proposals (the chain does
- * not depend on which kernel runs).  Cost model: an
- * accepted proposal costs ~2 us of its replica's chain, a rejected one next to nothing -- 100-300 x OFF in
- * the glassy regime annealing ends in (acceptance <= 2 %), break-even near 60 % acceptance, up to ~1.5 x
- * slower than OFF when nearly every proposal is accepted. */
+ * one row read per proposal.  ON / AUTO: the local fields of every replica stay resident in LDS and a row is
+ * read only when a proposal is ACCEPTED, to update them -- the reference's incremental mode,
+ * core/energy_computer.py:166-173,262-265.  Same sites, uniforms and accept rule on exact integers: the chain
+ * equals OFF's bit for bit.  Served:
+ *   dense couplings (sga_set_dense, one model): J integer valued and symmetric with a zero diagonal, h in
+ *     multiples of 1/2, max_i(sum_j |J_ij| + |h_i|) < 2^24 (2^23 with half-integer h), n <= ~75 000 (int16
+ *     fields; ~37 000 with int32); fields seeded by one pass over J on the matrix cores; any rule but
+ *     SGA_RULE_WOLFF, every site mode and arithmetic;
+ *   CSR couplings (sga_set_csr, or a sparse matrix sga_set_dense kept as CSR): J integer valued and symmetric
+ *     in strictly sorted rows (no duplicate entries), zero diagonal, h in multiples of 1/2,
+ *     max_i sum_j |J_ij| < 2^15 (only the dynamic part J s of a field is kept, as int16; h is read beside it),
+ *     rows of <= 2048 entries, n <= ~72 000; production sweeps (SGA_SITE_RANDOM, SGA_ARITH_F64, Metropolis, no
+ *     per-update records) -- other arguments take OFF's kernels for that call, the same chain.
+ * ON: sga_sweep fails with SGA_ERR_UNSUPPORTED where the problem does not qualify.  AUTO: falls back to OFF's
+ * kernels there -- and while replicas are hot: it starts on OFF's kernels, reads the per-replica acceptance
+ * counters back every 4 ... 32 sweeps and then routes EACH replica of a dense problem by its own acceptance
+ * (break-even = what an update costs its chain on OFF's kernel over what an accept costs it here: 0.25 on
+ * bit-planes, 0.39 on int8 rows at n = 10^4, never on fp32 rows): a ladder with a hot end runs as two concurrent
+ * launches over disjoint replica lists (option "replica_routing" = 0, and CSR problems: one launch, decided by the
+ * hottest replica).  Cost model: an accepted proposal costs ~1.1 - 1.7 us of its replica's serial chain, a
+ * rejected one next to nothing -- 100-450 x OFF in the glassy regime annealing ends in. */
 #define SGA_FIELD_CACHE_OFF 0
 #define SGA_FIELD_CACHE_ON 1
 #define SGA_FIELD_CACHE_AUTO 2
