@@ -363,10 +363,12 @@ int sga_get_option(sga_engine *e, const char *key, int64_t *value);
 int sga_option_name(int index, char *buf, int buflen);
 /* Tuning override (0 = heuristic): waves per replica and sweeps per launch. */
 int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
-/* Measured choice of the dense launch geometry: times the sweep kernel for every feasible
- * waves-per-replica on the current replicas (a few sweeps each) and keeps the fastest.  The
- * chain does not depend on the geometry and the replicas' state, best states and counters are
- * restored, so results are unaffected; timing statistics are reset.  No-op for CSR problems.
+/* Measured choice of the launch geometry / sweep form: times the sweep kernel for every feasible candidate on the
+ * current replicas (a few sweeps each) and keeps the fastest -- dense problems: waves per replica; CSR problems
+ * (round 4): waves per replica x several updates per step or one, i.e. every form sga_init_replicas chooses between
+ * by thresholds (the state travels through the geometry-independent blob of sga_export_state).  The chain does not
+ * depend on the form and the replicas' state, best states and counters are restored, so results are unaffected;
+ * timing statistics are reset.  No-op for sga_set_tsp problems.
  * (No reference counterpart: the reference has no launch geometry.) */
 int sga_autotune(sga_engine *e, double *best_ms_per_sweep);
 

@@ -765,6 +765,94 @@ int sga_set_field_cache(sga_engine *e, int mode) {
     return SGA_OK;
 }
 
+// Measured choice of the sweep FORM of a CSR problem (round 4).  The forms of sga_init_replicas -- waves per
+// replica (1, 2, 4, 8: a row dealt to several waves), spins as int8 or bits, several updates per step or one -- are
+// picked by thresholds measured on a few instance families; here every candidate that the problem admits runs the
+// real sweep kernel on the real replicas.  The state travels through the geometry-independent checkpoint blob
+// (sga_export_state / sga_import_state), so the run continues exactly as if this call had not happened; the chain
+// does not depend on the form.  The winner stays as sga_set_tuning / "csr_updates_per_step" would have set it.
+static int autotune_csr(sga_engine *e, double *best_ms_per_sweep) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    uint64_t need = 0;
+    int rc = sga_export_state(e, nullptr, 0, &need);
+    if (rc != SGA_OK) return rc;
+    std::vector<unsigned char> blob((size_t)need);
+    rc = sga_export_state(e, blob.data(), need, nullptr);
+    if (rc != SGA_OK) return rc;
+    const int R = e->R, Rg = e->Rg, replica0 = e->replica0, n_ladders = e->n_ladders;
+    const uint64_t seed = e->seed;
+    std::vector<double> ladder;
+    if (n_ladders > 0) {
+        ladder.resize((size_t)Rg);
+        HIPCHK(hipMemcpy(ladder.data(), e->slot_temps, sizeof(double) * (size_t)Rg, hipMemcpyDeviceToHost));
+    }
+    const int user_waves = e->tune_waves, user_spl = e->tune_spl, user_cache = e->field_cache;
+    const long long user_ups = e->opt[OPT_CSR_UPDATES_PER_STEP];
+    const bool was_timing = e->timing;
+    e->field_cache = SGA_FIELD_CACHE_OFF;  // (the forms are the row-per-proposal kernels')
+    // lay the replicas out for a candidate and put the saved state back
+    auto layout = [&](int waves, long long ups) -> int {
+        e->tune_waves = waves;
+        e->opt[OPT_CSR_UPDATES_PER_STEP] = ups;
+        int r2 = sga_init_replicas(e, R, Rg, replica0, seed, nullptr);
+        if (r2 == SGA_OK && n_ladders > 0) r2 = sga_set_ladder(e, ladder.data(), n_ladders);
+        if (r2 == SGA_OK) r2 = sga_import_state(e, blob.data(), need);
+        return r2;
+    };
+    auto timed = [&](int k, double &ms) -> int {
+        e->tune_spl = k;
+        e->timing = true;
+        int64_t launches = 0;
+        double t = 0.0;
+        (void)sga_get_kernel_time(e, &launches, &t, 1);
+        int r2 = sga_sweep(e, k, SGA_SITE_RANDOM, SGA_ARITH_F64, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (r2 != SGA_OK) return r2;
+        r2 = sga_get_kernel_time(e, &launches, &t, 1);
+        ms = t;
+        return r2;
+    };
+    struct Cand {
+        int waves;
+        long long ups;
+    };
+    std::vector<Cand> cands = {{0, -1}, {1, -1}, {2, -1}, {4, -1}, {8, -1}};
+    if (e->max_row_len <= 256) cands.push_back({0, 0}), cands.push_back({1, 0});  // (one update at a time)
+    double best = 1e300;
+    int best_i = -1;
+    char seen[16][96];
+    int n_seen = 0;
+    for (size_t i = 0; i < cands.size(); ++i) {
+        if (layout(cands[i].waves, cands[i].ups) != SGA_OK) {
+            (void)hipGetLastError();
+            continue;  // (a form the problem does not admit)
+        }
+        double t1 = 0.0, t = 0.0;
+        if (timed(1, t1) != SGA_OK) continue;
+        // the same kernel form as an earlier candidate?  (the heuristic's choice is one of the explicit ones)
+        bool dup = false;
+        for (int q = 0; q < n_seen; ++q) dup = dup || std::strncmp(seen[q], sga::last_sweep_kernel(), 95) == 0;
+        if (dup) continue;
+        if (n_seen < 16) std::snprintf(seen[n_seen++], 96, "%s", sga::last_sweep_kernel());
+        const int k = t1 > 0.0 ? (int)std::min(32.0, std::max(1.0, std::ceil(2.0 / t1))) : 1;
+        if (layout(cands[i].waves, cands[i].ups) != SGA_OK || timed(k, t) != SGA_OK) continue;
+        if (t / k < best * 0.995) {  // (ties go to the earlier, simpler candidate)
+            best = t / k;
+            best_i = (int)i;
+        }
+    }
+    e->timing = was_timing;
+    e->tune_spl = user_spl;
+    e->field_cache = user_cache;
+    e->fields_valid = false;
+    dev_free(e->fields);
+    rc = layout(best_i >= 0 ? cands[(size_t)best_i].waves : user_waves, best_i >= 0 ? cands[(size_t)best_i].ups : user_ups);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (rc != SGA_OK) return rc;
+    if (best_i >= 0 && best_ms_per_sweep) *best_ms_per_sweep = best;
+    return SGA_OK;
+}
+
 // Measured choice of the dense launch geometry.  Every candidate (waves per replica) runs the
 // real sweep kernel on the real replicas for a trial; the chain does not depend on the geometry,
 // and spins / energies / best states / counters are put back afterwards, so the run continues
@@ -773,7 +861,8 @@ int sga_autotune(sga_engine *e, double *best_ms_per_sweep) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (e->R <= 0) return fail(SGA_ERR_INVALID, "no replicas (call sga_init_replicas)");
     if (best_ms_per_sweep) *best_ms_per_sweep = 0.0;
-    if (e->csr || e->tsp) return SGA_OK;  // CSR forms are chosen from LDS residency (sga_init_replicas)
+    if (e->tsp) return SGA_OK;
+    if (e->csr) return autotune_csr(e, best_ms_per_sweep);
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int n = e->n, R = e->R;

@@ -1374,3 +1374,49 @@ def test_csr_medium_rows_with_a_short_last_row(sg, longest):
         assert np.array_equal(out["energy_trace"], ref["energy_trace"]), k
         assert np.array_equal(e.spins(), s)
         assert np.array_equal(e.stats()[0], ref["n_accepted"])
+
+
+@pytest.mark.parametrize("n,deg,R", [(1200, 30, 48), (900, 220, 40), (2500, 700, 24)])
+def test_csr_autotune_keeps_the_chain_and_the_state(sg, n, deg, R):
+    """sga_autotune on a CSR problem: every admissible sweep form (waves per replica, several updates per step or one)
+    is timed on the live replicas through the geometry-independent state blob; the run continues as if nothing had
+    happened -- spins, energies, bests, counters, ladder permutation -- and stays on the oracle's chain."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    rng = np.random.RandomState(n + deg)
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rng.choice(n, deg // 2, replace=False):
+            if i != j:
+                J[i, j] = J[j, i] = float(rng.choice([-2.0, -1.0, 1.0, 2.0]))
+    h = rng.randint(-1, 2, n).astype(np.float32)
+    csr = csr_of(J)
+    temps = ladder(R, 2.0 * np.sqrt(deg), 0.1 * np.sqrt(deg))
+    seed = 99 + n
+    prob = oracle.Problem(csr=csr, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, 3, seed=seed, n_threads=8)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(*csr, h)
+        e.init_replicas(R, seed=seed)
+        e.set_ladder(temps)
+        e.sweep(3)
+        e.exchange()
+        before = (e.energies(), e.spins(), e.stats()[0], e.slot_map(), e.counters(), e.best()[0], e.temperatures())
+        k0 = last_kernel()
+        ms = e.autotune()
+        assert ms > 0.0
+        after = (e.energies(), e.spins(), e.stats()[0], e.slot_map(), e.counters(), e.best()[0], e.temperatures())
+        for x, y in zip(before, after):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+        assert np.array_equal(before[1], s) and np.array_equal(before[0], ref["energy"])
+        # the run goes on, on whatever form was picked, exactly like one that was never tuned
+        e.sweep(3)
+        with sg.AnnealEngine(0) as plain:
+            plain.set_csr(*csr, h)
+            plain.init_replicas(R, seed=seed)
+            plain.set_ladder(temps)
+            plain.sweep(3)
+            plain.exchange()
+            plain.sweep(3)
+            assert np.array_equal(plain.energies(), e.energies()) and np.array_equal(plain.spins(), e.spins())
+        print(n, deg, "before:", k0, "| picked:", last_kernel(), f"| {ms:.4f} ms per sweep")
