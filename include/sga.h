@@ -313,7 +313,7 @@ int sga_set_csr_storage(sga_engine *e, int storage);
  *     per-update records) -- other arguments take OFF's kernels for that call, the same chain.
  * ON: sga_sweep fails with SGA_ERR_UNSUPPORTED where the problem does not qualify.  AUTO: falls back to OFF's
  * kernels there -- and while replicas are hot: it starts on OFF's kernels, reads the per-replica acceptance
- * counters back every 4 ... 32 sweeps and then routes EACH replica of a dense problem by its own acceptance
+ * counters back every 4 ... 16 sweeps and then routes EACH replica of a dense problem by its own acceptance
  * (break-even = what an update costs its chain on OFF's kernel over what an accept costs it here: 0.25 on
  * bit-planes, 0.39 on int8 rows at n = 10^4, never on fp32 rows): a ladder with a hot end runs as two concurrent
  * launches over disjoint replica lists (option "replica_routing" = 0, and CSR problems: one launch, decided by the
@@ -333,6 +333,14 @@ int sga_set_field_cache(sga_engine *e, int mode);
  *   "force_general"         0 (default) | 1   general kernel builds even for production arguments       [sweep; SGA_FORCE_GENERAL]
  *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the windowed cached-field
  *                           sweep (a value selects that form)                                       [sweep; SGA_CLF_WAVES]
+ *   "clf_tail_waves"        0 | 1 (default)   cached-field sweep over dense couplings (ON and AUTO): the per-replica
+ *                           acceptance is looked at every 4 ... 16 sweeps; once the mean is below 0.28 of the
+ *                           hottest replica's -- the launch is that replica's chain, the chip idles behind it -- every
+ *                           replica runs at eight waves.  Same chain                          [sweep; SGA_NO_CLF_TAIL_WAVES]
+ *   "clf_batched"           0 (default) | 1   cached-field sweep under production arguments commits SEVERAL accepts per
+ *                           round: all decisions of a window guessed at once, the guess checked against the couplings
+ *                           between the accepting sites, the rows applied back to back (csrc/sweep_clfb_impl.h).
+ *                           Same chain; ahead only while replicas accept more than ~2 %, hence opt-in [sweep; SGA_CLF_BATCHED]
  *   "clf_chain"             0 (default) | 1   cached-field sweep under production arguments in the chain-wave form: one
  *                           wave walks the chain over the few candidates that can accept within a window's flip
  *                           budget, three waves keep the field array up to date (csrc/sweep_clfc_impl.h).  Same

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,8 @@ int fail(int code, const std::string &msg) {
 enum Opt {
     OPT_LOOK_AHEAD, OPT_CLF_WAVES, OPT_SPARSE_ROUTE, OPT_BATCHED_ENERGY, OPT_FORCE_GENERAL, OPT_CSR_UPDATES_PER_STEP,
     OPT_TSP_PARALLEL, OPT_FORCE_CSR_BITS, OPT_CSR_BITS, OPT_CSR_SLOTS, OPT_HALF_TABLE, OPT_FORCE_CSR_ACC,
-    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_CHAIN, OPT_CLF_FLIPS, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_COUNT
+    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_CHAIN, OPT_CLF_FLIPS, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_CLF_BATCHED,
+    OPT_CLF_TAIL_WAVES, OPT_COUNT
 };
 struct OptDef {
     const char *key;
@@ -58,6 +60,8 @@ constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"clf_flips", "SGA_CLF_FLIPS", 0, 0, 12, 1, 64},
     {"replica_routing", "SGA_NO_REPLICA_ROUTING", 1, 0, 1, 0, 1},
     {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536},
+    {"clf_batched", "SGA_CLF_BATCHED", 1, 1, 0, 0, 1},
+    {"clf_tail_waves", "SGA_NO_CLF_TAIL_WAVES", 1, 0, 1, 0, 1},
 };
 int find_option(const char *key) {
     if (!key) return -1;
@@ -230,8 +234,9 @@ struct sga_engine {
     // per-replica counters): an accept costs ~2 us of its replica's chain, so the cached-field sweep only
     // pays while the HOTTEST replica accepts little
     bool auto_unavailable = false;      // the fields could not be allocated: AUTO stays on the row-per-proposal kernels
-    std::vector<int> route;             // AUTO, per local replica: 0 = cached-field kernel, 1 = row-per-proposal kernel
+    std::vector<int> route;             // per local replica: 0 = cached-field kernel, 1 = row-per-proposal kernel (AUTO)
     int n_route_clf = 0;                // replicas routed to the cached-field kernel
+    bool clf_wide = false;              // the cached-field launch runs at eight waves per replica (option "clf_tail_waves")
     bool route_dirty = true;            // the device copy of the replica lists is stale
     int *d_rep_lists = nullptr;         // [2][R]: the cached-field kernel's replicas, then the row kernels'
     hipStream_t aux_stream = nullptr;   // the second launch of a mixed sweep
@@ -323,6 +328,7 @@ struct sga_engine {
         auto_unavailable = false;
         route.clear();
         n_route_clf = 0;
+        clf_wide = false;
         route_dirty = true;
         dev_free(d_rep_lists);
         auto_mark_attempted = 0;
@@ -1917,16 +1923,29 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // of the two (profiles/r04_experiments.md 2), and a ladder with a hot end runs as TWO concurrent launches (two
     // streams) over disjoint replica lists.  The chain of a replica does not depend on the kernel that walks it.
     // The run starts on the row kernels (nothing is known yet); the per-replica counters are read back every
-    // 4 ... 32 sweeps.  Option "replica_routing" = 0: one launch, decided by the hottest replica (round 3).
+    // 4 ... 16 sweeps.  Option "replica_routing" = 0: one launch, decided by the hottest replica (round 3).
+    // Both cached-field modes (ON and AUTO) look at the per-replica acceptance now and then.  A launch of the cached-field
+    // kernel ends with its hottest replica's serial chain; once most replicas accept next to nothing -- their workgroups
+    // are gone early and the chip idles behind that one chain -- EVERY replica gets eight waves (option "clf_tail_waves"):
+    // the workgroups then run as two rounds, which costs where the replicas are busy (sweeps 5-25 of the 10 000-spin ladder:
+    // 0.42 against 0.27 ms per sweep) and pays in the tail (after 100 sweeps 0.098 against 0.106;
+    // profiles/r04_experiments.md 9).  Giving only the hottest replicas eight waves in a launch of their own did not:
+    // beside the four-wave workgroups of the others their rounds took 1.6 us instead of 0.9.
     int n_clf = clf ? R : 0;  // replicas on the cached-field kernel in this call
-    if (clf && e->field_cache == SGA_FIELD_CACHE_AUTO) {
-        if (e->auto_unavailable) {
+    const bool is_auto = e->field_cache == SGA_FIELD_CACHE_AUTO;
+    const int clf_waves_std = (clf && !e->csr) ? sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]) : 0;
+    const bool tail_opt = clf && !e->csr && e->opt[OPT_CLF_TAIL_WAVES] != 0 && e->opt[OPT_CLF_WAVES] == 0 && e->opt[OPT_CLF_CHAIN] == 0 &&
+                         clf_waves_std < 8 && e->ldj >= 6 * (e->want_i8 ? 1024 : 256) && e->R >= 16;
+    if (clf && (is_auto || tail_opt)) {
+        if (is_auto && e->auto_unavailable) {
             n_clf = 0;
         } else {
             if ((long long)e->auto_mark_acc.size() != e->R) {
                 e->auto_mark_acc.assign((size_t)e->R, 0ull);
-                e->route.assign((size_t)e->R, 1);  // 1 = row-per-proposal kernel, 0 = cached-field kernel
-                e->n_route_clf = 0;
+                // AUTO: 1 = row-per-proposal kernel until the acceptance is known; ON: 0 = cached-field kernel
+                e->route.assign((size_t)e->R, is_auto ? 1 : 0);
+                e->n_route_clf = is_auto ? 0 : e->R;
+                e->clf_wide = false;
                 e->auto_mark_attempted = 0;
                 e->auto_interval = 4;
             }
@@ -1936,40 +1955,60 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                 HIPCHK(hipMemcpyAsync(now.data(), e->n_acc, sizeof(unsigned long long) * e->R, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (since > 0) {
-                    // (enter, leave): acceptance below which a replica is taken onto the cached-field kernel, above
-                    // which it is given back (hysteresis)
-                    // Break-even acceptance of ONE replica = (what an update costs its chain on the row kernel) / (what
-                    // an accept costs it on the cached-field kernel).  Both kernels are paced by a replica's serial
-                    // chain, not by the chip, whenever only part of the replicas is hot: ~1.5 us per accept (1.15 alone
-                    // on its CU ... 1.7 with busy neighbours), and per update 0.38 us on bit-planes / 0.58 us on int8
-                    // rows at n = 10^4, ~0.3 us on short rows (profiles/r04_routing.py; fp32 rows: estimate).
-                    const double kn = (double)n / 1000.0;
-                    const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
-                                         : e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
-                    const double theta = t_upd / 1.5;
-                    const double enter = 0.8 * theta, leave = 1.2 * theta;
                     bool back = false;
-                    if (e->opt[OPT_REPLICA_ROUTING] != 0 && !e->csr) {  // (the CSR row kernels take no replica lists)
-                        for (int r2 = 0; r2 < e->R; ++r2) {
-                            const double acc = (double)(now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]) / (double)since;
-                            int &rt = e->route[(size_t)r2];
-                            if (rt == 0 && acc > leave) rt = 1;
-                            else if (rt == 1 && acc < enter) rt = 0, back = true;
+                    const bool was_wide = e->clf_wide;
+                    if (is_auto) {
+                        // (enter, leave): acceptance below which a replica is taken onto the cached-field kernel, above
+                        // which it is given back (hysteresis)
+                        // Break-even acceptance of ONE replica = (what an update costs its chain on the row kernel) / (what
+                        // an accept costs it on the cached-field kernel).  Both kernels are paced by a replica's serial
+                        // chain, not by the chip, whenever only part of the replicas is hot: ~1.5 us per accept (1.15 alone
+                        // on its CU ... 1.7 with busy neighbours), and per update 0.38 us on bit-planes / 0.58 us on int8
+                        // rows at n = 10^4, ~0.3 us on short rows (profiles/r04_routing.py; fp32 rows: estimate).
+                        const double kn = (double)n / 1000.0;
+                        const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
+                                             : e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
+                        const double theta = t_upd / 1.5;
+                        const double enter = 0.8 * theta, leave = 1.2 * theta;
+                        if (e->opt[OPT_REPLICA_ROUTING] != 0 && !e->csr) {  // (the CSR row kernels take no replica lists)
+                            for (int r2 = 0; r2 < e->R; ++r2) {
+                                const double acc = (double)(now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]) / (double)since;
+                                int &rt = e->route[(size_t)r2];
+                                if (rt == 0 && acc > leave) rt = 1;
+                                else if (rt == 1 && acc < enter) rt = 0, back = true;
+                            }
+                        } else {
+                            unsigned long long top = 0;
+                            for (int r2 = 0; r2 < e->R; ++r2) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
+                            const double hottest = (double)top / (double)since;
+                            const bool was = e->n_route_clf > 0;
+                            const bool use = was ? hottest < leave : hottest < enter;
+                            back = use && !was;
+                            e->route.assign((size_t)e->R, use ? 0 : 1);
                         }
-                    } else {
-                        unsigned long long top = 0;
-                        for (int r2 = 0; r2 < e->R; ++r2) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
-                        const double hottest = (double)top / (double)since;
-                        const bool was = e->n_route_clf > 0;
-                        const bool use = was ? hottest < leave : hottest < enter;
-                        back = use && !was;
-                        e->route.assign((size_t)e->R, use ? 0 : 1);
                     }
                     int cnt = 0;
                     for (int v : e->route) cnt += v == 0;
                     e->n_route_clf = cnt;
+                    e->clf_wide = false;
+                    if (tail_opt && cnt > 0) {
+                        // accepts per sweep of the replicas on the cached-field kernel: the hottest one's, and the mean
+                        const double per_sweep = (double)n / (double)since;  // counter difference -> accepts per sweep
+                        double amax = 0.0, asum = 0.0;
+                        for (int r2 = 0; r2 < e->R; ++r2) {
+                            if (e->route[(size_t)r2] != 0) continue;
+                            const double ar = (double)(now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]) * per_sweep;
+                            amax = std::max(amax, ar);
+                            asum += ar;
+                        }
+                        // (mean / hottest ~ the share of the launch during which the chip is busy: measured ahead at 0.21,
+                        //  behind at 0.38 -- in below 0.28, out above 0.36; a chain of two dozen accepts per sweep is the
+                        //  least that matters against the windows of a sweep)
+                        const double ratio = asum / (double)cnt / std::max(amax, 1.0);
+                        e->clf_wide = amax >= 24.0 && ratio < (was_wide ? 0.36 : 0.28);
+                    }
                     if (back) e->fields_valid = false;  // somebody returns from the row kernels: fields are seeded anew
-                    e->auto_interval = std::min(32, e->auto_interval * 2);
+                    e->auto_interval = std::min(16, e->auto_interval * 2);
                     e->route_dirty = true;
                 }
                 e->auto_mark_acc.swap(now);
@@ -1993,7 +2032,8 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             return rc;
         }
     }
-    const bool mixed = clf && n_clf < R;
+    const int n_rows = clf ? R - n_clf : 0;  // replicas of this call on the row-per-proposal kernels beside the cached ones
+    const bool mixed = clf && n_rows > 0;
     if (mixed) {
         // replica lists on the device ([0, n_clf): cached-field kernel, [R, R + R - n_clf): row kernels), the second
         // stream and the two events that fork / join it
@@ -2013,7 +2053,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         if (!e->fork_ev) HIPCHK(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
         if (!e->join_ev) HIPCHK(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
     }
-    if (clf && !mixed) {
+    if (clf && n_rows == 0) {
         // no row streaming to bound the launch by: many sweeps per launch (a sweep is 0.1 ... 10 ms here:
         // at most 256 of them, so that a launch stays well under a few seconds)
         if (e->tune_spl <= 0) spl = std::min(n_sweeps, 256);
@@ -2141,13 +2181,23 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             ac.clf_chain = (int)e->opt[OPT_CLF_CHAIN];
             ac.clf_flips = (int)e->opt[OPT_CLF_FLIPS];
             ac.clf_jmax = e->j_abs_max;
-            const int cw = sga::sweep_clf_waves(e->ldj, e->want_i8, mixed ? n_clf : e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]);
+            const int cw = (tail_opt && e->clf_wide)
+                               ? 8
+                               : sga::sweep_clf_waves(e->ldj, e->want_i8, mixed ? n_clf : e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]);
             // option "clf_chain": production arguments take the chain-wave form (one wave walks the chain, three keep
             // the fields up to date: sweep_clfc_impl.h) -- the same chain; measured no faster than the windowed form
             // (profiles/r04_experiments.md 3), hence opt-in
             const bool chain = e->opt[OPT_CLF_WAVES] == 0 && sga::sweep_clfc_applies(ac);
+            // option "clf_batched": production arguments commit several accepts per round -- every decision of a
+            // super-window guessed at once, the guess checked against the few couplings between the accepting sites
+            // (sweep_clfb_impl.h); the same chain.  Measured ahead only while replicas accept more than ~2 % (hot first
+            // sweeps 2.19 -> 1.90 ms), behind after 100 sweeps (0.106 -> 0.123): opt-in (profiles/r04_experiments.md 9)
+            ac.clf_batched = (int)e->opt[OPT_CLF_BATCHED];
+            const bool batched = !chain && sga::sweep_clfb_applies(ac, e->want_i8);
             auto launch_cached = [&](const sga::SweepArgs &aa, hipStream_t s2) -> hipError_t {
-                return chain ? sga::launch_sweep_clfc(aa, e->want_i8, s2) : sga::launch_sweep_clf(aa, e->want_i8, cw, s2);
+                return chain     ? sga::launch_sweep_clfc(aa, e->want_i8, s2)
+                       : batched ? sga::launch_sweep_clfb(aa, e->want_i8, cw, s2)
+                                 : sga::launch_sweep_clf(aa, e->want_i8, cw, s2);
             };
             if (!mixed) {
                 le = launch_cached(ac, st);
@@ -2871,13 +2921,15 @@ int sga_describe(sga_engine *e, char *buf, int buflen) {
     } else if (clf_active(e)) {
         if (e->field_cache == SGA_FIELD_CACHE_ON)
             std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
-                          " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica, row read on accept only)",
-                          e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]));
+                          " sweep=cached-local-fields(int%d in LDS, %d wave(s) per replica%s, row read on accept only)",
+                          e->clf_bits, sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]),
+                          e->clf_wide ? " -- now 8: the launch is its hottest replica's chain" : "");
         else
             std::snprintf(tmp + std::strlen(tmp), sizeof(tmp) - std::strlen(tmp),
                           " sweep=auto(cached local fields, int%d in LDS, per replica by its own acceptance; now: %d of %d "
-                          "replica(s) cached, the rest one row per proposal)",
-                          e->clf_bits, e->auto_unavailable ? 0 : e->n_route_clf, e->R);
+                          "replica(s) cached%s, the rest one row per proposal)",
+                          e->clf_bits, e->auto_unavailable ? 0 : e->n_route_clf, e->R,
+                          (!e->auto_unavailable && e->clf_wide) ? " at 8 waves each" : "");
     }
     std::snprintf(buf, (size_t)buflen, "%s", tmp);
     return SGA_OK;

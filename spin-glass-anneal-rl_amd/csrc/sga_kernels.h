@@ -85,6 +85,7 @@ struct SweepArgs {
     long long ldf;
     int field_bits;      // 16 | 32
     int field_scale;     // 1 | 2 (J integer, h a multiple of 1/2)
+    int clf_batched;     // 1: several accepts per round (sweep_clfb_impl.h) where the arguments are the production ones
     int clf_chain;       // 1: the chain-wave form (sweep_clfc_impl.h) where the arguments are the production ones
     int clf_flips;       // chain-wave form: accepted proposals per window (the candidate filter's flip budget K)
     int clf_jmax;        // max |J_ij| (integer): the most one flip moves another site's field, in units of 2 scale
@@ -153,6 +154,10 @@ hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t 
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
 hipError_t launch_sweep_clfc(const SweepArgs &a, bool j_is_i8, hipStream_t st);  // chain-wave form, production arguments
 bool sweep_clfc_applies(const SweepArgs &a);
+hipError_t launch_sweep_clfb(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);  // several accepts per round
+bool sweep_clfb_applies(const SweepArgs &a, bool j_is_i8);
+size_t sweep_clfb_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
+int sweep_clf_batch(long long ldj, bool j_is_i8, int waves);
 // ... and of CSR problems with integer couplings (rows sorted, |sum_j J_ij s_j| < 2^15)
 hipError_t launch_sweep_clf_csr(const SweepArgs &a, int waves, hipStream_t st);
 bool sweep_clf_csr_applies(const SweepArgs &a, int waves);

@@ -86,23 +86,53 @@ __device__ __forceinline__ int add_pair(int pair, int d_lo, int d_hi) {
     return (int)(((p + (unsigned int)d_lo) & 0xFFFFu) | ((p + ((unsigned int)d_hi << 16)) & 0xFFFF0000u));
 }
 
-// F_j -= 2 scale J_ij s_i for the EPL = 16 / sizeof(JT) couplings x = J[i][j0 .. j0 + EPL) of one lane.  NEG = the
-// amount is subtracted (mult < 0): a compile-time constant, the caller branches once per accept on the wave-uniform
-// sign (left to the compiler the select costs two more VALU per int16 pair).  mult = -2 scale s_i(old).
+// F_j -= 2 scale J_ij s_i for the EPL = 16 / sizeof(JT) couplings x = J[i][j0 .. j0 + EPL) of one lane, in three
+// steps -- the lane's EPL fields LDS -> registers, the update, registers -> LDS -- so that a caller with several
+// chunks per row can read all their fields first and pay the LDS round trip once per row (clf_apply_chunk does one
+// chunk from end to end).  NEG = the amount is subtracted (mult < 0): a compile-time constant, the caller branches
+// once per accept on the wave-uniform sign (left to the compiler the select costs two more VALU per int16 pair).
+// mult = -2 scale s_i(old).
+template <typename JT, typename FT>
+struct ClfFields {
+    static constexpr int N = (16 / (int)sizeof(JT)) * (int)sizeof(FT) / 4;  // dwords: 2 | 4 | 8 | 16
+    int v[N];
+};
+template <typename JT, typename FT>
+__device__ __forceinline__ ClfFields<JT, FT> clf_fields_load(const FT *F, long long j0) {
+    ClfFields<JT, FT> f;
+    if constexpr (ClfFields<JT, FT>::N == 2) {
+        const int2 t = *reinterpret_cast<const int2 *>(F + j0);
+        f.v[0] = t.x, f.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < ClfFields<JT, FT>::N / 4; ++i) {
+            const int4 t = *reinterpret_cast<const int4 *>(reinterpret_cast<const unsigned char *>(F + j0) + 16 * i);
+            f.v[4 * i] = t.x, f.v[4 * i + 1] = t.y, f.v[4 * i + 2] = t.z, f.v[4 * i + 3] = t.w;
+        }
+    }
+    return f;
+}
+template <typename JT, typename FT>
+__device__ __forceinline__ void clf_fields_store(FT *F, long long j0, const ClfFields<JT, FT> &f) {
+    if constexpr (ClfFields<JT, FT>::N == 2) {
+        *reinterpret_cast<int2 *>(F + j0) = make_int2(f.v[0], f.v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ClfFields<JT, FT>::N / 4; ++i)
+            *reinterpret_cast<int4 *>(reinterpret_cast<unsigned char *>(F + j0) + 16 * i) =
+                make_int4(f.v[4 * i], f.v[4 * i + 1], f.v[4 * i + 2], f.v[4 * i + 3]);
+    }
+}
 template <typename JT, typename FT, bool NEG, typename VEC>
-__device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j0, int mult, int sc) {
+__device__ __forceinline__ void clf_fields_update(ClfFields<JT, FT> &f, const VEC &x, int mult, int sc) {
     constexpr int FB = (int)sizeof(FT);
     if constexpr (sizeof(JT) == 4) {
         const int d0 = mult * (int)x.x, d1 = mult * (int)x.y, d2 = mult * (int)x.z, d3 = mult * (int)x.w;
         if constexpr (FB == 2) {
-            int2 f = *reinterpret_cast<int2 *>(F + j0);
-            f.x = add_pair(f.x, d0, d1);
-            f.y = add_pair(f.y, d2, d3);
-            *reinterpret_cast<int2 *>(F + j0) = f;
+            f.v[0] = add_pair(f.v[0], d0, d1);
+            f.v[1] = add_pair(f.v[1], d2, d3);
         } else {
-            int4 f = *reinterpret_cast<int4 *>(F + j0);
-            f.x += d0, f.y += d1, f.z += d2, f.w += d3;
-            *reinterpret_cast<int4 *>(F + j0) = f;
+            f.v[0] += d0, f.v[1] += d1, f.v[2] += d2, f.v[3] += d3;
         }
     } else {
         const int wds[4] = {x.x, x.y, x.z, x.w};
@@ -112,8 +142,6 @@ __device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j
             // arithmetic shift right by 8 - log2 |mult| makes it |mult| * b, one packed add or subtract
             // applies it: 3 instructions per pair.  |mult| = 2 scale is 2 or 4.
             typedef short short2v __attribute__((ext_vector_type(2)));
-            int4 f0 = *reinterpret_cast<int4 *>(F + j0), f1 = *reinterpret_cast<int4 *>(F + j0 + 8);
-            int *fp[8] = {&f0.x, &f0.y, &f0.z, &f0.w, &f1.x, &f1.y, &f1.z, &f1.w};
             const short sh = (short)(sc == 1 ? 7 : 6);
             const short2v shv = {sh, sh};
 #pragma unroll
@@ -122,25 +150,43 @@ __device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j
                 const unsigned int t23 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x070c060cu);
                 const short2v v01 = __builtin_bit_cast(short2v, t01) >> shv;
                 const short2v v23 = __builtin_bit_cast(short2v, t23) >> shv;
-                short2v lo = __builtin_bit_cast(short2v, *fp[2 * d]), hi = __builtin_bit_cast(short2v, *fp[2 * d + 1]);
+                short2v lo = __builtin_bit_cast(short2v, f.v[2 * d]), hi = __builtin_bit_cast(short2v, f.v[2 * d + 1]);
                 if constexpr (NEG) lo -= v01, hi -= v23;
                 else lo += v01, hi += v23;
-                *fp[2 * d] = __builtin_bit_cast(int, lo);
-                *fp[2 * d + 1] = __builtin_bit_cast(int, hi);
+                f.v[2 * d] = __builtin_bit_cast(int, lo);
+                f.v[2 * d + 1] = __builtin_bit_cast(int, hi);
             }
-            *reinterpret_cast<int4 *>(F + j0) = f0;
-            *reinterpret_cast<int4 *>(F + j0 + 8) = f1;
         } else {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                int4 f = *reinterpret_cast<int4 *>(F + j0 + 4 * d);
-                f.x += mult * (int)(int8_t)(wds[d]);
-                f.y += mult * (int)(int8_t)(wds[d] >> 8);
-                f.z += mult * (int)(int8_t)(wds[d] >> 16);
-                f.w += mult * (wds[d] >> 24);
-                *reinterpret_cast<int4 *>(F + j0 + 4 * d) = f;
+                f.v[4 * d] += mult * (int)(int8_t)(wds[d]);
+                f.v[4 * d + 1] += mult * (int)(int8_t)(wds[d] >> 8);
+                f.v[4 * d + 2] += mult * (int)(int8_t)(wds[d] >> 16);
+                f.v[4 * d + 3] += mult * (wds[d] >> 24);
             }
         }
+    }
+}
+template <typename JT, typename FT, bool NEG, typename VEC>
+__device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j0, int mult, int sc) {
+    ClfFields<JT, FT> f = clf_fields_load<JT, FT>(F, j0);
+    clf_fields_update<JT, FT, NEG>(f, x, mult, sc);
+    clf_fields_store<JT, FT>(F, j0, f);
+}
+// a wave's whole first batch of chunks, all of them full (no lane guard): fields of every chunk read first
+template <typename JT, typename FT, bool NEG, int NCH, bool UPFRONT = true, typename VEC, typename ELEM0>
+__device__ __forceinline__ void clf_apply_full_chunks(FT *F, const VEC *x, ELEM0 elem_of, int mult, int sc) {
+    if constexpr (UPFRONT && ClfFields<JT, FT>::N * NCH <= 24) {
+        ClfFields<JT, FT> f[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) f[q] = clf_fields_load<JT, FT>(F, elem_of(q));
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) clf_fields_update<JT, FT, NEG>(f[q], x[q], mult, sc);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) clf_fields_store<JT, FT>(F, elem_of(q), f[q]);
+    } else {  // (too many registers to hold at once: chunk by chunk)
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) clf_apply_chunk<JT, FT, NEG>(F, x[q], elem_of(q), mult, sc);
     }
 }
 
@@ -225,11 +271,26 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
     auto apply_chunk = [&](const vec_t &x, long long j0, int mult /* -2 scale s_i(old) */, auto neg) {
         clf_apply_chunk<JT, FT, decltype(neg)::value>(F, x, j0, mult, sc);
     };
-    auto apply_row_signed = [&](const RowRegs &rr, int site, int mult, auto neg) {
+    // chunks of this wave's first batch that lie fully inside the row (wave-uniform): their field update needs no lane
+    // guard, and without the guards a row's updates are one straight line with the field reads up front
+    int nfull = 0;
 #pragma unroll
-        for (int q = 0; q < CLF_BATCH; ++q) {
-            const long long j0 = elem0(w + q * W);
-            if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult, neg);
+    for (int q = 0; q < CLF_BATCH; ++q)
+        if ((long long)(w + q * W + 1) * EPC <= a.ldj) nfull = q + 1;
+    auto first_chunk = [&](int q) -> long long { return elem0(w + q * W); };
+    auto apply_row_signed = [&](const RowRegs &rr, int site, int mult, auto neg) {
+        if (!TAIL && nfull == CLF_BATCH) {  // (the long-row build keeps the guarded form throughout)
+            clf_apply_full_chunks<JT, FT, decltype(neg)::value, CLF_BATCH>(F, rr.x, first_chunk, mult, sc);
+        } else if (!TAIL && nfull == CLF_BATCH - 1) {
+            clf_apply_full_chunks<JT, FT, decltype(neg)::value, CLF_BATCH - 1>(F, rr.x, first_chunk, mult, sc);
+            const long long j0 = elem0(w + (CLF_BATCH - 1) * W);
+            if (j0 < a.ldj) apply_chunk(rr.x[CLF_BATCH - 1], j0, mult, neg);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CLF_BATCH; ++q) {
+                const long long j0 = elem0(w + q * W);
+                if (j0 < a.ldj) apply_chunk(rr.x[q], j0, mult, neg);
+            }
         }
         if constexpr (!TAIL) return;
         const JT *row = Jbase + (long long)site * a.ldj;

@@ -74,7 +74,9 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     from spin_glass_anneal_rl_amd.engine import last_kernel
-    forms = [opts] if waves else [opts, {"clf_chain": 1}]   # (the opt-in chain-wave form on the same cases)
+    # the default takes one accept per round (sweep_clf_kernel); the opt-in forms -- several accepts per round
+    # (sweep_clfb_kernel), the chain wave (sweep_clfc_kernel) -- walk the same cases
+    forms = [opts, dict(opts, clf_batched=1)] + ([] if waves else [{"clf_chain": 1}])
     for form in forms:
         with sg.AnnealEngine(0) as e:
             e.set_options(form)
@@ -85,7 +87,8 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
             chain = bool(form.get("clf_chain")) and bool(J.any())   # (n = 1: no coupling at all, nothing to filter by)
-            assert last_kernel().startswith("sweep_clfc_kernel" if chain else "sweep_clf_kernel"), last_kernel()
+            want = "sweep_clfc_kernel" if chain else "sweep_clfb_kernel" if form.get("clf_batched") else "sweep_clf_kernel"
+            assert last_kernel().startswith(want), (want, last_kernel())
             check_against(e, ref, s, out)
 
 
@@ -154,7 +157,7 @@ def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(
     """Option clf_chain = 1: production arguments take the chain-wave form (csrc/sweep_clfc_impl.h): candidates that
     cannot accept within the window's flip budget K are dropped, the rest followed in registers by one wave.  Every
     budget -- 1 (a window ends at each accept), the default, 64 (the filter lets nearly everything through) -- and
-    the windowed form (the default) give the oracle's chain; small n: every site is proposed several times per window."""
+    the windowed form (the default) and its several-accepts-per-round variant give the oracle's chain; small n: every site is proposed several times per window."""
     from spin_glass_anneal_rl_amd.engine import last_kernel
     J = int_couplings(n, 7 * n, amp, density=0.8) if amp > 1 else pm1(n, 3 * n)
     h = np.random.RandomState(n).randint(-amp, amp + 1, n).astype(np.float32)
@@ -164,7 +167,7 @@ def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     assert ref["n_accepted"].max() > n // 2         # a hot end: several accepts per window there
-    for opts in ({"clf_chain": 1, "clf_flips": 1}, {"clf_chain": 1}, {"clf_chain": 1, "clf_flips": 64}, {}):
+    for opts in ({"clf_chain": 1, "clf_flips": 1}, {"clf_chain": 1}, {"clf_chain": 1, "clf_flips": 64}, {}, {"clf_batched": 1}):
         with sg.AnnealEngine(0) as e:
             e.set_options(opts)
             e.set_field_cache("on")
@@ -173,7 +176,8 @@ def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
             k = last_kernel()
-            assert k.startswith("sweep_clfc_kernel" if opts.get("clf_chain") else "sweep_clf_kernel"), k
+            assert k.startswith("sweep_clfc_kernel" if opts.get("clf_chain") else
+                                "sweep_clfb_kernel" if opts.get("clf_batched") else "sweep_clf_kernel"), k
             check_against(e, ref, s, out)
 
 
@@ -671,3 +675,44 @@ def test_cached_fields_over_csr_what_does_not_qualify(sg):
             e.set_field_cache("auto")
             e.sweep(2)
             assert "cached" not in e.describe() or "sweep=auto" not in e.describe(), (name, e.describe())
+
+
+
+@pytest.mark.parametrize("cache", ["on", "auto"])
+@pytest.mark.parametrize("form", [{}, {"clf_batched": 1}])
+def test_every_replica_gets_eight_waves_once_the_launch_is_one_replicas_chain(sg, cache, form):
+    """Option "clf_tail_waves" (default): a launch of the cached-field kernel ends with its hottest replica's chain; once
+    the mean acceptance is below 0.28 of the hottest replica's, every replica runs at eight waves (the workgroups
+    of the others are gone early anyway).  Same chain as with the option off and as the oracle's."""
+    from spin_glass_anneal_rl_amd.engine import last_kernel
+    n, R, seed, ns = 1600, 16, 0x807, 40
+    J = pm1(n, 77)
+    h = np.zeros(n, np.float32)
+    temps = ladder(R, 0.8 * np.sqrt(n), 0.002 * np.sqrt(n))   # a hot end; most of the ladder accepts next to nothing
+    prob = oracle.Problem(J=J, h=h)
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
+    acc = ref["n_accepted"] / ns
+    assert acc.max() > 24 and acc.mean() < 0.25 * acc.max(), acc
+    seen = {}
+    for tail in (1, 0):
+        with sg.AnnealEngine(0) as e:
+            e.set_options(dict(form, clf_tail_waves=tail))
+            e.set_field_cache(cache)
+            e.set_dense(J, h, storage="f32")
+            e.init_replicas(R, seed=seed)
+            e.set_temperatures(temps)
+            kernels = []
+            for _ in range(ns // 4):
+                e.sweep(4)
+                kernels.append(last_kernel())
+            assert np.array_equal(e.energies(), ref["energy"]) and np.array_equal(e.spins(), s)
+            assert np.array_equal(e.stats()[0], ref["n_accepted"])
+            tracked = e.energies()
+            e.recompute_energies()
+            assert np.array_equal(e.energies(), tracked)
+            seen[tail] = (kernels, e.describe())
+    kernels, desc = seen[1]
+    assert "x 8 wave" in kernels[-1] and ("now 8" in desc or "at 8 waves each" in desc), (kernels, desc)
+    assert "x 8 wave" not in kernels[0]
+    assert not any("x 8 wave" in k for k in seen[0][0]), seen[0][0]
