@@ -103,14 +103,16 @@ def test_cached_fields_int16_and_int32(sg, amp, n, bits, storage):
     temps = ladder(R, 40.0 * amp, 0.5 * amp)
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
-    with sg.AnnealEngine(0) as e:
-        e.set_field_cache("on")
-        e.set_dense(J, h, storage=storage)
-        e.init_replicas(R, seed=seed)
-        assert f"cached-local-fields(int{bits}" in e.describe(), e.describe()
-        e.set_temperatures(temps)
-        out = e.sweep(ns, energy_trace=True)
-        check_against(e, ref, s, out)
+    for form in ({}, {"clf_batched": 1}):          # one accept per round | several
+        with sg.AnnealEngine(0) as e:
+            e.set_options(form)
+            e.set_field_cache("on")
+            e.set_dense(J, h, storage=storage)
+            e.init_replicas(R, seed=seed)
+            assert f"cached-local-fields(int{bits}" in e.describe(), e.describe()
+            e.set_temperatures(temps)
+            out = e.sweep(ns, energy_trace=True)
+            check_against(e, ref, s, out)
 
 
 @pytest.mark.parametrize("amp,n,bits", [(2, 300, 16), (120, 700, 32)])
@@ -125,8 +127,9 @@ def test_cached_fields_with_half_integer_fields(sg, amp, n, bits):
     temps = ladder(R, 30.0 * amp, 0.4 * amp)
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=5)
-    for storage in ("f32", "i8"):
+    for storage, form in (("f32", {}), ("i8", {}), ("f32", {"clf_batched": 1}), ("i8", {"clf_batched": 1})):
         with sg.AnnealEngine(0) as e:
+            e.set_options(form)
             e.set_field_cache("on")
             e.set_dense(J, h, storage=storage)
             e.init_replicas(R, seed=seed)
@@ -475,17 +478,22 @@ def test_all_replica_field_pass_in_tiles(sg):
 def test_c2a_at_full_size_with_cached_fields(sg):
     """10 000-spin dense +-1 SK instance, 1024 replicas (bench.py's variant): the oracle follows
     replicas 0..2 (Philox streams are keyed by the global replica id); all replicas: tracked
-    energy == energy from scratch, and the row-per-proposal kernels give the same energies."""
+    energy == energy from scratch, and the row-per-proposal kernels give the same energies.  123 sweeps with exchange
+    rounds: the default form ends at eight waves per replica (the launch is its hottest replica's chain by then), the
+    several-accepts-per-round form at the standard waves walks the same chain."""
     import torch
     import bench
+    from spin_glass_anneal_rl_amd.engine import last_kernel
     n, R, seed, ns = 10000, 1024, 42, 3
     J = bench.make_sk_instance(n, 2, torch.device("cuda", 0))
     h = torch.zeros(n, device="cuda:0")
     temps = ladder(R, 10.0, 0.1)
-    res = {}
-    for cache in ("on", "off"):
+    res, long_run = {}, {}
+    for cache in ("on", "on-batched", "off"):
         with sg.AnnealEngine(0) as e:
-            e.set_field_cache(cache)
+            if cache == "on-batched":
+                e.set_options({"clf_batched": 1, "clf_tail_waves": 0})
+            e.set_field_cache(cache.split("-")[0])
             e.set_dense(J, h, storage="f32" if cache == "off" else "auto")
             e.init_replicas(R, seed=seed)
             e.set_ladder(temps)
@@ -494,25 +502,28 @@ def test_c2a_at_full_size_with_cached_fields(sg):
             e.recompute_energies()
             assert np.array_equal(e.energies(), tracked)
             res[cache] = (out["energy_trace"], e.spins()[:4].copy(), e.stats()[0])
-            if cache == "on":
-                # a longer run of the multi-wave form (4 waves per replica, two barriers per accept, ~10^7
-                # accepts in all): any ordering slip between the waves of a replica -- round 3 had one: the
-                # flipped spin read after the barrier by a slower wave -- leaves fields, spins and the
-                # tracked energy inconsistent
-                e.set_field_cache("on")
-                for _ in range(6):
+            if cache != "off":
+                # a longer run of the multi-wave forms (barriers between the waves of a replica, ~10^7 accepts in
+                # all): any ordering slip between the waves -- round 3 had one: the flipped spin read after the
+                # barrier by a slower wave -- leaves fields, spins and the tracked energy inconsistent
+                for _ in range(12):
                     e.sweep(10)
                     e.exchange(count=False)
                 tracked = e.energies()
                 e.recompute_energies()
                 assert np.array_equal(e.energies(), tracked)
+                long_run[cache] = (tracked, e.stats()[0], last_kernel(), e.describe())
                 e.set_field_cache("off")  # the row-per-proposal kernel continues from the same state
                 e.sweep(1)
                 tracked = e.energies()
                 e.recompute_energies()
                 assert np.array_equal(e.energies(), tracked)
-    assert np.array_equal(res["on"][0], res["off"][0])
-    assert np.array_equal(res["on"][1], res["off"][1]) and np.array_equal(res["on"][2], res["off"][2])
+    for cache in ("on", "on-batched"):
+        assert np.array_equal(res[cache][0], res["off"][0])
+        assert np.array_equal(res[cache][1], res["off"][1]) and np.array_equal(res[cache][2], res["off"][2])
+    assert np.array_equal(long_run["on"][0], long_run["on-batched"][0]) and np.array_equal(long_run["on"][1], long_run["on-batched"][1])
+    assert long_run["on"][2].startswith("sweep_clf_kernel") and "x 8 wave" in long_run["on"][2], long_run["on"][2:]
+    assert long_run["on-batched"][2].startswith("sweep_clfb_kernel") and "x 4 wave" in long_run["on-batched"][2]
     k = 3
     prob = oracle.Problem(J=J.cpu().numpy(), h=np.zeros(n, np.float32))
     oracle.set_exact_f32(True)
