@@ -114,6 +114,8 @@ def test_round4_headline_carries_the_other_configs_and_honest_roofs():
     cl = d["variants"]["cached_local_fields"]
     assert cl["tracked_energy_equals_recomputed"] is True and cl["value"] > 100 * d["value"]
     assert cl["after_100_sweeps"]["value"] > cl["after_100_sweeps"]["one_sweep_per_launch"]["value"] > cl["value"]
+    # ... and once the launch is its hottest replica's chain every replica runs at eight waves (option clf_tail_waves)
+    assert cl["after_100_sweeps"]["value"] >= 1.0e11 and "x 8 wave" in cl["kernel_instantiation"]
     # the all-gather of the one-rank RCCL line is timed on the device (events), the host share beside it
     f = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_c2a_f32_force_dist.json")))
     assert f["backend"] == "nccl" and f["exchange"]["rounds_timed"] >= 1
