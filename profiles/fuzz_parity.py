@@ -49,9 +49,13 @@ while time.time() < t_end:
     if kind == "csr" and rng.rand() < 0.5:
         env["SGA_FORCE_CSR_BIG"] = "1"
     # cached-local-field sweep (round 3): "auto" takes it wherever the problem allows, any waves per replica
-    cache = str(rng.choice(["off", "auto", "auto"]))
-    if cache == "auto" and rng.rand() < 0.6:
+    # (round 4: AUTO starts on the row kernels until it has seen the acceptance, so "on" is in the mix -- a problem that
+    #  does not qualify answers "cached local fields ..." and the case is skipped; the several-accepts-per-round form too)
+    cache = str(rng.choice(["off", "auto", "on", "on"]))
+    if cache != "off" and rng.rand() < 0.6:
         env["SGA_CLF_WAVES"] = str(rng.choice([1, 2, 3, 4, 8]))
+    if cache != "off" and rng.rand() < 0.5:
+        env["SGA_CLF_BATCHED"] = "1"
     if kind == "csr" and rng.rand() < 0.5:  # (unset: several updates per step wherever the form applies)
         env["SGA_CSR_PAIR_AHEAD"] = str(rng.choice([0, 1, 2, 4, 8]))
     seed = int(rng.randint(1, 1 << 30))
@@ -177,7 +181,7 @@ while time.time() < t_end:
                     n_fail += 1
                     print("MISMATCH batch", desc, "|", e.describe(), flush=True)
         except Exception as ex:
-            if not any(t in str(ex) for t in ("not integer", "ternary", "waves", "tuning")):
+            if not any(t in str(ex) for t in ("not integer", "ternary", "waves", "tuning", "cached local fields")):
                 n_fail += 1
                 print("ERROR batch", desc, "|", str(ex)[:200], flush=True)
         finally:
@@ -266,8 +270,8 @@ while time.time() < t_end:
                 print("MISMATCH", desc, f"autotuned={tuned} |", geom, "| inputs and both results in", dump, flush=True)
     except Exception as ex:
         msg = str(ex)
-        if "not integer" in msg or "ternary" in msg or "waves" in msg or "tuning" in msg:
-            pass  # an impossible request (e.g. t2 for non-ternary), not a parity failure
+        if "not integer" in msg or "ternary" in msg or "waves" in msg or "tuning" in msg or (cache == "on" and "cached local fields" in msg):
+            pass  # an impossible request (e.g. t2 for non-ternary, the field cache for real couplings), not a parity failure
         else:
             n_fail += 1
             print("ERROR", desc, "|", msg[:200], flush=True)
