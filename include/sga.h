@@ -337,10 +337,11 @@ int sga_set_field_cache(sga_engine *e, int mode);
  *                           acceptance is looked at every 4 ... 16 sweeps; once the mean is below 0.28 of the
  *                           hottest replica's -- the launch is that replica's chain, the chip idles behind it -- every
  *                           replica runs at eight waves.  Same chain                          [sweep; SGA_NO_CLF_TAIL_WAVES]
- *   "clf_batched"           0 (default) | 1   cached-field sweep under production arguments commits SEVERAL accepts per
+ *   "clf_batched"           2 (default) | 1 | 0   cached-field sweep under production arguments commits SEVERAL accepts per
  *                           round: all decisions of a window guessed at once, the guess checked against the couplings
- *                           between the accepting sites, the rows applied back to back (csrc/sweep_clfb_impl.h).
- *                           Same chain; ahead only while replicas accept more than ~2 %, hence opt-in [sweep; SGA_CLF_BATCHED]
+ *                           between the accepting sites, the rows applied two at a time (csrc/sweep_clfb_impl.h).  Same
+ *                           chain.  2 = while the hottest replica accepts more than ~1 % of its proposals (where the
+ *                           form is ahead), 1 = always, 0 = never                               [sweep; SGA_CLF_BATCHED]
  *   "clf_chain"             0 (default) | 1   cached-field sweep under production arguments in the chain-wave form: one
  *                           wave walks the chain over the few candidates that can accept within a window's flip
  *                           budget, three waves keep the field array up to date (csrc/sweep_clfc_impl.h).  Same

@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 J = bench.make_sk_instance(n, 2, dev)
 for waves in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]:
     with sg.AnnealEngine(0) as e:
-        e.set_option("clf_waves", waves)
+        e.set_options({"clf_batched": 1, "clf_tail_waves": 0, "clf_waves": waves})
         e.set_field_cache("on")
         e.set_dense(J, torch.zeros(n, device=dev), storage=os.environ.get("STORAGE", "auto"))
         e.init_replicas(R, seed=42)
@@ -43,4 +43,4 @@ for waves in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0").split(
                       f"{col[3] / sw:.1f} listed/round {col[4] / max(col[1], 1):.1f} lookers/round (wave 0) {col[5] / max(col[1], 1):.1f} | us/sweep: "
                       f"total {us(col[10]):.1f} = table {us(col[11]):.1f} + draw {us(col[9]):.1f} + guess {us(col[6]):.1f} + check "
                       f"{us(col[7]):.1f} + apply {us(col[8]):.1f} || guess before barrier {us(col[12]):.1f}; check: list {us(col[13]):.1f}, "
-                      f"through pairs {us(col[14]):.1f}, through publish {us(col[15]):.1f}; apply: commit {us(col[16]):.1f}, through rows {us(col[17]):.1f}", flush=True)
+                      f"through pairs {us(col[14]):.1f}, through publish {us(col[15]):.1f} (last wave: {us(col[19]):.1f}, lookers/round {col[18] / max(col[1], 1):.1f}); apply: commit {us(col[16]):.1f}, through rows {us(col[17]):.1f}", flush=True)

@@ -22,7 +22,7 @@ h = torch.zeros(n, device=dev)
 waves = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 t_hot, t_cold = float(os.environ.get("T_HOT", 10.0)), float(os.environ.get("T_COLD", 0.1))
 storage = os.environ.get("STORAGE", "auto")
-variants = [("one per round", {"clf_batched": 0, "clf_tail_waves": 0}), ("+ 8 waves in the tail", {"clf_batched": 0})] + [(f"batched w={w}", {"clf_batched": 1, "clf_waves": w}) for w in waves if 0 <= w <= 16] + \
+variants = [("one per round", {"clf_batched": 0, "clf_tail_waves": 0}), ("+ 8 waves in the tail", {"clf_batched": 0}), ("default", {})] + [(f"batched w={w}", {"clf_batched": 1, "clf_waves": w, "clf_tail_waves": 0}) for w in waves if 0 <= w <= 16] + \
            [(f"one/round w={-w}", {"clf_batched": 0, "clf_waves": -w}) for w in waves if -16 <= w < 0]
 ref = None
 for name, opts in variants:

@@ -60,7 +60,7 @@ constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"clf_flips", "SGA_CLF_FLIPS", 0, 0, 12, 1, 64},
     {"replica_routing", "SGA_NO_REPLICA_ROUTING", 1, 0, 1, 0, 1},
     {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536},
-    {"clf_batched", "SGA_CLF_BATCHED", 1, 1, 0, 0, 1},
+    {"clf_batched", "SGA_CLF_BATCHED", 0, 0, 2, 0, 2},
     {"clf_tail_waves", "SGA_NO_CLF_TAIL_WAVES", 1, 0, 1, 0, 1},
 };
 int find_option(const char *key) {
@@ -237,6 +237,7 @@ struct sga_engine {
     std::vector<int> route;             // per local replica: 0 = cached-field kernel, 1 = row-per-proposal kernel (AUTO)
     int n_route_clf = 0;                // replicas routed to the cached-field kernel
     bool clf_wide = false;              // the cached-field launch runs at eight waves per replica (option "clf_tail_waves")
+    bool clf_hot = true;                // its hottest replica accepts > ~1 %: several accepts per round (option "clf_batched" = 2)
     bool route_dirty = true;            // the device copy of the replica lists is stale
     int *d_rep_lists = nullptr;         // [2][R]: the cached-field kernel's replicas, then the row kernels'
     hipStream_t aux_stream = nullptr;   // the second launch of a mixed sweep
@@ -329,6 +330,7 @@ struct sga_engine {
         route.clear();
         n_route_clf = 0;
         clf_wide = false;
+        clf_hot = true;
         route_dirty = true;
         dev_free(d_rep_lists);
         auto_mark_attempted = 0;
@@ -1936,7 +1938,11 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     const int clf_waves_std = (clf && !e->csr) ? sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]) : 0;
     const bool tail_opt = clf && !e->csr && e->opt[OPT_CLF_TAIL_WAVES] != 0 && e->opt[OPT_CLF_WAVES] == 0 && e->opt[OPT_CLF_CHAIN] == 0 &&
                          clf_waves_std < 8 && e->ldj >= 6 * (e->want_i8 ? 1024 : 256) && e->R >= 16;
-    if (clf && (is_auto || tail_opt)) {
+    // Option "clf_batched" = 2 (default): the form that commits several accepts per round (sweep_clfb_impl.h) while the
+    // hottest replica accepts more than ~1 % of its proposals -- 16 % ahead on the first sweeps from random spins, 10 %
+    // at sweeps 5-25 of the 10 000-spin ladder -- and one accept per round below (7 % ahead after 100 sweeps).
+    const bool adaptive = clf && !e->csr && e->opt[OPT_CLF_BATCHED] == 2 && e->opt[OPT_CLF_CHAIN] == 0;
+    if (clf && (is_auto || tail_opt || adaptive)) {
         if (is_auto && e->auto_unavailable) {
             n_clf = 0;
         } else {
@@ -1946,6 +1952,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                 e->route.assign((size_t)e->R, is_auto ? 1 : 0);
                 e->n_route_clf = is_auto ? 0 : e->R;
                 e->clf_wide = false;
+                e->clf_hot = true;   // (nothing known yet: a run starts hot)
                 e->auto_mark_attempted = 0;
                 e->auto_interval = 4;
             }
@@ -1991,7 +1998,14 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                     for (int v : e->route) cnt += v == 0;
                     e->n_route_clf = cnt;
                     e->clf_wide = false;
-                    if (tail_opt && cnt > 0) {
+                    if (adaptive && cnt > 0) {  // (hysteresis: in above 1.5 % of the hottest replica's proposals, out below 1 %)
+                        unsigned long long top = 0;
+                        for (int r2 = 0; r2 < e->R; ++r2)
+                            if (e->route[(size_t)r2] == 0) top = std::max(top, now[(size_t)r2] - e->auto_mark_acc[(size_t)r2]);
+                        const double hottest = (double)top / (double)since;
+                        e->clf_hot = hottest > (e->clf_hot ? 0.010 : 0.015);
+                    }
+                    if (tail_opt && cnt > 0 && !(adaptive && e->clf_hot)) {
                         // accepts per sweep of the replicas on the cached-field kernel: the hottest one's, and the mean
                         const double per_sweep = (double)n / (double)since;  // counter difference -> accepts per sweep
                         double amax = 0.0, asum = 0.0;
@@ -2190,9 +2204,10 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             const bool chain = e->opt[OPT_CLF_WAVES] == 0 && sga::sweep_clfc_applies(ac);
             // option "clf_batched": production arguments commit several accepts per round -- every decision of a
             // super-window guessed at once, the guess checked against the few couplings between the accepting sites
-            // (sweep_clfb_impl.h); the same chain.  Measured ahead only while replicas accept more than ~2 % (hot first
-            // sweeps 2.19 -> 1.90 ms), behind after 100 sweeps (0.106 -> 0.123): opt-in (profiles/r04_experiments.md 9)
-            ac.clf_batched = (int)e->opt[OPT_CLF_BATCHED];
+            // (sweep_clfb_impl.h); the same chain.  Ahead while the hottest replica accepts more than ~1 % (first sweeps
+            // from random spins 2.19 -> 1.84 ms, sweeps 5-25 0.272 -> 0.246), behind after 100 sweeps (0.105 -> 0.113):
+            // 2 = by the hottest replica's acceptance (default), 1 = always, 0 = never (profiles/r04_experiments.md 9)
+            ac.clf_batched = (e->opt[OPT_CLF_BATCHED] == 1 || (adaptive && e->clf_hot)) ? 1 : 0;
             const bool batched = !chain && sga::sweep_clfb_applies(ac, e->want_i8);
             auto launch_cached = [&](const sga::SweepArgs &aa, hipStream_t s2) -> hipError_t {
                 return chain     ? sga::launch_sweep_clfc(aa, e->want_i8, s2)

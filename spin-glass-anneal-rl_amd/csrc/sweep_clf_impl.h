@@ -167,6 +167,31 @@ __device__ __forceinline__ void clf_fields_update(ClfFields<JT, FT> &f, const VE
         }
     }
 }
+// ... the same update with the sign taken from mult at run time (several rows into one set of fields): int8 couplings
+// into int16 pairs as one packed multiply-add per pair (v_perm_b32 puts a coupling into the high byte of each half,
+// one packed arithmetic shift right by 8 sign-extends it, v_pk_mad_i16 adds mult times it); the other types
+// multiply by mult anyway
+template <typename JT, typename FT, typename VEC>
+__device__ __forceinline__ void clf_fields_update_signed(ClfFields<JT, FT> &f, const VEC &x, int mult, int sc) {
+    if constexpr (sizeof(JT) == 1 && sizeof(FT) == 2) {
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        const short2v sh8 = {8, 8};
+        const int mm = (mult & 0xFFFF) | (mult << 16);  // mult in both halves
+        const int wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned int t01 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x050c040cu);
+            const unsigned int t23 = __builtin_amdgcn_perm((unsigned int)wds[d], 0u, 0x070c060cu);
+            const int v01 = __builtin_bit_cast(int, __builtin_bit_cast(short2v, t01) >> sh8);
+            const int v23 = __builtin_bit_cast(int, __builtin_bit_cast(short2v, t23) >> sh8);
+            // (the compiler splits a v2i16 multiply-add into v_pk_mul_lo_u16 + v_pk_add_u16)
+            asm("v_pk_mad_i16 %0, %1, %2, %0" : "+v"(f.v[2 * d]) : "v"(v01), "s"(mm));
+            asm("v_pk_mad_i16 %0, %1, %2, %0" : "+v"(f.v[2 * d + 1]) : "v"(v23), "s"(mm));
+        }
+    } else {
+        clf_fields_update<JT, FT, false>(f, x, mult, sc);  // (these forms do not look at NEG)
+    }
+}
 template <typename JT, typename FT, bool NEG, typename VEC>
 __device__ __forceinline__ void clf_apply_chunk(FT *F, const VEC &x, long long j0, int mult, int sc) {
     ClfFields<JT, FT> f = clf_fields_load<JT, FT>(F, j0);

@@ -9,8 +9,8 @@
 //
 // Here a round GUESSES all decisions of the super-window at once and checks the guess:
 //   1. every wave evaluates its 128 updates against the state in LDS and publishes, in chain order, the candidates
-//      that flip (position, site, spin) -- the guess; up to CLFB_LIST of them make the round's batch.  Their rows are
-//      asked for at once (loads that write a scrap of LDS: they only bring the rows into the L2);
+//      that flip (position, site, spin) -- the guess; up to CLFB_LIST of them make the round's batch.  The rows of the
+//      first two are requested at once (registers): they travel during the check;
 //   2. the guess is exact for every update up to and including the first accept.  Behind an accept a candidate's
 //      k = s_i F_i has moved by  -2 scale s_a s_i J[a][i]  for each accepted a before it -- by at most m D behind m
 //      accepts (D = 2 scale max|J|), so with an accept table that does not increase anywhere "u >= p(k - m D)"
@@ -22,9 +22,10 @@
 //      accept of its own site: the list carries its old spin) ends the batch: everything before it IS the chain --
 //      a decision depends on earlier decisions only, and those agree with the guess there -- and that position's
 //      own second decision is exact too.  Without such a position the whole batch stands;
-//   4. the rows of all committed accepts are applied back to back (each wave to its own chunks of the field
-//      array: no barrier between rows, the next row in flight while one is applied), the spins flipped, and the
-//      walk continues behind the last decided update.
+//   4. the rows of all committed accepts are applied two at a time (each wave to its own chunks of the field array,
+//      no barrier in between: the fields of a chunk are read once, both rows' shares added in registers -- one
+//      v_pk_mad_i16 per pair of int16 fields and row --, written once), the spins flipped, and the walk continues
+//      behind the last decided update.
 // A round commits at least its first accept (the old round), typically three or four for the hottest replica of a
 // ladder and the whole window for the cold ones.  Energies: dE = 2 k / scale of every committed accept is an integer
 // or half-integer below 2^40, so their sum per sweep, formed once at the sweep's end, is the value the
@@ -40,13 +41,12 @@ namespace sga {
 
 constexpr int CLFB_LIST = 16;  // accepts one round commits at most
 constexpr int CLFB_PASS = 3;   // candidates of either stream (even / odd updates) whose couplings are gathered together
-constexpr int CLFB_PREF = 0;   // guessed accepts per candidate stream whose rows a wave touches ahead (0: measured a loss --
-                               // the touched lines cross the CU's fetch path twice, profiles/r04_experiments.md 9)
+constexpr int CLFB_ROWS = 2;   // rows of a batch applied together: a wave reads its fields once for both
 
 // LDS behind the accept table: list [2][64] int2 | count [2][8] int | over [2][8] int | check [8] int4 | sums [2] u64 |
-// scrap [8][64] bytes (where the look-ahead loads land) | three bitmaps of sstride bits: sites proposed in this
+// three bitmaps of sstride bits: sites proposed in this
 // super-window (seen), proposed more than once (twice), and those of the latter accepted by this round's guess (accb)
-constexpr int CLFB_FIXED_BYTES = 2 * 64 * 8 + 2 * CLF_MAX_WAVES * 4 + 2 * CLF_MAX_WAVES * 4 + CLF_MAX_WAVES * 16 + 16 + CLF_MAX_WAVES * 64;
+constexpr int CLFB_FIXED_BYTES = 2 * 64 * 8 + 2 * CLF_MAX_WAVES * 4 + 2 * CLF_MAX_WAVES * 4 + CLF_MAX_WAVES * 16 + 16;
 inline size_t clfb_lds_bytes(long long ldf, int fbytes, int sstride, int table_m) {
     return (size_t)clf_table_offset(ldf, fbytes, sstride) + sizeof(float) * (size_t)((table_m + 4) & ~3) + CLFB_FIXED_BYTES +
            3 * (size_t)(sstride / 8);
@@ -54,14 +54,11 @@ inline size_t clfb_lds_bytes(long long ldf, int fbytes, int sstride, int table_m
 
 // workgroup barrier for LDS traffic only: global loads stay in flight across it
 __device__ __forceinline__ void clfb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// one byte per lane global -> LDS scrap, no register: brings the lines into the L2 ahead of their use
-__device__ __forceinline__ void clfb_touch(const unsigned char *g, unsigned char *scrap) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)scrap,
-                                     1, 0, 0);
-}
-
+// (four waves per SIMD = every replica of a 1024-replica launch resident at four waves per replica: the short-row builds
+//  are held to 128 registers; the long-row build keeps what it needs)
 template <typename JT, typename FT, int CLF_BATCH = CLF_BATCH_MAX, bool TAIL = true>
-__global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const SweepArgs a) {
+__global__ void __launch_bounds__(64 * CLF_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(TAIL ? 1 : 4)))
+sweep_clfb_kernel(const SweepArgs a) {
     constexpr int EPL = 16 / (int)sizeof(JT), EPC = 64 * EPL;  // elements per lane / per 1-KiB chunk
     constexpr int FB = (int)sizeof(FT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -73,8 +70,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
     int *over2 = count2 + 2 * CLF_MAX_WAVES;
     int4 *check = reinterpret_cast<int4 *>(over2 + 2 * CLF_MAX_WAVES);
     unsigned long long *sums = reinterpret_cast<unsigned long long *>(check + CLF_MAX_WAVES);
-    unsigned char *scrap = reinterpret_cast<unsigned char *>(sums + 2);
-    unsigned int *seen = reinterpret_cast<unsigned int *>(scrap + CLF_MAX_WAVES * 64);
+    unsigned int *seen = reinterpret_cast<unsigned int *>(sums + 2);
     unsigned int *twice = seen + a.sstride / 32;
     unsigned int *accb = twice + a.sstride / 32;
 
@@ -118,6 +114,46 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
         req_off[q] = (unsigned int)((j0 < a.ldj ? j0 : 0) * (long long)sizeof(JT));
     }
     const unsigned int pitch = (unsigned int)(a.ldj * (long long)sizeof(JT));
+    // chunks of this wave's first batch that exist at all (wave-uniform), and one chunk of one row
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < CLF_BATCH; ++q)
+        if ((long long)(w + q * W) * EPC < a.ldj) nq = q + 1;
+    auto chunk_load = [&](int site, int q) -> vec_t {
+        const unsigned char *row = Jbytes + (unsigned long long)(unsigned int)site * pitch;  // wave-uniform
+        unsigned int off = req_off[q];
+        asm volatile("" : "+v"(off));  // (kept 32-bit: scalar row base + one offset register per load)
+#ifdef CLFB_NOLOAD
+        vec_t o{};
+        asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w) : "s"(row));
+        return o;
+#else
+        return *reinterpret_cast<const vec_t *>(row + off);
+#endif
+    };
+    // Up to CLFB_ROWS rows into the wave's fields, chunk by chunk: the fields of a chunk are read once, every row's
+    // share added in registers, written once.  buf holds the rows' chunks on entry where `preloaded` (the first
+    // two listed accepts, requested during the check); later pairs of rows are requested here, all chunks at once.
+    auto apply_rows = [&](auto kc, vec_t (&buf)[CLFB_ROWS][CLF_BATCH], const int (&sites)[CLFB_ROWS], const int (&mults)[CLFB_ROWS],
+                          bool preloaded) {
+        constexpr int K = decltype(kc)::value;
+        if (!preloaded) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int q = 0; q < CLF_BATCH; ++q) buf[k][q] = chunk_load(sites[k], q);
+        }
+#pragma unroll
+        for (int q = 0; q < CLF_BATCH; ++q) {
+            const long long j0 = elem0(w + q * W);
+            if (q < nq && j0 < a.ldj) {
+                ClfFields<JT, FT> f = clf_fields_load<JT, FT>(F, j0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) clf_fields_update_signed<JT, FT>(f, buf[k][q], mults[k], sc);
+                clf_fields_store<JT, FT>(F, j0, f);
+            }
+        }
+    };
     auto row_request = [&](int site) -> RowRegs {
         RowRegs o;
         const unsigned char *row = Jbytes + (unsigned long long)(unsigned int)site * pitch;  // wave-uniform
@@ -175,16 +211,6 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
         if (mult < 0) apply_row_signed(rr, site, mult, std::true_type{});  // wave-uniform
         else apply_row_signed(rr, site, mult, std::false_type{});
     };
-    // the row of a guessed accept, asked for as soon as the guess is known: lane l touches the 128-byte line
-    // l (+ 64, 128, 192) of the row, the bytes land in this wave's scrap of LDS and are never read
-    unsigned char *my_scrap = scrap + w * 64;
-    auto touch_row = [&](int site) {
-        const unsigned char *row = Jbytes + (unsigned long long)(unsigned int)site * pitch;  // wave-uniform
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if ((unsigned int)q * 8192u < pitch) clfb_touch(row + min((unsigned int)(q * 64 + lane) * 128u, pitch - 1u), my_scrap);
-    };
-
     // does a move with k = s_i F_i flip?  Both candidates of a lane at once (their table reads travel together);
     // the table covers k <= table_m (entry 0 = 1 serves every downhill move), the few moves beyond it are evaluated
     // behind a wave-uniform test -- the same function of the same arguments as sweep_clf_kernel's
@@ -312,13 +338,6 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
                     if (gsB && rB == S) over[w] = gB;
                     if (gsA && dupA) atomicOr(&accb[sA >> 5], bitA);
                     if (gsB && dupB) atomicOr(&accb[sB >> 5], bitB);
-                    unsigned long long pA = mA, pB = mB;
-#pragma unroll
-                    for (int j = 0; j < CLFB_PREF; ++j) {
-                        if (pA) touch_row(__builtin_amdgcn_readlane(sA, (int)__builtin_ctzll(pA)));
-                        if (pB) touch_row(__builtin_amdgcn_readlane(sB, (int)__builtin_ctzll(pB)));
-                        pA &= pA - 1ull, pB &= pB - 1ull;
-                    }
                 }
                 if (lane == 0) {
                     count[w] = cw;
@@ -354,7 +373,8 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
                 const unsigned long long vm2 = vmL & (vmL - 1ull);
                 const int early1 = __builtin_amdgcn_readlane(ent_site, (int)__builtin_ctzll(vm));
                 const int early2 = vm2 ? __builtin_amdgcn_readlane(ent_site, (int)__builtin_ctzll(vm2)) : early1;
-                RowRegs cur, nxt;
+                [[maybe_unused]] RowRegs cur, nxt;
+                vec_t rowbuf[CLFB_ROWS][CLF_BATCH];  // (the rows of the first two listed accepts travel during the check)
                 [[maybe_unused]] const long long tick1a = CLFB_TICK();
                 CLFB_ADD(13, tick1a - tick1);
                 // 3. the check
@@ -398,7 +418,14 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
                             }
                         }
                         if (first_pass) {
-                            cur = row_request(early1), nxt = row_request(early2);
+                            if constexpr (TAIL) {
+                                cur = row_request(early1), nxt = row_request(early2);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < CLF_BATCH; ++q) rowbuf[0][q] = chunk_load(early1, q);
+#pragma unroll
+                                for (int q = 0; q < CLF_BATCH; ++q) rowbuf[1][q] = chunk_load(early2, q);
+                            }
                             first_pass = false;
                         }
 #pragma unroll
@@ -477,6 +504,36 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
                     }
                 };
                 CLFB_ADD(16, CLFB_TICK() - tick2);
+                if constexpr (!TAIL) {
+                    // The committed rows in order (the guessed accepts before Q in slot order, then the checked position):
+                    // lane j of `tab` holds row j's site and spin.  Row j < napply IS the j-th listed accept, so the first
+                    // pass -- rows 0 .. min(2, napply) - 1 -- finds its rows already requested during the check.
+                    const int napply = (int)__popcll(rows);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(rows >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)rows, 0u));
+                    int tab = __builtin_amdgcn_ds_permute((mine_row ? rank : 63) << 2, ent.y);
+                    if (lane == napply && xacc) tab = xsite | (xsi < 0 ? (int)0x80000000 : 0);
+                    int sites[CLFB_ROWS], mults[CLFB_ROWS];
+                    auto take = [&](int r0, int k) {
+#pragma unroll
+                        for (int j = 0; j < CLFB_ROWS; ++j) {
+                            const int ey = __builtin_amdgcn_readlane(tab, r0 + (j < k ? j : 0));
+                            sites[j] = ey & 0x7fffffff, mults[j] = ey < 0 ? 2 * sc : -2 * sc;
+                        }
+                    };
+                    auto run = [&](int k, bool preloaded) {  // wave-uniform
+                        if (k == 1) apply_rows(std::integral_constant<int, 1>{}, rowbuf, sites, mults, preloaded);
+                        else apply_rows(std::integral_constant<int, 2>{}, rowbuf, sites, mults, preloaded);
+                    };
+                    int done = min(CLFB_ROWS, napply);
+                    take(0, done);
+                    run(done, true);
+                    while (done < nrows) {
+                        const int k = min(CLFB_ROWS, nrows - done);
+                        take(done, k);
+                        run(k, false);
+                        done += k;
+                    }
+                } else
                 {   // The two row buffers take turns: step 0 applies the first accept's row (cur), step 1 the second
                     // listed accept's (nxt) -- both asked for during the check --, step i + 2 the row asked for as soon
                     // as step i's buffer was free.  Every step asks for exactly one row (past the last: the current one
@@ -550,9 +607,15 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clfb_kernel(const Sw
 #ifdef CLFB_PROFILE
         prof[10] = wall_clock64() - prof_t0;
         if (a.energy_trace && a.n_sweeps >= 20)
-            for (int i = 0; i < 20; ++i) a.energy_trace[(long long)i * a.R + r] = (double)prof[i];
+            for (int i = 0; i < 18; ++i) a.energy_trace[(long long)i * a.R + r] = (double)prof[i];
 #endif
     }
+#ifdef CLFB_PROFILE
+    if (tid == 64 * (W - 1) && a.energy_trace && a.n_sweeps >= 20) {  // the last wave's view: who looked, how long its check took
+        a.energy_trace[18ll * a.R + r] = (double)prof[5];
+        a.energy_trace[19ll * a.R + r] = (double)prof[15];
+    }
+#endif
 #undef CLFB_TICK
 #undef CLFB_ADD
 }

@@ -36,7 +36,7 @@ def test_plain_c_program_runs_the_engine(tmp_path):
     p = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith("OK version="), (p.returncode, p.stdout, p.stderr)
     # ... and the same run through sga_set_field_cache(ON): identical energies, the kernel it launched
-    assert "OK cached-fields" in p.stdout and "kernel=sweep_clf_kernel" in p.stdout, p.stdout
+    assert "OK cached-fields" in p.stdout and "kernel=sweep_clf" in p.stdout, p.stdout
 
 
 def test_csr_storage_codes_agree_between_header_and_host():

@@ -74,9 +74,9 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     from spin_glass_anneal_rl_amd.engine import last_kernel
-    # the default takes one accept per round (sweep_clf_kernel); the opt-in forms -- several accepts per round
-    # (sweep_clfb_kernel), the chain wave (sweep_clfc_kernel) -- walk the same cases
-    forms = [opts, dict(opts, clf_batched=1)] + ([] if waves else [{"clf_chain": 1}])
+    # one accept per round (sweep_clf_kernel), several (sweep_clfb_kernel: what the default -- clf_batched = 2, by the
+    # hottest replica's acceptance -- starts a run with), and the opt-in chain wave (sweep_clfc_kernel) walk the same cases
+    forms = [dict(opts, clf_batched=0), dict(opts, clf_batched=1), opts] + ([] if waves else [{"clf_chain": 1}])
     for form in forms:
         with sg.AnnealEngine(0) as e:
             e.set_options(form)
@@ -87,7 +87,9 @@ def test_cached_field_sweeps_match_oracle(sg, n, R, storage, waves):
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
             chain = bool(form.get("clf_chain")) and bool(J.any())   # (n = 1: no coupling at all, nothing to filter by)
-            want = "sweep_clfc_kernel" if chain else "sweep_clfb_kernel" if form.get("clf_batched") else "sweep_clf_kernel"
+            # (the default picks by the hottest replica's acceptance: either windowed form)
+            want = ("sweep_clfc_kernel" if chain else "sweep_clf" if "clf_batched" not in form else
+                    "sweep_clfb_kernel" if form["clf_batched"] else "sweep_clf_kernel")
             assert last_kernel().startswith(want), (want, last_kernel())
             check_against(e, ref, s, out)
 
@@ -103,7 +105,7 @@ def test_cached_fields_int16_and_int32(sg, amp, n, bits, storage):
     temps = ladder(R, 40.0 * amp, 0.5 * amp)
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=6)
-    for form in ({}, {"clf_batched": 1}):          # one accept per round | several
+    for form in ({"clf_batched": 0}, {"clf_batched": 1}):          # one accept per round | several
         with sg.AnnealEngine(0) as e:
             e.set_options(form)
             e.set_field_cache("on")
@@ -127,7 +129,7 @@ def test_cached_fields_with_half_integer_fields(sg, amp, n, bits):
     temps = ladder(R, 30.0 * amp, 0.4 * amp)
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, trace=True, n_threads=5)
-    for storage, form in (("f32", {}), ("i8", {}), ("f32", {"clf_batched": 1}), ("i8", {"clf_batched": 1})):
+    for storage, form in (("f32", {"clf_batched": 0}), ("i8", {"clf_batched": 0}), ("f32", {"clf_batched": 1}), ("i8", {"clf_batched": 1})):
         with sg.AnnealEngine(0) as e:
             e.set_options(form)
             e.set_field_cache("on")
@@ -170,7 +172,7 @@ def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(
     s = oracle.init_spins(n, R, seed)
     ref = oracle.sweeps(prob, s, temps, ns, seed=seed, n_threads=8)
     assert ref["n_accepted"].max() > n // 2         # a hot end: several accepts per window there
-    for opts in ({"clf_chain": 1, "clf_flips": 1}, {"clf_chain": 1}, {"clf_chain": 1, "clf_flips": 64}, {}, {"clf_batched": 1}):
+    for opts in ({"clf_chain": 1, "clf_flips": 1}, {"clf_chain": 1}, {"clf_chain": 1, "clf_flips": 64}, {}, {"clf_batched": 0}, {"clf_batched": 1}):
         with sg.AnnealEngine(0) as e:
             e.set_options(opts)
             e.set_field_cache("on")
@@ -179,8 +181,8 @@ def test_chain_wave_form_flip_budgets_and_the_windowed_form_walk_the_same_chain(
             e.set_temperatures(temps)
             out = e.sweep(ns, energy_trace=True)
             k = last_kernel()
-            assert k.startswith("sweep_clfc_kernel" if opts.get("clf_chain") else
-                                "sweep_clfb_kernel" if opts.get("clf_batched") else "sweep_clf_kernel"), k
+            assert k.startswith("sweep_clfc_kernel" if opts.get("clf_chain") else "sweep_clf" if "clf_batched" not in opts else
+                                "sweep_clfb_kernel" if opts["clf_batched"] else "sweep_clf_kernel"), k
             check_against(e, ref, s, out)
 
 
@@ -400,12 +402,13 @@ def test_auto_routes_every_replica_by_its_own_acceptance(sg):
             assert np.array_equal(runs[name, cache][5], runs[name, "off"][5]), (name, cache)
         assert set(runs[name, "off"][2]) == {"sweep_dense_kernel"}
     assert runs["cold", "auto"][2][0] == "sweep_dense_kernel"          # until the acceptance is known
-    assert runs["cold", "auto"][2][-1] == "sweep_clf_kernel" and f"now: {R} of {R} replica(s) cached" in runs["cold", "auto"][3]
+    # (either windowed form: several accepts per round while the hottest replica still accepts more than 1 %)
+    assert runs["cold", "auto"][2][-1] in ("sweep_clf_kernel", "sweep_clfb_kernel") and f"now: {R} of {R} replica(s) cached" in runs["cold", "auto"][3]
     assert set(runs["hot", "auto"][2]) == {"sweep_dense_kernel"} and f"now: 0 of {R} replica(s)" in runs["hot", "auto"][3]
     # the ladder with a hot end: both kernels in one sweep call, each on its own replicas
     assert runs["mixed", "auto"][2][-1] == "mixed", runs["mixed", "auto"][2]
     last = runs["mixed", "auto"][4]
-    assert "sweep_clf_kernel" in last and "sweep_dense_kernel" in last and "||" in last, last
+    assert "sweep_clf" in last and "sweep_dense_kernel" in last and "||" in last, last
     import re
     m = re.search(r"now: (\d+) of", runs["mixed", "auto"][3])
     assert m and 0 < int(m.group(1)) < R, runs["mixed", "auto"][3]
@@ -447,7 +450,7 @@ def test_field_cache_request_after_a_sparse_matrix_was_taken_as_csr(sg):
             e.init_replicas(4, seed=1)
             e.set_temperatures(temps * (9000.0 if big else 1.0))
             e.sweep(5)
-            assert "sweep=cached-local-fields(int" in e.describe() and last_kernel().startswith("sweep_clf_kernel")
+            assert "sweep=cached-local-fields(int" in e.describe() and last_kernel().startswith("sweep_clf")
             if not big:
                 assert np.array_equal(e.energies(), as_csr[0]) and np.array_equal(e.spins(), as_csr[1])
 
@@ -480,7 +483,9 @@ def test_c2a_at_full_size_with_cached_fields(sg):
     replicas 0..2 (Philox streams are keyed by the global replica id); all replicas: tracked
     energy == energy from scratch, and the row-per-proposal kernels give the same energies.  123 sweeps with exchange
     rounds: the default form ends at eight waves per replica (the launch is its hottest replica's chain by then), the
-    several-accepts-per-round form at the standard waves walks the same chain."""
+    several-accepts-per-round form at the standard waves walks the same chain.  The default (clf_batched = 2) starts on
+    the several-accepts form -- from random spins every replica accepts several per cent -- and leaves it once the
+    hottest replica accepts less than 1 %."""
     import torch
     import bench
     from spin_glass_anneal_rl_amd.engine import last_kernel
@@ -498,6 +503,7 @@ def test_c2a_at_full_size_with_cached_fields(sg):
             e.init_replicas(R, seed=seed)
             e.set_ladder(temps)
             out = e.sweep(ns, energy_trace=True)
+            first_kernel = last_kernel()
             tracked = e.energies()
             e.recompute_energies()
             assert np.array_equal(e.energies(), tracked)
@@ -512,7 +518,7 @@ def test_c2a_at_full_size_with_cached_fields(sg):
                 tracked = e.energies()
                 e.recompute_energies()
                 assert np.array_equal(e.energies(), tracked)
-                long_run[cache] = (tracked, e.stats()[0], last_kernel(), e.describe())
+                long_run[cache] = (tracked, e.stats()[0], last_kernel(), e.describe(), first_kernel)
                 e.set_field_cache("off")  # the row-per-proposal kernel continues from the same state
                 e.sweep(1)
                 tracked = e.energies()
@@ -522,6 +528,7 @@ def test_c2a_at_full_size_with_cached_fields(sg):
         assert np.array_equal(res[cache][0], res["off"][0])
         assert np.array_equal(res[cache][1], res["off"][1]) and np.array_equal(res[cache][2], res["off"][2])
     assert np.array_equal(long_run["on"][0], long_run["on-batched"][0]) and np.array_equal(long_run["on"][1], long_run["on-batched"][1])
+    assert long_run["on"][4].startswith("sweep_clfb_kernel"), long_run["on"][4]
     assert long_run["on"][2].startswith("sweep_clf_kernel") and "x 8 wave" in long_run["on"][2], long_run["on"][2:]
     assert long_run["on-batched"][2].startswith("sweep_clfb_kernel") and "x 4 wave" in long_run["on-batched"][2]
     k = 3
@@ -690,7 +697,7 @@ def test_cached_fields_over_csr_what_does_not_qualify(sg):
 
 
 @pytest.mark.parametrize("cache", ["on", "auto"])
-@pytest.mark.parametrize("form", [{}, {"clf_batched": 1}])
+@pytest.mark.parametrize("form", [{"clf_batched": 0}, {"clf_batched": 1}])
 def test_every_replica_gets_eight_waves_once_the_launch_is_one_replicas_chain(sg, cache, form):
     """Option "clf_tail_waves" (default): a launch of the cached-field kernel ends with its hottest replica's chain; once
     the mean acceptance is below 0.28 of the hottest replica's, every replica runs at eight waves (the workgroups
