@@ -39,8 +39,14 @@
 
 namespace sga {
 
-constexpr int CLFB_LIST = 16;  // accepts one round commits at most
-constexpr int CLFB_PASS = 3;   // candidates of either stream (even / odd updates) whose couplings are gathered together
+#ifndef CLFB_LIST_N  // (A/B builds: profiles/build_variant.sh)
+#define CLFB_LIST_N 8  // (4: 0.259 ms at sweeps 5-25 and 1.88 on the first, hot sweeps; 6 ... 12: 0.244 and 1.73; 16: 0.247 / 1.85; 32: 0.249 / 2.29)
+#endif
+#ifndef CLFB_PASS_N
+#define CLFB_PASS_N 3
+#endif
+constexpr int CLFB_LIST = CLFB_LIST_N;  // accepts one round commits at most
+constexpr int CLFB_PASS = CLFB_PASS_N;  // candidates of either stream (even / odd updates) whose couplings are gathered together
 constexpr int CLFB_ROWS = 2;   // rows of a batch applied together: a wave reads its fields once for both
 
 // LDS behind the accept table: list [2][64] int2 | count [2][8] int | over [2][8] int | check [8] int4 | sums [2] u64 |
