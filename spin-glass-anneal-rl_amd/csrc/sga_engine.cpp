@@ -2205,7 +2205,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             // option "clf_batched": production arguments commit several accepts per round -- every decision of a
             // super-window guessed at once, the guess checked against the few couplings between the accepting sites
             // (sweep_clfb_impl.h); the same chain.  Ahead while the hottest replica accepts more than ~1 % (first sweeps
-            // from random spins 2.19 -> 1.84 ms, sweeps 5-25 0.272 -> 0.246), behind after 100 sweeps (0.105 -> 0.113):
+            // from random spins 2.19 -> 1.72 ms, sweeps 5-25 0.272 -> 0.245), behind after 100 sweeps (0.105 -> 0.112):
             // 2 = by the hottest replica's acceptance (default), 1 = always, 0 = never (profiles/r04_experiments.md 9)
             ac.clf_batched = (e->opt[OPT_CLF_BATCHED] == 1 || (adaptive && e->clf_hot)) ? 1 : 0;
             const bool batched = !chain && sga::sweep_clfb_applies(ac, e->want_i8);
