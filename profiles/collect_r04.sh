@@ -3,6 +3,7 @@
 #   headline  bench.py C2a fp32 with --waves = the autotuner's pick of the committed line; stats + FETCH_SIZE + WRITE_SIZE
 #   c3        bench.py --workload c3: stats, traffic AND the instruction counters its roofline block reads (VALU / SALU / LDS)
 #   c4cached  the cached-field sweep over CSR couplings on C4 (profiles/r04_c4_cached.py c4)
+#   cached    the dense cached-field variant (ON): sweep_clfb_kernel, then sweep_clf_kernel (profiles/r04_cached_profile_run.py)
 #   mixed     per-replica routing: both kernels of a mixed launch (profiles/r04_mixed_profile_run.py); kernel trace kept
 #   energy    the all-replica field pass after the XCD-aware tile mapping: C2 fp32, n = 32768 fp32
 # One counter set per --pmc pass, never with other trace domains; the program comes directly after `--`.
@@ -43,6 +44,8 @@ for t in "$@"; do
                "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
                python3 bench.py --workload c5 --implicit --no-cpu-baseline ;;
     c4cached) passes c4_cached "profiles/r04_c4_cached.py c4 (cache off / on / auto, 50 sweeps each)" "" python3 profiles/r04_c4_cached.py c4 ;;
+    cached) passes c2a_cached "profiles/r04_cached_profile_run.py (field cache ON, int8 rows, 120 sweeps in launches of 10)" "" \
+               python3 profiles/r04_cached_profile_run.py ;;
     mixed) KEEP_TRACE=1 passes c2a_mixed "profiles/r04_mixed_profile_run.py (int8 couplings, ladder 400 -> 0.1, routed by replica)" "" \
                python3 profiles/r04_mixed_profile_run.py ;;
     energy)
