@@ -2,6 +2,7 @@
 # Round-4 rocprofv3 passes (run on the GPU box through gpurun; summaries via summarize_rocprof.py).
 #   headline  bench.py C2a fp32 with --waves = the autotuner's pick of the committed line; stats + FETCH_SIZE + WRITE_SIZE
 #   c3        bench.py --workload c3: stats, traffic AND the instruction counters its roofline block reads (VALU / SALU / LDS)
+#   c4 | c5 | c5k  the graded one-row-per-proposal lines of C4, C5 at 100 and at 1000 cities: stats + FETCH_SIZE + WRITE_SIZE
 #   c4cached  the cached-field sweep over CSR couplings on C4 (profiles/r04_c4_cached.py c4)
 #   cached    the dense cached-field variant (ON): sweep_clfb_kernel, then sweep_clf_kernel (profiles/r04_cached_profile_run.py)
 #   mixed     per-replica routing: both kernels of a mixed launch (profiles/r04_mixed_profile_run.py); kernel trace kept
@@ -43,6 +44,12 @@ for t in "$@"; do
     c5i) passes c5_100_implicit "bench.py --workload c5 --implicit --no-cpu-baseline (sweep_tsp_par_kernel)" \
                "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
                python3 bench.py --workload c5 --implicit --no-cpu-baseline ;;
+    c4) passes c4_csr "bench.py --workload c4 --no-variants --no-cpu-baseline (sweep_csr_kernel, one row per proposal)" "" \
+               python3 bench.py --workload c4 --no-variants --no-cpu-baseline ;;
+    c5) passes c5_csr "bench.py --workload c5 --no-variants --no-cpu-baseline (100 cities, CSR)" "" \
+               python3 bench.py --workload c5 --no-variants --no-cpu-baseline ;;
+    c5k) passes c5_1000_csr "bench.py --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1 --no-variants --no-cpu-baseline" "" \
+               python3 bench.py --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1 --no-variants --no-cpu-baseline ;;
     c4cached) passes c4_cached "profiles/r04_c4_cached.py c4 (cache off / on / auto, 50 sweeps each)" "" python3 profiles/r04_c4_cached.py c4 ;;
     cached) passes c2a_cached "profiles/r04_cached_profile_run.py (field cache ON, int8 rows, 120 sweeps in launches of 10)" "" \
                python3 profiles/r04_cached_profile_run.py ;;
