@@ -846,8 +846,10 @@ def main():
 
         clf_steps(a.warmup)
         first = clf_timed(a.steps)          # the same sweeps the headline times
+        first["kernel_instantiation_these_sweeps"] = last_kernel()   # (the engine picks the form by the hottest replica's acceptance)
         clf_steps(max(0, 100 - done))
         later = clf_timed(a.steps)          # after 100 sweeps of the same ladder
+        later["kernel_instantiation_these_sweeps"] = last_kernel()
         later["one_sweep_per_launch"] = clf_timed(a.steps, per_launch=1)
         tracked = eng.energies()
         eng.recompute_energies()

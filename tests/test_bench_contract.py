@@ -115,7 +115,9 @@ def test_round4_headline_carries_the_other_configs_and_honest_roofs():
     assert cl["tracked_energy_equals_recomputed"] is True and cl["value"] > 100 * d["value"]
     assert cl["after_100_sweeps"]["value"] > cl["after_100_sweeps"]["one_sweep_per_launch"]["value"] > cl["value"]
     # ... and once the launch is its hottest replica's chain every replica runs at eight waves (option clf_tail_waves)
-    assert cl["after_100_sweeps"]["value"] >= 1.0e11 and "x 8 wave" in cl["kernel_instantiation"]
+    assert cl["after_100_sweeps"]["value"] >= 1.0e11 and "x 8 wave" in cl["after_100_sweeps"]["kernel_instantiation_these_sweeps"]
+    # ... and several accepts per round while the hottest replica accepts more than ~1 % (option clf_batched = 2)
+    assert cl["kernel_instantiation_these_sweeps"].startswith("sweep_clfb_kernel") and cl["value"] >= 3.9e10
     # the all-gather of the one-rank RCCL line is timed on the device (events), the host share beside it
     f = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_c2a_f32_force_dist.json")))
     assert f["backend"] == "nccl" and f["exchange"]["rounds_timed"] >= 1
