@@ -312,7 +312,9 @@ int sga_set_csr_storage(sga_engine *e, int storage);
  *     rows of <= 2048 entries, n <= ~72 000; production sweeps (SGA_SITE_RANDOM, SGA_ARITH_F64, Metropolis, no
  *     per-update records) -- other arguments take OFF's kernels for that call, the same chain.
  * ON: sga_sweep fails with SGA_ERR_UNSUPPORTED where the problem does not qualify.  AUTO: falls back to OFF's
- * kernels there -- and while replicas are hot: it starts on OFF's kernels, reads the per-replica acceptance
+ * kernels there -- and while replicas are hot: it starts on OFF's kernels (on the cached fields where the break-even
+ * below is above ~0.3: nothing is known yet, and there the row kernels lose more on a cold ladder than the cached
+ * fields on a hot one), reads the per-replica acceptance
  * counters back every 4 ... 16 sweeps and then routes EACH replica of a dense problem by its own acceptance
  * (break-even = what an update costs its chain on OFF's kernel over what an accept costs it here: 0.25 on
  * bit-planes, 0.39 on int8 rows at n = 10^4, never on fp32 rows): a ladder with a hot end runs as two concurrent

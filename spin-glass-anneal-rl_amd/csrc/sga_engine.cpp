@@ -1924,7 +1924,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // fp32 rows at n = 10^4) -- so a replica belongs on the row kernels only while its acceptance exceeds the ratio
     // of the two (profiles/r04_experiments.md 2), and a ladder with a hot end runs as TWO concurrent launches (two
     // streams) over disjoint replica lists.  The chain of a replica does not depend on the kernel that walks it.
-    // The run starts on the row kernels (nothing is known yet); the per-replica counters are read back every
+    // The run starts on the kernel that loses least if the guess is wrong (below); the per-replica counters are read back every
     // 4 ... 16 sweeps.  Option "replica_routing" = 0: one launch, decided by the hottest replica (round 3).
     // Both cached-field modes (ON and AUTO) look at the per-replica acceptance now and then.  A launch of the cached-field
     // kernel ends with its hottest replica's serial chain; once most replicas accept next to nothing -- their workgroups
@@ -1942,15 +1942,26 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     // hottest replica accepts more than ~1 % of its proposals -- 16 % ahead on the first sweeps from random spins, 10 %
     // at sweeps 5-25 of the 10 000-spin ladder -- and one accept per round below (7 % ahead after 100 sweeps).
     const bool adaptive = clf && !e->csr && e->opt[OPT_CLF_BATCHED] == 2 && e->opt[OPT_CLF_CHAIN] == 0;
+    auto routing_theta = [&]() -> double {  // break-even acceptance of one replica: t_update (row kernel) / t_accept (cached)
+        const double kn = (double)n / 1000.0;
+        const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
+                             : e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
+        return t_upd / 1.5;
+    };
     if (clf && (is_auto || tail_opt || adaptive)) {
         if (is_auto && e->auto_unavailable) {
             n_clf = 0;
         } else {
             if ((long long)e->auto_mark_acc.size() != e->R) {
                 e->auto_mark_acc.assign((size_t)e->R, 0ull);
-                // AUTO: 1 = row-per-proposal kernel until the acceptance is known; ON: 0 = cached-field kernel
-                e->route.assign((size_t)e->R, is_auto ? 1 : 0);
-                e->n_route_clf = is_auto ? 0 : e->R;
+                // ON: 0 = cached-field kernel.  AUTO: nothing is known yet -- the run starts on the kernel that loses least
+                // if the guess is wrong: the cached-field kernel where a replica would have to accept more than ~30 % of
+                // its proposals for the row kernels to win (int8 and fp32 rows at n = 10^4: the first four sweeps of the
+                // bench ladder 55 / 218 ms on the row kernels against 8 / 30 ms cached, and 36 against 56 / 208 ms on a
+                // ladder that stays hot), the row-per-proposal kernel otherwise (bit-planes, small n).
+                const bool start_cached = !is_auto || (!e->csr && 0.8 * routing_theta() >= 0.3);
+                e->route.assign((size_t)e->R, start_cached ? 0 : 1);
+                e->n_route_clf = start_cached ? e->R : 0;
                 e->clf_wide = false;
                 e->clf_hot = true;   // (nothing known yet: a run starts hot)
                 e->auto_mark_attempted = 0;
@@ -1972,10 +1983,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
                         // chain, not by the chip, whenever only part of the replicas is hot: ~1.5 us per accept (1.15 alone
                         // on its CU ... 1.7 with busy neighbours), and per update 0.38 us on bit-planes / 0.58 us on int8
                         // rows at n = 10^4, ~0.3 us on short rows (profiles/r04_routing.py; fp32 rows: estimate).
-                        const double kn = (double)n / 1000.0;
-                        const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
-                                             : e->use_t2 ? 0.29 + 0.009 * kn : (e->want_i8 ? 0.27 + 0.031 * kn : 0.30 + 0.12 * kn);
-                        const double theta = t_upd / 1.5;
+                        const double theta = routing_theta();
                         const double enter = 0.8 * theta, leave = 1.2 * theta;
                         if (e->opt[OPT_REPLICA_ROUTING] != 0 && !e->csr) {  // (the CSR row kernels take no replica lists)
                             for (int r2 = 0; r2 < e->R; ++r2) {
