@@ -106,26 +106,68 @@ CUDAKernelManager = HIPKernelManager
 
 
 class GPUMemoryOptimizer:
-    """Host helper of the reference (cuda_kernels.py:446-569): batch sizing and dense/CSR choice."""
+    """Host helper of the reference, same method names and argument meaning (annealing/cuda_kernels.py:446-569):
+    batch sizing, scratch tensors, dense / sparse choice, memory statistics.  What differs is the sizing model: the
+    reference counts one copy of J per configuration (and caps the batch at 64); in this engine the replicas of a
+    batch share ONE copy of the couplings, so `get_optimal_batch_size` returns how many replicas fit beside it."""
 
     def __init__(self, device=None):
-        self.device = device
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.memory_pool = {}
 
     @staticmethod
     def bytes_per_replica(n_spins: int) -> int:
         return n_spins * 2 + 64  # spins + best spins (int8) + scalars; J is shared
 
-    def optimal_batch_size(self, n_spins: int, available_bytes: Optional[int] = None) -> int:
-        if available_bytes is None:
-            free, _ = torch.cuda.mem_get_info()
-            available_bytes = int(free * 0.8)
-        j_bytes = 2 * n_spins * n_spins * 4  # raw + packed fp32 copies
-        return max(1, (available_bytes - j_bytes) // self.bytes_per_replica(n_spins))
+    def get_optimal_batch_size(self, n_spins: int, available_memory: Optional[int] = None) -> int:
+        """Replicas that fit into 80 % of `available_memory` (bytes; default: what the device has free) beside the raw and
+        the packed fp32 copy of the couplings (cuda_kernels.py:458-490, with this engine's footprint)."""
+        if available_memory is None:
+            if self.device.type == "cuda" and torch.cuda.is_available():
+                available_memory, _ = torch.cuda.mem_get_info(self.device)
+            else:
+                available_memory = 4 * 1024 ** 3   # (the reference's assumption without a GPU)
+        usable = int(available_memory * 0.8)
+        j_bytes = 2 * n_spins * n_spins * 4
+        return max(1, (usable - j_bytes) // self.bytes_per_replica(n_spins))
+
+    optimal_batch_size = get_optimal_batch_size   # (round-1 name)
+
+    def create_memory_efficient_tensors(self, n_spins: int, batch_size: int, use_half_precision: bool = False) -> dict:
+        """The reference's scratch set, same keys and shapes (cuda_kernels.py:492-518)."""
+        dtype = torch.float16 if use_half_precision else torch.float32
+        shapes = {"spins_batch": (batch_size, n_spins), "energies_batch": (batch_size,), "temp_spins": (n_spins,),
+                  "random_values": (batch_size * n_spins,), "local_fields": (batch_size, n_spins)}
+        return {k: torch.zeros(*shape, dtype=dtype, device=self.device) for k, shape in shapes.items()}
+
+    def optimize_coupling_matrix_storage(self, couplings: torch.Tensor, sparsity_threshold: float = 0.1) -> torch.Tensor:
+        """Sparse COO when more than `sparsity_threshold` of the entries are zero, else the dense matrix as it is
+        (cuda_kernels.py:520-540; IsingModel / sga_set_csr take either)."""
+        if couplings.is_sparse:
+            return couplings
+        zeros = 1.0 - float(torch.count_nonzero(couplings).item()) / max(couplings.numel(), 1)
+        return couplings.to_sparse_coo() if zeros > sparsity_threshold else couplings
 
     @staticmethod
     def prefers_sparse(couplings: torch.Tensor, threshold: float = 0.9) -> bool:
-        """CSR pays when fewer than ~10 % of the entries are non-zero (reference :520-540)."""
+        """CSR pays in THIS engine when fewer than ~10 % of the entries are non-zero."""
         if couplings.is_sparse:
             return True
         nz = int((couplings != 0).sum().item())
         return 1.0 - nz / couplings.numel() > threshold
+
+    def clear_memory_cache(self):
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        self.memory_pool.clear()
+
+    def get_memory_stats(self) -> dict:
+        """Keys of the reference (cuda_kernels.py:548-569); zeros without a GPU."""
+        stats = {"device": str(self.device), "memory_allocated": 0, "memory_reserved": 0, "max_memory_allocated": 0,
+                 "memory_stats": {}}
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            stats.update(memory_allocated=torch.cuda.memory_allocated(self.device),
+                         memory_reserved=torch.cuda.memory_reserved(self.device),
+                         max_memory_allocated=torch.cuda.max_memory_allocated(self.device),
+                         memory_stats=torch.cuda.memory_stats(self.device))
+        return stats

@@ -257,3 +257,27 @@ def test_spin_dynamics_diagnostics_equal_reference():
     finally:
         builtins.__import__ = real_import
         sys.modules.update(saved)
+
+
+def test_memory_optimizer_keeps_the_reference_method_names():
+    """annealing/cuda_kernels.py:446-569: get_optimal_batch_size / create_memory_efficient_tensors /
+    optimize_coupling_matrix_storage / clear_memory_cache / get_memory_stats, same argument meaning."""
+    import torch
+    from spin_glass_anneal_rl_amd.kernel_manager import GPUMemoryOptimizer
+    opt = GPUMemoryOptimizer(torch.device("cpu"))
+    b = opt.get_optimal_batch_size(1000, available_memory=1 << 30)
+    assert b == (int((1 << 30) * 0.8) - 2 * 1000 * 1000 * 4) // (2 * 1000 + 64) and opt.get_optimal_batch_size(10 ** 5, 1 << 20) == 1
+    t = opt.create_memory_efficient_tensors(10, 3, use_half_precision=True)
+    assert set(t) == {"spins_batch", "energies_batch", "temp_spins", "random_values", "local_fields"}
+    assert t["spins_batch"].shape == (3, 10) and t["random_values"].shape == (30,) and t["local_fields"].dtype == torch.float16
+    dense = torch.ones(8, 8)
+    assert opt.optimize_coupling_matrix_storage(dense) is dense
+    sparse = torch.zeros(8, 8)
+    sparse[0, 1] = sparse[1, 0] = 1.0
+    out = opt.optimize_coupling_matrix_storage(sparse, sparsity_threshold=0.1)
+    assert out.is_sparse and torch.equal(out.to_dense(), sparse)
+    opt.memory_pool["x"] = 1
+    opt.clear_memory_cache()
+    assert opt.memory_pool == {}
+    st = opt.get_memory_stats()
+    assert set(st) == {"device", "memory_allocated", "memory_reserved", "max_memory_allocated", "memory_stats"} and st["memory_allocated"] == 0
