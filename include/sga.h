@@ -315,7 +315,7 @@ int sga_set_csr_storage(sga_engine *e, int storage);
  * kernels there -- and while replicas are hot: it starts on OFF's kernels (on the cached fields where the break-even
  * below is above ~0.3: nothing is known yet, and there the row kernels lose more on a cold ladder than the cached
  * fields on a hot one), reads the per-replica acceptance
- * counters back every 4 ... 16 sweeps (at the start of a sga_sweep call: a single call of many sweeps keeps its form) and
+ * counters back every 4 ... 16 sweeps (when a sga_sweep call starts; a long production call is walked in pieces of 16 sweeps for that) and
  * then routes EACH replica of a dense problem by its own acceptance
  * (break-even = what an update costs its chain on OFF's kernel over what an accept costs it here: 0.25 on
  * bit-planes, 0.39 on int8 rows at n = 10^4, never on fp32 rows): a ladder with a hot end runs as two concurrent
@@ -337,7 +337,7 @@ int sga_set_field_cache(sga_engine *e, int mode);
  *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the windowed cached-field
  *                           sweep (a value selects that form)                                       [sweep; SGA_CLF_WAVES]
  *   "clf_tail_waves"        0 | 1 (default)   cached-field sweep over dense couplings (ON and AUTO): the per-replica
- *                           acceptance is looked at every 4 ... 16 sweeps (at the start of a sga_sweep call); once the mean is below 0.28 of the
+ *                           acceptance is looked at every 4 ... 16 sweeps (when a sga_sweep call or one of its 16-sweep pieces starts); once the mean is below 0.28 of the
  *                           hottest replica's -- the launch is that replica's chain, the chip idles behind it -- every
  *                           replica runs at eight waves.  Same chain                          [sweep; SGA_NO_CLF_TAIL_WAVES]
  *   "clf_batched"           2 (default) | 1 | 0   cached-field sweep under production arguments commits SEVERAL accepts per

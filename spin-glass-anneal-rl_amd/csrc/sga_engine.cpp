@@ -1847,6 +1847,23 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     if (rc != SGA_OK) return rc;
     if (!e->csr && !e->tsp && e->sstride != (int)e->ld)
         return fail(SGA_ERR_INVALID, "tuning changed after sga_init_replicas; re-initialise");
+    // The cached-field modes pick their kernel form by the acceptance counters, looked at when a call starts: a long
+    // production call is walked in pieces of 16 sweeps so that the form follows the run (the chain does not depend on
+    // how a run is cut into calls).
+    constexpr int PIECE = 16;
+    if (n_sweeps > PIECE && e->field_cache != SGA_FIELD_CACHE_OFF && e->rule != SGA_RULE_WOLFF && site_mode == SGA_SITE_RANDOM &&
+        !replay_site && !replay_u && !accept_trace && !dE_trace) {
+        const char *why = nullptr;
+        if (clf_possible(e, &why)) {
+            for (int k = 0; k < n_sweeps; k += PIECE) {
+                rc = sga_sweep(e, std::min(PIECE, n_sweeps - k), site_mode, arith, sched ? sched + (long long)k * sched_sweep_stride : nullptr,
+                               sched_sweep_stride, sched_replica_stride, nullptr, nullptr,
+                               energy_trace ? energy_trace + (size_t)k * (size_t)e->R : nullptr, nullptr, nullptr);
+                if (rc != SGA_OK) return rc;
+            }
+            return SGA_OK;
+        }
+    }
 
     const int n = e->n, R = e->R;
     const long long per = (long long)n_sweeps * n;

@@ -697,12 +697,15 @@ def test_cached_fields_over_csr_what_does_not_qualify(sg):
 
 
 @pytest.mark.parametrize("cache", ["on", "auto"])
-@pytest.mark.parametrize("form", [{"clf_batched": 0}, {"clf_batched": 1}])
+@pytest.mark.parametrize("form", [{"clf_batched": 0}, {"clf_batched": 1}, {"clf_batched": 0, "one_call": True}])
 def test_every_replica_gets_eight_waves_once_the_launch_is_one_replicas_chain(sg, cache, form):
     """Option "clf_tail_waves" (default): a launch of the cached-field kernel ends with its hottest replica's chain; once
     the mean acceptance is below 0.28 of the hottest replica's, every replica runs at eight waves (the workgroups
-    of the others are gone early anyway).  Same chain as with the option off and as the oracle's."""
+    of the others are gone early anyway).  Same chain as with the option off and as the oracle's.  A single call of
+    40 sweeps is walked in pieces of 16 (the counters are looked at when a call starts), so it gets there as well."""
     from spin_glass_anneal_rl_amd.engine import last_kernel
+    form = dict(form)
+    one_call = form.pop("one_call", False)
     n, R, seed, ns = 1600, 16, 0x807, 40
     J = pm1(n, 77)
     h = np.zeros(n, np.float32)
@@ -721,9 +724,14 @@ def test_every_replica_gets_eight_waves_once_the_launch_is_one_replicas_chain(sg
             e.init_replicas(R, seed=seed)
             e.set_temperatures(temps)
             kernels = []
-            for _ in range(ns // 4):
-                e.sweep(4)
-                kernels.append(last_kernel())
+            if one_call:
+                out = e.sweep(ns, energy_trace=True)
+                assert np.array_equal(out["energy_trace"], ref["energy_trace"])
+                kernels = ["(first piece)", last_kernel()]
+            else:
+                for _ in range(ns // 4):
+                    e.sweep(4)
+                    kernels.append(last_kernel())
             assert np.array_equal(e.energies(), ref["energy"]) and np.array_equal(e.spins(), s)
             assert np.array_equal(e.stats()[0], ref["n_accepted"])
             tracked = e.energies()
