@@ -51,7 +51,8 @@ for t in "$@"; do
     c5k) passes c5_1000_csr "bench.py --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1 --no-variants --no-cpu-baseline" "" \
                python3 bench.py --workload c5 --cities 1000 --replicas 256 --steps 2 --warmup 1 --no-variants --no-cpu-baseline ;;
     c4cached) passes c4_cached "profiles/r04_c4_cached.py c4 (cache off / on / auto, 50 sweeps each)" "" python3 profiles/r04_c4_cached.py c4 ;;
-    cached) passes c2a_cached "profiles/r04_cached_profile_run.py (field cache ON, int8 rows, 120 sweeps in launches of 10)" "" \
+    cached) passes c2a_cached "profiles/r04_cached_profile_run.py (field cache ON, int8 rows, 120 sweeps in launches of 10)" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SMEM" \
                python3 profiles/r04_cached_profile_run.py ;;
     mixed) KEEP_TRACE=1 passes c2a_mixed "profiles/r04_mixed_profile_run.py (int8 couplings, ladder 400 -> 0.1, routed by replica)" "" \
                python3 profiles/r04_mixed_profile_run.py ;;
