@@ -143,7 +143,7 @@ def cpu_baseline(J_host, n, seed, budget_replicas_per_core=8, sweeps=32, csr=Non
                       f"{'' if csr is not None else ', fp32 SIMD row dot'}, {dt:.2f} s"}
 
 
-def build_workload(name, a, dev, world=1, dist=None, backend="nccl"):
+def build_workload(name, a, dev, world=1, dist=None, backend="nccl", R=None, cities=None, implicit=None):
     """The problem of one BASELINE config, ready to load: {"n", "R", "n_ladders", "t_hot", "t_cold", "label",
     "J" (dense device matrix | None), "csr" (host arrays | (None, length-only, None) | None), "h", "load": f(engine)}.
     c2a: BASELINE configs[1] roofline instance; c3: configs[2]; c4: configs[3] (one rank's 1024 replicas);
@@ -151,9 +151,9 @@ def build_workload(name, a, dev, world=1, dist=None, backend="nccl"):
     from spin_glass_anneal_rl_amd import encoders as enc
     n = a.spins
     default_R = {"c2a": 1024, "c3": 4096, "c4": 1024, "c5": 2048}[name]
-    R = (a.replicas if name == a.workload else 0) or default_R
-    cities = a.cities if name == a.workload else 100
-    implicit = bool(a.implicit) and name == a.workload
+    R = R or (a.replicas if name == a.workload else 0) or default_R
+    cities = cities or (a.cities if name == a.workload else 100)
+    implicit = (bool(a.implicit) and name == a.workload) if implicit is None else implicit
     storage = a.storage if name == a.workload else "f32"
     out = {"n_ladders": 1, "t_hot": 10.0, "t_cold": 0.1, "label": "", "J": None, "csr": None, "implicit": implicit,
            "cities": cities, "storage": storage}
@@ -427,24 +427,55 @@ def cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev, exchange_interva
     return out
 
 
-def config_line(name, a, dev, local_rank, comm_dev, warmup=5, steps=10):
+def _all_gather_i64(dist, backend, value, world, comm_dev):
+    mine = torch.tensor([value], dtype=torch.int64, device=comm_dev)
+    every = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+    if backend == "nccl":
+        dist.all_gather_into_tensor(every, mine)
+    else:
+        dist.all_gather(list(every.chunk(world)), mine)
+    return every
+
+
+def checksums_agree(eng, dist, backend, world, comm_dev):
+    """Every rank must hold the same couplings (replicated, built per rank): (agree, this rank's checksum)."""
+    checksum = eng.problem_checksum()
+    if dist is None:
+        return True, checksum
+    every = _all_gather_i64(dist, backend, checksum - (1 << 64) if checksum >= (1 << 63) else checksum, world, comm_dev)
+    if not bool((every == every[0]).all().item()):
+        raise SystemExit(f"bench.py: ranks hold different couplings (checksums {every.tolist()})")
+    return True, checksum
+
+
+def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, warmup=5, steps=10,
+                R=None, cities=None, implicit=None):
     """A short line of another BASELINE config, run after the headline in the default invocation: the same engine
-    calls as `--workload <name>` (5 warm-up + 10 timed sweeps, exchange every 10), with a small CPU-oracle sample
-    replayed on the GPU (energy gap) beside it."""
+    calls as `--workload <name>` (warm-up + timed sweeps, exchange every `--exchange-interval`), with a small CPU-oracle
+    sample replayed on the GPU (energy gap) beside it at N = 1.  With N > 1 ranks the replicas are sharded as BASELINE
+    states them: C4 = ONE ladder of R x N temperatures spanning the ranks (exchange = all-gather of the energies on the
+    shared stream, identical decisions everywhere); C5 = whole 64-temperature ladders per rank (exchange rounds are
+    local: no collective).  Timing: barrier + synchronize on both sides, MAX over ranks."""
     import spin_glass_anneal_rl_amd as sg
     from spin_glass_anneal_rl_amd.engine import last_kernel
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
+    from spin_glass_anneal_rl_amd import encoders as enc
     t_setup = time.perf_counter()
-    wl = build_workload(name, a, dev, 1)
+    wl = build_workload(name, a, dev, world, R=R, cities=cities, implicit=implicit)
     n, R, n_ladders = wl["n"], wl["R"], wl["n_ladders"]
+    Rg = R * world
+    t_built = time.perf_counter()
     eng = sg.AnnealEngine(local_rank)
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(waves_per_replica=0, sweeps_per_launch=1)
     wl["load"](eng)
+    torch.cuda.synchronize()
+    t_loaded = time.perf_counter()
     eng.set_field_cache("off")  # the graded form: one coupling-row read per proposal
-    ladder = np.tile(geometric_ladder(R // n_ladders, wl["t_hot"], wl["t_cold"]), n_ladders)
-    pt = ShardedTempering(eng, R_local=R, rank=0, world=1, seed=42, slot_temps=ladder, n_ladders=n_ladders,
-                          dist=None, device=comm_dev)
+    ladder = np.tile(geometric_ladder(Rg // n_ladders, wl["t_hot"], wl["t_cold"]), n_ladders)
+    pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42, slot_temps=ladder, n_ladders=n_ladders,
+                          dist=dist, device=comm_dev)
+    agree, checksum = checksums_agree(eng, dist, a.backend, world, comm_dev)
     done = 0
 
     def step():
@@ -454,34 +485,104 @@ def config_line(name, a, dev, local_rank, comm_dev, warmup=5, steps=10):
         if a.exchange_interval > 0 and done % a.exchange_interval == 0:
             pt.exchange(count=False)
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    if a.exchange_interval > 0:
+        pt.exchange()  # one untimed round: first-use allocations of the collective happen here (the same chain at any N)
+    barrier()
     eng.enable_timing(True)
     eng.kernel_time(reset=True)
+    pt.gather_calls, pt.gather_ms = 0, 0.0
+    pt.time_collectives = True
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    barrier()
+    dt_mine = time.perf_counter() - t0
+    dt = dt_mine
+    if dist is not None:
+        tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     launches, kernel_ms = eng.kernel_time(reset=True)
     eng.enable_timing(False)
     kernel_inst = last_kernel()
+    what = ("couplings implicit (TSP structure: 2 distance rows per attempt)" if wl["implicit"] else
+            f"CSR mean degree {len(wl['csr'][1]) / n:.1f}")
     line = {"workload": (wl["label"] or f"C3: {n}-spin CSR +-1 Ising") +
-                        f", CSR mean degree {len(wl['csr'][1]) / n:.1f}, {R} replicas/GPU, {n_ladders} geometric ladder(s) T "
+                        f", {what}, {R} replicas/GPU, {n_ladders} geometric ladder(s) T "
                         f"{wl['t_hot']:g}->{wl['t_cold']:g}, exchange every {a.exchange_interval}",
-            "value": float(R) * n * steps / dt, "unit": "attempts/s", "steps": steps, "warmup": warmup,
+            "value": float(Rg) * n * steps / dt, "unit": "attempts/s", "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "kernel_ms_total": kernel_ms, "geometry": eng.describe(),
             "kernel_instantiation": kernel_inst,
+            "setup_ms": {"build_couplings": (t_built - t_setup) * 1e3, "engine_load": (t_loaded - t_built) * 1e3,
+                         "note": "untimed set-up on this rank: writing the couplings, then sga_set_* (validation incl. the "
+                                 "symmetry pass, layout, packing)"},
             "roofline": roofline_block(wl, name, R, (kernel_ms / max(launches, 1)) * 1e-3, launches, kernel_inst),
             "best_energy": eng.best(with_spins=False)[0]}
-    if not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(None, n, 42, csr=wl["csr"], h=wl["h"].cpu().numpy(), eng=eng,
-                                            t_range=(wl["t_hot"], wl["t_cold"]), budget_replicas_per_core=2, scale=0.25)
-    if name == "c4" and not a.no_variants:
+    if world > 1:
+        line.update({
+            "n_gpus": world, "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "scaling": "weak",
+            "replicas_total": Rg, "couplings_checksum_agree": agree, "couplings_checksum": f"{checksum:016x}",
+            "ms_per_step_this_rank": dt_mine / steps * 1e3,
+            "placement": ("whole ladders per rank: exchange rounds are local, no collective (SURVEY.md 8e)"
+                          if pt.ladders_local else
+                          f"one ladder of {Rg // n_ladders} temperatures spans the ranks: all-gather of the energies per round, "
+                          "identical Philox decisions on every rank, temperature labels swap"),
+            "exchange": {"rounds_timed": (done // a.exchange_interval - warmup // a.exchange_interval)
+                                         if a.exchange_interval > 0 else 0,
+                         "allgathers_timed": pt.gather_calls,
+                         "allgather_ms_per_round": pt.gather_device_ms_per_round(),
+                         "enqueue_ms_per_round": (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
+                         "bytes_per_rank": 0 if pt.ladders_local else 8 * R}})
+    import hashlib
+    e_all = pt.gather_energies().cpu().numpy() if world > 1 else eng.energies()
+    line["energies_sha256"] = hashlib.sha256(np.ascontiguousarray(e_all, np.float64).tobytes()).hexdigest()[:16]
+    e_best, _, who = pt.global_best()
+    line["best_energy_global"], line["best_replica_global"] = e_best, who
+    if not a.no_cpu_baseline and world == 1 and rank == 0:
+        if wl["csr"] is not None and wl["csr"][0] is not None:
+            line["cpu_baseline"] = cpu_baseline(None, n, 42, csr=wl["csr"], h=wl["h"].cpu().numpy(), eng=eng,
+                                                t_range=(wl["t_hot"], wl["t_cold"]), budget_replicas_per_core=2,
+                                                scale=0.25)
+        elif name == "c5":
+            # no host copy of this instance (implicit couplings / 32 GB of CSR; the CPU port indexes entries with 32
+            # bits): the CPU sample runs on the first 500 cities of the same point set, replayed on a second engine in
+            # the same coupling form as this line
+            sub = min(wl["cities"], 500)
+            dsub = wl["dmat"][:sub, :sub]
+            tsp2 = enc.tsp_csr(dsub, city_visit=200.0, position_fill=200.0, device=dev)
+            csr2 = (tsp2[0].cpu().numpy().astype(np.int32), tsp2[1].cpu().numpy(), tsp2[2].cpu().numpy())
+            h2 = tsp2[3].cpu().numpy()
+            eng2 = sg.AnnealEngine(local_rank)
+            if wl["implicit"]:
+                d32, w_city, w_pos, h_np, _ = enc.tsp_structure(dsub, 200.0, 200.0)
+                eng2.set_tsp(torch.from_numpy(d32).to(dev), w_city, w_pos, torch.from_numpy(h_np).to(dev))
+            else:
+                eng2.set_csr(tsp2[0], tsp2[1], tsp2[2], tsp2[3])
+            del tsp2
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(None, sub * sub, 42, csr=csr2, h=h2, eng=eng2,
+                                                t_range=(wl["t_hot"], wl["t_cold"]), budget_replicas_per_core=2,
+                                                scale=0.25)
+            line["cpu_baseline"]["substitute_instance"] = (
+                f"the first {sub} of the {wl['cities']} cities ({sub * sub} spins, {len(csr2[1])} CSR entries) on the CPU; "
+                f"replayed on the GPU in this line's coupling form "
+                f"({'implicit' if wl['implicit'] else 'stored CSR'})")
+            eng2.close()
+            del csr2
+    if name == "c4" and not a.no_variants and world == 1:
         line["variants"] = {"cached_local_fields": cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev,
                                                                       a.exchange_interval)}
     eng.close()
+    wl.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
     line["wall_s_with_setup"] = time.perf_counter() - t_setup
     return line
 
@@ -556,6 +657,15 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short C3 / C4 / C5 lines that follow the headline in the default run")
+    ap.add_argument("--configs", default=None,
+                    help="comma list of the config lines to run after the headline (c3,c4,c5,c5_1000,c5_1000_csr); "
+                         "given explicitly it overrides --no-variants / --no-configs")
+    ap.add_argument("--config-replicas", type=int, default=0,
+                    help="replicas per rank of the c4 / c5 config lines (tests: a small sharded run against the same "
+                         "global replica set on one rank)")
+    ap.add_argument("--no-c5-1000", action="store_true", help="skip the 1000-city lines of configs[4] in the default run")
+    ap.add_argument("--no-c5-1000-csr", action="store_true",
+                    help="skip only the stored-CSR 1000-city line (32 GB of couplings written out: ~15 s of set-up)")
     ap.add_argument("--no-beyond-cache", action="store_true",
                     help="skip the second roofline block (same kernel, 4.3 GB matrix beyond every cache)")
     ap.add_argument("--beyond-cache-spins", type=int, default=32768)
@@ -641,19 +751,7 @@ def main():
             pt = tempering()
     geometry = eng.describe()
     # every rank must hold the same couplings (J is replicated, built per rank from a seeded generator)
-    checksum = eng.problem_checksum()
-    checksum_agree = True
-    if dist is not None:
-        mine = torch.tensor([checksum - (1 << 64) if checksum >= (1 << 63) else checksum], dtype=torch.int64,
-                            device=comm_dev)
-        every = torch.zeros(world, dtype=torch.int64, device=comm_dev)
-        if a.backend == "nccl":
-            dist.all_gather_into_tensor(every, mine)
-        else:
-            dist.all_gather(list(every.chunk(world)), mine)
-        checksum_agree = bool((every == every[0]).all().item())
-        if not checksum_agree:
-            raise SystemExit(f"bench.py: ranks hold different couplings (checksums {every.tolist()})")
+    checksum_agree, checksum = checksums_agree(eng, dist, a.backend, world, comm_dev)
 
     def barrier():
         if dist is not None:
@@ -966,12 +1064,43 @@ def main():
     else:
         out["cpu_baseline"] = None
     # BASELINE configs[2], [3], [4] in the line the driver runs: short runs of the same engine calls as
-    # `--workload c3 | c4 | c5` (5 warm-up + 10 timed sweeps each), each with its own roofline and a small CPU sample
-    if a.workload == "c2a" and world == 1 and rank == 0 and not a.no_configs and not a.no_variants:
+    # `--workload c3 | c4 | c5` (5 warm-up + 10 timed sweeps each), each with its own roofline and, at N = 1, a small
+    # CPU sample.  With N > 1 ranks: configs[3] and [4] sharded over the ranks as BASELINE states them (every rank
+    # takes part; rank 0 prints).
+    wanted = None if a.configs is None else [c for c in a.configs.split(",") if c]
+    if a.workload == "c2a" and (wanted is not None or (not a.no_configs and not a.no_variants)):
         eng.close()
-        del J
+        J = None
+        wl.clear()
+        gc.collect()
         torch.cuda.empty_cache()
-        out["configs"] = {name: config_line(name, a, dev, local_rank, comm_dev) for name in ("c3", "c4", "c5")}
+        if wanted is None:
+            wanted = (["c3"] if world == 1 else []) + ["c4", "c5"]
+            if not a.no_c5_1000:
+                wanted += ["c5_1000"] + (["c5_1000_csr"] if world == 1 and not a.no_c5_1000_csr else [])
+        kw = dict(rank=rank, world=world, dist=dist)
+        cr = a.config_replicas
+        cfgs = {}
+        for c in wanted:
+            if c == "c3":
+                cfgs[c] = config_line("c3", a, dev, local_rank, comm_dev, **kw)
+            elif c == "c4":  # configs[3]: 1024 replicas per GPU of ONE ladder spanning the GPUs
+                cfgs[c] = config_line("c4", a, dev, local_rank, comm_dev, R=cr or None, **kw)
+            elif c == "c5":
+                # configs[4]: 2048 replicas in 32 ladders of 64 over 8 GPUs = 256 replicas (4 whole ladders) per GPU; one
+                # GPU alone holds all 32 ladders of the 100-city instance
+                cfgs[c] = config_line("c5", a, dev, local_rank, comm_dev, R=cr or (2048 if world == 1 else 256), **kw)
+            elif c == "c5_1000":
+                # ... at its stated size (1000 cities, 10^6 spins), one rank's share, couplings never stored (sga_set_tsp)
+                cfgs[c] = config_line("c5", a, dev, local_rank, comm_dev, R=cr or 256, cities=1000, implicit=True,
+                                      warmup=2, steps=3, **kw)
+            elif c == "c5_1000_csr":
+                # ... and with the 32 GB of CSR written out (the graded byte model; set-up reported as setup_ms)
+                cfgs[c] = config_line("c5", a, dev, local_rank, comm_dev, R=cr or 256, cities=1000, implicit=False,
+                                      warmup=1, steps=2, **kw)
+            else:
+                raise SystemExit(f"bench.py: unknown config line {c!r}")
+        out["configs"] = cfgs
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

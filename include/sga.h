@@ -199,7 +199,11 @@ int sga_recompute_energies(sga_engine *e);
 /* One nearest-neighbour replica-exchange round over the ladder(s)
  * (parallel_tempering.py:214-258: even/odd pairs, accept min(1, exp((b_j-b_i)(E_j-E_i)))).
  *   energies_global: [R_global] doubles indexed by GLOBAL replica id (after an all-gather);
- *                    NULL = the engine's own energies (requires R_local == R_global).
+ *                    NULL = the engine's own energies: needs R_local == R_global, or every ladder whole
+ *                    on one rank (replica0 and R_local multiples of the ladder length) -- then only the
+ *                    local ladders are decided (same Philox keys as in the unsharded run: global ladder
+ *                    index), the slot map / exchange statistics of the other ranks' ladders stay
+ *                    untouched here, and *n_accepted counts the local ladders' swaps.
  *   start: [n_ladders] int32 0/1 parity per ladder, NULL = Philox (domain 1).
  *   u: [n_ladders][slots/2] doubles in attempt order, NULL = Philox.
  *   n_accepted: optional out (host int). */

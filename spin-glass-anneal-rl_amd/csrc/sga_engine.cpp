@@ -2441,11 +2441,14 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
                  const double *u, int *n_accepted) {
     if (!e) return fail(SGA_ERR_INVALID, "engine is NULL");
     if (e->n_ladders <= 0) return fail(SGA_ERR_INVALID, "no ladder (call sga_set_ladder)");
-    if (!energies_global && e->R != e->Rg)
-        return fail(SGA_ERR_INVALID, "sharded replicas need the all-gathered energies");
+    const int L = e->Rg / e->n_ladders;
+    // whole ladders on this rank: their rounds need nobody else's energies (zero exchange traffic)
+    const bool ladders_local = !energies_global && e->R != e->Rg && e->replica0 % L == 0 && e->R % L == 0;
+    if (!energies_global && e->R != e->Rg && !ladders_local)
+        return fail(SGA_ERR_INVALID, "sharded replicas need the all-gathered energies (unless every ladder lies "
+                                     "whole on one rank)");
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = e->stream;
-    const int L = e->Rg / e->n_ladders;
     DevIn<double> d_e, d_u;
     DevIn<int32_t> d_start;
     int rc;
@@ -2479,6 +2482,9 @@ int sga_exchange(sga_engine *e, const double *energies_global, const int32_t *st
     a.seed_lo = (uint32_t)e->seed;
     a.seed_hi = (uint32_t)(e->seed >> 32);
     a.round = e->rounds;
+    a.ladder0 = ladders_local ? e->replica0 / L : 0;
+    a.n_ladders_local = ladders_local ? e->R / L : e->n_ladders;
+    a.energy_base = ladders_local ? e->replica0 : 0;
     HIPCHK(sga::launch_exchange_neighbor(a, st));
     e->rounds += 1;
     if (n_accepted) {

@@ -192,6 +192,9 @@ struct ExchangeArgs {
     int *n_accepted;          // device counter
     int R_global, R_local, replica0, n_ladders;
     uint32_t seed_lo, seed_hi, round;
+    // the ladders this launch decides: all of them (energies by global id), or only those the local replicas fill
+    // (whole ladders per rank: `energies` are the local ones, shifted by energy_base = replica0; no gather needed)
+    int ladder0, n_ladders_local, energy_base;
 };
 
 // launchers (defined in the .hip files); all return hipGetLastError() after the launch

@@ -806,10 +806,11 @@ hipError_t launch_energy_csr(const EnergyArgs &a, hipStream_t st) {
 __global__ void exchange_neighbor_kernel(const ExchangeArgs a) {
     const int L = a.R_global / a.n_ladders;
     const int half = L / 2;
-    const int total = a.n_ladders * half;
+    const int total = a.n_ladders_local * half;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += gridDim.x * blockDim.x) {
-        const int l = idx / half, q = idx - l * half;
+        const int ll = idx / half, q = idx - ll * half;
+        const int l = a.ladder0 + ll;  // global ladder: keys the Philox draws and indexes start / u
         int start;
         if (a.start) {
             start = a.start[l] & 1;
@@ -824,7 +825,7 @@ __global__ void exchange_neighbor_kernel(const ExchangeArgs a) {
         // _attempt_single_exchange, parallel_tempering.py:234-258
         const double beta_i = 1.0 / a.slot_temps[i], beta_j = 1.0 / a.slot_temps[i + 1];
         const int ri = a.slot_to_rep[i], rj = a.slot_to_rep[i + 1];
-        const double x = (beta_j - beta_i) * (a.energies[rj] - a.energies[ri]);
+        const double x = (beta_j - beta_i) * (a.energies[rj - a.energy_base] - a.energies[ri - a.energy_base]);
         const double prob = (x >= 0.0) ? 1.0 : exp_det(x);
         double uu;
         if (a.u) {
@@ -852,7 +853,7 @@ __global__ void exchange_neighbor_kernel(const ExchangeArgs a) {
 
 hipError_t launch_exchange_neighbor(const ExchangeArgs &a, hipStream_t st) {
     const int L = a.R_global / a.n_ladders;
-    const int total = a.n_ladders * (L / 2);
+    const int total = a.n_ladders_local * (L / 2);
     if (total <= 0) return hipSuccess;
     const int blocks = (total + 255) / 256;
     hipLaunchKernelGGL(exchange_neighbor_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -148,30 +148,31 @@ class MultiGPUAnnealer:
         temps = np.tile(one, n_ladders)
         seed = fresh_seed(acfg.random_seed)
         side = None
-        if dist is not None:
-            rank = dist.get_rank()
-            gpu = int(os.environ.get("LOCAL_RANK", rank))
-            on_gpu = dist.get_backend() == "nccl"
-            comm_dev = torch.device("cuda", gpu) if on_gpu else torch.device("cpu")
-            seed_t = torch.tensor([seed], dtype=torch.int64, device=comm_dev)
-            dist.broadcast(seed_t, src=0)  # all ranks must share the Philox key
-            eng = self._make_engine(gpu, model)
-            if on_gpu:
-                # ONE stream for the engine's kernels and the collectives: energies copy -> all-gather -> exchange
-                # kernel are ordered by it (ShardedTempering._stream_ordered), no host synchronisation in a round
-                side = torch.cuda.Stream(comm_dev)
-                torch.cuda.set_stream(side)
-                eng.use_stream(side.cuda_stream)
-            self._same_couplings_everywhere([eng], dist, comm_dev)
-            pt = ShardedTempering(eng, Rl, rank, world, int(seed_t.item()), temps, n_ladders, dist, comm_dev)
-            engines = [eng]
-        else:
-            engines = [self._make_engine(g, model) for g in cfg.gpu_ids]
-            self._same_couplings_everywhere(engines, None, None)
-            pt = LocalShardedTempering(engines, Rl, seed, temps, n_ladders)
-        self._engines = engines
+        self._engines = engines = []  # filled as the engines come up: cleanup() and the finally block see every one
         done, history, rounds = 0, [], 0
         try:
+            if dist is not None:
+                rank = dist.get_rank()
+                gpu = int(os.environ.get("LOCAL_RANK", rank))
+                on_gpu = dist.get_backend() == "nccl"
+                comm_dev = torch.device("cuda", gpu) if on_gpu else torch.device("cpu")
+                seed_t = torch.tensor([seed], dtype=torch.int64, device=comm_dev)
+                dist.broadcast(seed_t, src=0)  # all ranks must share the Philox key
+                eng = self._make_engine(gpu, model)
+                engines.append(eng)
+                if on_gpu:
+                    # ONE stream for the engine's kernels and the collectives: energies copy -> all-gather -> exchange
+                    # kernel are ordered by it (ShardedTempering._stream_ordered), no host synchronisation in a round
+                    side = torch.cuda.Stream(comm_dev)
+                    torch.cuda.set_stream(side)
+                    eng.use_stream(side.cuda_stream)
+                self._same_couplings_everywhere([eng], dist, comm_dev)
+                pt = ShardedTempering(eng, Rl, rank, world, int(seed_t.item()), temps, n_ladders, dist, comm_dev)
+            else:
+                for g in cfg.gpu_ids:
+                    engines.append(self._make_engine(g, model))
+                self._same_couplings_everywhere(engines, None, None)
+                pt = LocalShardedTempering(engines, Rl, seed, temps, n_ladders)
             while done < acfg.n_sweeps:
                 step = min(cfg.synchronization_interval, acfg.n_sweeps - done)
                 pt.sweep(step)
@@ -187,8 +188,10 @@ class MultiGPUAnnealer:
                     best_here = float(t.item())
                 history.append(best_here)
             best_e, best_s, _ = pt.global_best()
-            attempts, accepts = (engines[0].exchange_stats() if rounds else (np.zeros(0), np.zeros(0)))
+            attempts, accepts = pt.exchange_totals() if rounds else (0, 0)
         finally:
+            # every exit path -- the coupling-mismatch error included -- hands torch its default stream back and
+            # releases the engines' HBM
             if side is not None:
                 side.synchronize()
                 torch.cuda.set_stream(torch.cuda.default_stream(side.device))
@@ -204,8 +207,8 @@ class MultiGPUAnnealer:
         # (the reference passes metadata= to AnnealingResult, which has no such field, multi_gpu.py:302-307;
         #  the same facts as attributes of the returned record)
         result.metadata = {"strategy": "replica_exchange", "n_replicas": Rg, "n_ladders": n_ladders,
-                           "exchange_rounds": rounds, "exchange_attempts": int(np.sum(attempts)),
-                           "exchanges": int(np.sum(accepts)), "world_size": world}
+                           "exchange_rounds": rounds, "exchange_attempts": int(attempts),
+                           "exchanges": int(accepts), "world_size": world}
         return result
 
     @staticmethod

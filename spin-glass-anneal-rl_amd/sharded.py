@@ -12,6 +12,10 @@ is a validated string, annealing/multi_gpu.py:26,41-43; "multi-GPU" is a thread 
   rank (RCCL over xGMI; 8 KiB per rank at 1024 replicas -- latency bound, link bandwidth is
   irrelevant).  Every rank then evaluates the same Philox-seeded decisions on the gathered
   vector and swaps temperature *labels*; spins never cross a link;
+* several ladders (BASELINE configs[4]: 32 ladders of 64 temperatures): when the ladder count is a
+  multiple of the rank count every ladder lies whole on one rank and an exchange round is purely
+  local -- no collective at all ("zero exchange traffic"); the decisions are keyed by
+  the GLOBAL ladder index, so the run equals the one-rank run bit for bit;
 * at the end the global best is found with one all-gather of the per-rank best energies and
   one broadcast of the winner's configuration.
 
@@ -35,6 +39,8 @@ class ShardedTempering:
         self.R_global = self.R_local * self.world
         self.replica0 = self.rank * self.R_local
         self.dist = dist if (world > 1 or force_dist) else None
+        # every ladder whole on one rank: exchange rounds need no energies from anybody else
+        self.ladders_local = self.dist is not None and self.world > 1 and int(n_ladders) % self.world == 0
         self.device = device if device is not None else torch.device("cpu")
         engine.init_replicas(self.R_local, seed=seed, s0=s0, R_global=self.R_global,
                              replica0=self.replica0)
@@ -105,9 +111,27 @@ class ShardedTempering:
         number of accepted swaps, or None with count=False (no read-back: the round stays asynchronous)."""
         if self.dist is None:
             return self.engine.exchange(count=count)
+        if self.ladders_local:
+            mine = self.engine.exchange(count=count)  # the local ladders only; nothing crosses a link
+            if not count:
+                return None
+            total = torch.tensor([mine], dtype=torch.int64, device=self.device)
+            self.dist.all_reduce(total)  # (only the caller's count: the round itself needed no collective)
+            return int(total.item())
         return self.engine.exchange(energies_global=self.gather_energies(), count=count)
 
     # ------------------------------------------------------------------ results
+    def exchange_totals(self):
+        """(attempts, accepted swaps) of all rounds so far over ALL ladders.  A rank that decides only its own
+        ladders (ladders_local) holds only their counters: the totals are summed over the ranks."""
+        att, acc = self.engine.exchange_stats()
+        if not self.ladders_local:
+            return int(np.sum(att)), int(np.sum(acc))
+        sl = slice(self.replica0, self.replica0 + self.R_local)
+        t = torch.tensor([int(np.sum(att[sl])), int(np.sum(acc[sl]))], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t)
+        return int(t[0].item()), int(t[1].item())
+
     def global_best(self):
         """(energy, spins int8 [n], global replica id) of the best configuration seen."""
         e, s, idx = self.engine.best()
@@ -165,6 +189,10 @@ class LocalShardedTempering:
         counts = [e.exchange(energies_global=all_e) for e in self.engines]
         assert len(set(counts)) == 1, "ranks disagree on the exchange decisions"
         return counts[0]
+
+    def exchange_totals(self):
+        att, acc = self.engines[0].exchange_stats()  # every engine decides every ladder: one holds the totals
+        return int(np.sum(att)), int(np.sum(acc))
 
     def global_best(self):
         bests = [e.best() for e in self.engines]

@@ -59,12 +59,20 @@ class OracleEngine:
         return tensor
 
     def exchange(self, energies_global=None, start=None, u=None, count=True):
-        e = self._energy if energies_global is None else \
-            np.asarray(energies_global.cpu() if hasattr(energies_global, "cpu") else energies_global,
-                       np.float64)
         L = self.R_global // self.n_ladders
+        ladders = range(self.n_ladders)
+        if energies_global is None and self.R != self.R_global:
+            # whole ladders on this rank (sga_exchange, include/sga.h): only those are decided, from the local energies
+            assert self.replica0 % L == 0 and self.R % L == 0, "sharded replicas need the all-gathered energies"
+            e = np.zeros(self.R_global)
+            e[self.replica0:self.replica0 + self.R] = self._energy
+            ladders = range(self.replica0 // L, (self.replica0 + self.R) // L)
+        else:
+            e = self._energy if energies_global is None else \
+                np.asarray(energies_global.cpu() if hasattr(energies_global, "cpu") else energies_global,
+                           np.float64)
         n_acc = 0
-        for l in range(self.n_ladders):
+        for l in ladders:
             sl = slice(l * L, (l + 1) * L)
             view, a, c = self.slot_to_rep[sl].copy(), self.ex_att[sl].copy(), self.ex_acc[sl].copy()
             n_acc += oracle.pt_exchange_round(self.slot_temps[sl], e, view, start=-1, seed=self.seed,
@@ -113,4 +121,4 @@ class OracleEngine:
         pass
 
     def close(self):
-        pass
+        self.closed = True

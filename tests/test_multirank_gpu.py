@@ -55,6 +55,45 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert d["exchange"]["rounds_timed"] >= 1 and d["exchange"]["allgather_ms_per_round"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_multirank_lines_of_configs_3_and_4_equal_the_one_rank_run():
+    """BASELINE configs[3] (ONE ladder spanning the ranks, exchange through an all-gather of the energies) and configs[4]
+    (whole 64-temperature ladders per rank, no collective) as `bench.py --gpus 2` runs them after the headline: the final
+    energies of all replicas, the global best and its replica equal the same global replica set on one rank, bit for bit."""
+    two_gpus = torch.cuda.device_count() >= 2
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spins", "2000",
+            "--replicas", "64", "--no-autotune", "--no-variants", "--no-cpu-baseline", "--configs", "c4,c5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    runs = {}
+    for world, per_rank in ((1, 256), (2, 128)):
+        cmd = base + ["--gpus", str(world), "--config-replicas", str(per_rank)]
+        if world > 1 and not two_gpus:
+            cmd += ["--backend", "gloo", "--share-device"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = p.stdout.splitlines()
+        assert len(lines) == 1, p.stdout[:500]
+        runs[world] = json.loads(lines[0])["configs"]
+    one, two = runs[1], runs[2]
+    assert set(two) == {"c4", "c5"}
+    for c in ("c4", "c5"):
+        assert two[c]["ranks_seen"] == 2 and two[c]["n_gpus"] == 2 and two[c]["couplings_checksum_agree"] is True
+        assert two[c]["replicas_total"] == 256 and two[c]["scaling"] == "weak"
+        assert two[c]["ms_per_step"] >= two[c]["ms_per_step_this_rank"] * 0.999  # MAX over the ranks
+        assert two[c]["energies_sha256"] == one[c]["energies_sha256"], c
+        assert two[c]["best_energy_global"] == one[c]["best_energy_global"], c
+        assert two[c]["best_replica_global"] == one[c]["best_replica_global"], c
+    # configs[3]: the ladder spans the ranks -> every timed round gathers the energies
+    assert two["c4"]["exchange"]["rounds_timed"] >= 1
+    assert two["c4"]["exchange"]["allgathers_timed"] == two["c4"]["exchange"]["rounds_timed"]
+    assert two["c4"]["exchange"]["allgather_ms_per_round"] > 0 and two["c4"]["exchange"]["bytes_per_rank"] == 8 * 128
+    assert "spans the ranks" in two["c4"]["placement"] and "1 geometric ladder" in two["c4"]["workload"]
+    # configs[4]: 2 whole ladders of 64 per rank -> rounds are local, nothing is gathered
+    assert two["c5"]["exchange"]["rounds_timed"] >= 1 and two["c5"]["exchange"]["allgathers_timed"] == 0
+    assert two["c5"]["exchange"]["bytes_per_rank"] == 0 and "whole ladders per rank" in two["c5"]["placement"]
+    assert "4 geometric ladder" in two["c5"]["workload"]
+
+
 def _rank_main(rank, world, port, backend, share, n_ladders, out_path, force=False, side_stream=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -121,7 +160,7 @@ def _run_ranks(world, backend, share, n_ladders, tmp_path, force=False, side_str
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
-@pytest.mark.parametrize("n_ladders", [1, 3])
+@pytest.mark.parametrize("n_ladders", [1, 2, 3])
 def test_two_ranks_on_real_engines_equal_one_rank(backend, n_ladders, tmp_path):
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank; this box has one (the 8-GPU driver run covers it)")
@@ -134,7 +173,10 @@ def test_two_ranks_on_real_engines_equal_one_rank(backend, n_ladders, tmp_path):
         sl = slice(rank * half, (rank + 1) * half)
         assert np.array_equal(o["swaps"], single["swaps"])
         assert np.array_equal(o["energies"], single["energies"])
-        assert np.array_equal(o["slot_map"], single["slot_map"])
+        if n_ladders % 2 == 0:  # whole ladders per rank: rounds decided locally, no gather (sga_exchange, sga.h)
+            assert np.array_equal(o["slot_map"][sl], single["slot_map"][sl])
+        else:
+            assert np.array_equal(o["slot_map"], single["slot_map"])
         assert np.array_equal(o["spins"], single["spins"][sl])
         assert np.array_equal(o["temps"], single["temps"][sl])
         assert o["best_e"] == single["best_e"] and o["best_idx"] == single["best_idx"]
@@ -228,3 +270,55 @@ def test_multi_gpu_annealer_over_a_one_rank_rccl_group_equals_the_plain_call(tmp
     assert a["best"] == b["best"] and np.array_equal(a["cfg"], b["cfg"]) and np.array_equal(a["hist"], b["hist"])
     assert a["exchanges"] == b["exchanges"] > 0 and a["attempts"] == b["attempts"] and len(a["hist"]) == 6
     assert 0 < a["mem"] <= a["total"]
+
+
+def _class_mismatch_main(port, out_path):
+    """A run that is refused after the engine and the side stream are up (the coupling check says no)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    import torch.distributed as dist
+    import spin_glass_anneal_rl_amd as sg
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    rng = np.random.RandomState(5)
+    J = np.triu(rng.randint(0, 2, (N_SPINS, N_SPINS)) * 2 - 1, 1).astype(np.float32)
+    m = sg.IsingModel(sg.IsingModelConfig(n_spins=N_SPINS, use_sparse=False))
+    m.set_couplings_from_matrix(torch.from_numpy(J + J.T))
+    made = []
+
+    class Refusing(sg.MultiGPUAnnealer):
+        def _make_engine(self, gpu, model):
+            made.append(super()._make_engine(gpu, model))
+            return made[-1]
+
+        @staticmethod
+        def _same_couplings_everywhere(engines, dist_, comm_dev):
+            raise sg.AnnealingError("the ranks hold different couplings (injected)")
+
+    ann = Refusing(sg.MultiGPUConfig(gpu_ids=[0], strategy="replica_exchange", synchronization_interval=2,
+                                     replicas_per_gpu=R_GLOBAL),
+                   sg.GPUAnnealerConfig(n_sweeps=4, initial_temp=6.0, final_temp=0.3, random_seed=SEED))
+    err = ""
+    try:
+        ann.anneal_replica_exchange(m)
+    except sg.AnnealingError as exc:
+        err = str(exc)
+    np.savez(out_path, err=err, made=len(made), closed=all(not e._h.value for e in made), left=len(ann._engines),
+             default_stream=bool(torch.cuda.current_stream() == torch.cuda.default_stream()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_a_refused_run_closes_its_engine_and_hands_the_default_stream_back(tmp_path):
+    """The coupling-mismatch error leaves after the engine is built and torch runs on the private side stream: the
+    finally block closes the engine (its HBM) and restores torch's default stream on that path too."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "refused.npz")
+    p = ctx.Process(target=_class_mismatch_main, args=(_free_port(), path))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    o = dict(np.load(path))
+    assert "different couplings" in str(o["err"])
+    assert int(o["made"]) == 1 and bool(o["closed"]) and int(o["left"]) == 0 and bool(o["default_stream"])

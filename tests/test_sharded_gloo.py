@@ -89,8 +89,11 @@ def _check(n_ladders, world=2):
         o = got[rank]
         assert o["swaps"] == single["swaps"]
         assert np.array_equal(o["energies"], single["energies"])
-        assert np.array_equal(o["slot_map"], single["slot_map"])
         sl = slice(rank * half, (rank + 1) * half)
+        if n_ladders % world == 0:  # whole ladders per rank: rounds are local, a rank keeps only its own ladders' slots
+            assert np.array_equal(o["slot_map"][sl], single["slot_map"][sl])
+        else:
+            assert np.array_equal(o["slot_map"], single["slot_map"])
         assert np.array_equal(o["spins"], single["spins"][sl])
         assert np.array_equal(o["temps"], single["temps"][sl])
         assert o["best"][0] == single["best"][0] and o["best"][2] == single["best"][2]
@@ -103,6 +106,15 @@ def test_two_rank_run_equals_single_rank_one_ladder():
 
 def test_two_rank_run_equals_single_rank_three_ladders():
     _check(3)
+
+
+def test_whole_ladders_per_rank_exchange_without_any_gather():
+    """BASELINE configs[4]'s placement: 4 ladders of 3 over 2 ranks, 6 ladders of 2 over 2 and over 3
+    ranks -- every ladder whole on one rank.  Rounds are decided locally (no energies cross ranks), keyed by the
+    global ladder index: swaps, spins, temperatures, energies and best equal the one-rank run."""
+    _check(4)
+    _check(6)
+    _check(6, world=3)
 
 
 def test_four_rank_run_equals_single_rank_ladders_straddling_ranks():
@@ -133,13 +145,16 @@ def _annealer(corrupt_rank=None, n_ladders=1):
             self.config, self.annealer_config = config, annealer_config
             self.devices = [torch.device("cpu")]
             self.master_device = self.devices[0]
+            self.made = []
 
         def _make_engine(self, gpu, model):
             J = model.couplings.numpy().copy()
             rank = dist.get_rank() if dist.is_initialized() else 0
             if corrupt_rank is not None and rank == corrupt_rank:
                 J[0, 1] = J[1, 0] = -J[0, 1] if J[0, 1] != 0 else 1.0   # one coupling differs on this rank
-            return OracleEngine(J=J, h=model.external_fields.numpy().copy())
+            eng = OracleEngine(J=J, h=model.external_fields.numpy().copy())
+            self.made.append(eng)
+            return eng
 
     cfg = sg.MultiGPUConfig(gpu_ids=[0], strategy="replica_exchange", communication_backend="gloo",
                             synchronization_interval=2, replicas_per_gpu=R_GLOBAL, n_ladders=n_ladders)
@@ -159,12 +174,14 @@ def _model():
 def _class_worker(rank, world, port, q, corrupt_rank, n_ladders):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    ann = _annealer(corrupt_rank, n_ladders)
     try:
-        res = _annealer(corrupt_rank, n_ladders).anneal_replica_exchange(_model(), n_replicas=R_GLOBAL)
+        res = ann.anneal_replica_exchange(_model(), n_replicas=R_GLOBAL)
         q.put((rank, dict(best=res.best_energy, cfg=res.best_configuration.numpy(), hist=res.energy_history,
                           meta=res.metadata)))
     except Exception as exc:  # noqa: BLE001 - reported to the parent
-        q.put((rank, dict(error=f"{type(exc).__name__}: {exc}")))
+        q.put((rank, dict(error=f"{type(exc).__name__}: {exc}", made=len(ann.made), left_open=len(ann._engines),
+                          closed=[getattr(e, "closed", False) for e in ann.made])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -204,6 +221,8 @@ def test_multi_gpu_annealer_refuses_ranks_with_different_couplings():
     got = _class_ranks(2, corrupt_rank=1)
     for rank in (0, 1):
         assert "error" in got[rank] and "different couplings" in got[rank]["error"], got[rank]
+        # the refusal is an ordinary exit path: the engine that was made is closed, none is left for cleanup()
+        assert got[rank]["made"] == 1 and got[rank]["closed"] == [True] and got[rank]["left_open"] == 0, got[rank]
 
 
 def test_multi_gpu_annealer_interface_of_the_reference():
