@@ -349,11 +349,6 @@ int sga_set_field_cache(sga_engine *e, int mode);
  *                           between the accepting sites, the rows applied two at a time (csrc/sweep_clfb_impl.h).  Same
  *                           chain.  2 = while the hottest replica accepts more than ~1 % of its proposals (where the
  *                           form is ahead), 1 = always, 0 = never                               [sweep; SGA_CLF_BATCHED]
- *   "clf_chain"             0 (default) | 1   cached-field sweep under production arguments in the chain-wave form: one
- *                           wave walks the chain over the few candidates that can accept within a window's flip
- *                           budget, three waves keep the field array up to date (csrc/sweep_clfc_impl.h).  Same
- *                           chain; measured no faster than the windowed form, hence opt-in            [sweep; SGA_CLF_CHAIN]
- *   "clf_flips"             12 (default), 1 ... 64: accepted proposals per window of that form      [sweep; SGA_CLF_FLIPS]
  *   "replica_routing"       0 | 1 (default)   SGA_FIELD_CACHE_AUTO routes each replica by its own acceptance (two
  *                           concurrent launches) instead of the whole launch by the hottest replica    [sweep; SGA_NO_REPLICA_ROUTING]
  *   "batched_energy"        0 = one pass over the couplings per replica, 1 (default) = all replicas in one pass where

@@ -31,7 +31,7 @@ int fail(int code, const std::string &msg) {
 enum Opt {
     OPT_LOOK_AHEAD, OPT_CLF_WAVES, OPT_SPARSE_ROUTE, OPT_BATCHED_ENERGY, OPT_FORCE_GENERAL, OPT_CSR_UPDATES_PER_STEP,
     OPT_TSP_PARALLEL, OPT_FORCE_CSR_BITS, OPT_CSR_BITS, OPT_CSR_SLOTS, OPT_HALF_TABLE, OPT_FORCE_CSR_ACC,
-    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_CLF_CHAIN, OPT_CLF_FLIPS, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_CLF_BATCHED,
+    OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_CLF_BATCHED,
     OPT_CLF_TAIL_WAVES, OPT_COUNT
 };
 struct OptDef {
@@ -56,8 +56,6 @@ constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"force_csr_acc", "SGA_FORCE_CSR_ACC", 0, 0, 0, 0, 3},
     {"force_dense_canonical", "SGA_FORCE_DENSE_CANON", 1, 1, 0, 0, 1},
     {"zero_slot_every", "SGA_ZERO_SLOT_EVERY", 0, 0, 0, 0, 1ll << 21},
-    {"clf_chain", "SGA_CLF_CHAIN", 1, 1, 0, 0, 1},
-    {"clf_flips", "SGA_CLF_FLIPS", 0, 0, 12, 1, 64},
     {"replica_routing", "SGA_NO_REPLICA_ROUTING", 1, 0, 1, 0, 1},
     {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536},
     {"clf_batched", "SGA_CLF_BATCHED", 0, 0, 2, 0, 2},
@@ -218,7 +216,7 @@ struct sga_engine {
     bool from_dense = false;  // CSR problem built from a sparse matrix handed over dense (sga_set_dense, SGA_J_AUTO)
     bool clf_problem = false;  // dense, one model, J and h integer valued, symmetric, zero diagonal, sums < 2^24
     float row_abs_max = 0.0f;  // max_i(sum_j |J_ij| + |h_i|)
-    int j_abs_max = 0;         // ceil(max |J_ij|): the most one flip moves another site's field (chain-wave form)
+    int j_abs_max = 0;         // ceil(max |J_ij|): the most one flip moves another site's field (several accepts per round: sweep_clfb_impl.h)
     // ... of CSR problems (sweep_clf_csr.hip): integer J, rows strictly sorted, max_i sum_j |J_ij| < 2^15, the accept
     // table applies, dE of the rule == energy change; the fields are then D = J s as int16, h stays outside
     bool clf_csr_problem = false;
@@ -1953,12 +1951,12 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
     int n_clf = clf ? R : 0;  // replicas on the cached-field kernel in this call
     const bool is_auto = e->field_cache == SGA_FIELD_CACHE_AUTO;
     const int clf_waves_std = (clf && !e->csr) ? sga::sweep_clf_waves(e->ldj, e->want_i8, e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]) : 0;
-    const bool tail_opt = clf && !e->csr && e->opt[OPT_CLF_TAIL_WAVES] != 0 && e->opt[OPT_CLF_WAVES] == 0 && e->opt[OPT_CLF_CHAIN] == 0 &&
+    const bool tail_opt = clf && !e->csr && e->opt[OPT_CLF_TAIL_WAVES] != 0 && e->opt[OPT_CLF_WAVES] == 0 &&
                          clf_waves_std < 8 && e->ldj >= 6 * (e->want_i8 ? 1024 : 256) && e->R >= 16;
     // Option "clf_batched" = 2 (default): the form that commits several accepts per round (sweep_clfb_impl.h) while the
     // hottest replica accepts more than ~1 % of its proposals -- 16 % ahead on the first sweeps from random spins, 10 %
     // at sweeps 5-25 of the 10 000-spin ladder -- and one accept per round below (7 % ahead after 100 sweeps).
-    const bool adaptive = clf && !e->csr && e->opt[OPT_CLF_BATCHED] == 2 && e->opt[OPT_CLF_CHAIN] == 0;
+    const bool adaptive = clf && !e->csr && e->opt[OPT_CLF_BATCHED] == 2;
     auto routing_theta = [&]() -> double {  // break-even acceptance of one replica: t_update (row kernel) / t_accept (cached)
         const double kn = (double)n / 1000.0;
         const double t_upd = e->csr ? 0.20 + 0.0008 * (double)e->nnz / (double)n  // (C4: 0.68, C2b as CSR: 0.36)
@@ -2217,27 +2215,19 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
             ac.ldf = e->ldf;
             ac.field_bits = e->clf_bits;
             ac.field_scale = e->clf_scale;
-            ac.clf_chain = (int)e->opt[OPT_CLF_CHAIN];
-            ac.clf_flips = (int)e->opt[OPT_CLF_FLIPS];
             ac.clf_jmax = e->j_abs_max;
             const int cw = (tail_opt && e->clf_wide)
                                ? 8
                                : sga::sweep_clf_waves(e->ldj, e->want_i8, mixed ? n_clf : e->R, e->cus, (int)e->opt[OPT_CLF_WAVES]);
-            // option "clf_chain": production arguments take the chain-wave form (one wave walks the chain, three keep
-            // the fields up to date: sweep_clfc_impl.h) -- the same chain; measured no faster than the windowed form
-            // (profiles/r04_experiments.md 3), hence opt-in
-            const bool chain = e->opt[OPT_CLF_WAVES] == 0 && sga::sweep_clfc_applies(ac);
             // option "clf_batched": production arguments commit several accepts per round -- every decision of a
             // super-window guessed at once, the guess checked against the few couplings between the accepting sites
             // (sweep_clfb_impl.h); the same chain.  Ahead while the hottest replica accepts more than ~1 % (first sweeps
             // from random spins 2.19 -> 1.72 ms, sweeps 5-25 0.272 -> 0.245), behind after 100 sweeps (0.105 -> 0.112):
             // 2 = by the hottest replica's acceptance (default), 1 = always, 0 = never (profiles/r04_experiments.md 9)
             ac.clf_batched = (e->opt[OPT_CLF_BATCHED] == 1 || (adaptive && e->clf_hot)) ? 1 : 0;
-            const bool batched = !chain && sga::sweep_clfb_applies(ac, e->want_i8);
+            const bool batched = sga::sweep_clfb_applies(ac, e->want_i8);
             auto launch_cached = [&](const sga::SweepArgs &aa, hipStream_t s2) -> hipError_t {
-                return chain     ? sga::launch_sweep_clfc(aa, e->want_i8, s2)
-                       : batched ? sga::launch_sweep_clfb(aa, e->want_i8, cw, s2)
-                                 : sga::launch_sweep_clf(aa, e->want_i8, cw, s2);
+                return batched ? sga::launch_sweep_clfb(aa, e->want_i8, cw, s2) : sga::launch_sweep_clf(aa, e->want_i8, cw, s2);
             };
             if (!mixed) {
                 le = launch_cached(ac, st);

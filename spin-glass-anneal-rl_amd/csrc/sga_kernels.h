@@ -86,8 +86,6 @@ struct SweepArgs {
     int field_bits;      // 16 | 32
     int field_scale;     // 1 | 2 (J integer, h a multiple of 1/2)
     int clf_batched;     // 1: several accepts per round (sweep_clfb_impl.h) where the arguments are the production ones
-    int clf_chain;       // 1: the chain-wave form (sweep_clfc_impl.h) where the arguments are the production ones
-    int clf_flips;       // chain-wave form: accepted proposals per window (the candidate filter's flip budget K)
     int clf_jmax;        // max |J_ij| (integer): the most one flip moves another site's field, in units of 2 scale
     // cached-field sweep of CSR problems (sweep_clf_csr.hip): fields = D [R][ldf] int16, D_i = sum_j J_ij s_j
     const int *clf_hq;   // [n] table_scale * h_i as integers (the static part of the local field)
@@ -152,8 +150,6 @@ hipError_t launch_fields_dense(const FieldsArgs &a, int mode, hipStream_t st);
 hipError_t launch_fields_finish(const FieldsArgs &a, bool y_is_int, hipStream_t st);
 // cached-local-field sweep: dense integer-valued symmetric problems
 hipError_t launch_sweep_clf(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);
-hipError_t launch_sweep_clfc(const SweepArgs &a, bool j_is_i8, hipStream_t st);  // chain-wave form, production arguments
-bool sweep_clfc_applies(const SweepArgs &a);
 hipError_t launch_sweep_clfb(const SweepArgs &a, bool j_is_i8, int waves, hipStream_t st);  // several accepts per round
 bool sweep_clfb_applies(const SweepArgs &a, bool j_is_i8);
 size_t sweep_clfb_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
@@ -165,7 +161,6 @@ size_t sweep_clf_csr_lds_bytes(long long ldf, int sstride, int table_m);
 hipError_t launch_csr_fields_seed(const long long *rowptr, const int2 *cv, const int8_t *spins, int sstride, int n, int R,
                                   short *D, long long ldf, hipStream_t st);
 hipError_t launch_scaled_fields(const float *h, int n, int scale, int *hq, hipStream_t st);
-size_t sweep_clfc_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 size_t sweep_clf_lds_bytes(long long ldf, int field_bits, int sstride, int table_m);
 int sweep_clf_waves(long long ldj, bool j_is_i8, int R, int cus, int forced);
 

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import oracle
+from oracle_follow import follow, ladder_ends
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +42,7 @@ def test_c3_sparse_instance_at_4096_replicas(sg):
     """10 000 spins, CSR degree ~32, 4096 replicas (bench.py --workload c3)."""
     import bench
     csr = bench.make_sparse_instance(10000, 16, 3)
-    n, R, seed, ns = 10000, 4096, 42, 3
+    n, R, seed, ns = 10000, 4096, 42, 10
     h = np.zeros(n, np.float32)
     temps = ladder(R, 10.0, 0.1)
     with sg.AnnealEngine(0) as e:
@@ -59,12 +60,13 @@ def test_c3_sparse_instance_at_4096_replicas(sg):
         swaps = e.exchange()
         assert 0 < swaps <= R // 2 and sorted(e.slot_map()) == list(range(R))
         spins = e.spins()
-    k = 4
+    # the oracle follows the hot end, the middle and the COLD end of the ladder (T = 0.1: accept table at its
+    # boundary, nearly every uphill proposal refused) for all ten sweeps
     prob = oracle.Problem(csr=csr, h=h)
-    s = oracle.init_spins(n, k, seed)
-    ref = oracle.sweeps(prob, s, temps[:k], ns, seed=seed, n_threads=k)
-    assert np.array_equal(out["energy_trace"][:, :k], ref["energy_trace"])
-    assert np.array_equal(spins[:k], s)
+    for r, (trace, s, n_acc) in follow(prob, n, seed, temps, ladder_ends(R, extra=(1, 2, 3, R - 2)), ns).items():
+        assert np.array_equal(out["energy_trace"][:, r], trace), r
+        assert np.array_equal(spins[r], s), r
+        assert acc[r] == n_acc, r
 
 
 # ----------------------------------------------------------------------------- configs[3]
@@ -79,7 +81,8 @@ def test_c4_scheduling_instance_at_1024_replicas_per_gpu(sg):
     n, R, Rg, seed = 50000, 1024, 8192, 31
     temps_g = ladder(Rg, 500.0, 5.0)
     runs = {}
-    for replica0 in (0, 3 * R):  # rank 0's and rank 3's share of the global ladder
+    ns = 10
+    for replica0 in (0, 3 * R, 7 * R):  # rank 0's, rank 3's and rank 7's (the coldest) share of the global ladder
         with sg.AnnealEngine(0) as e:
             e.set_csr(*csr, h)
             e.init_replicas(R, seed=seed, R_global=Rg, replica0=replica0)
@@ -89,21 +92,22 @@ def test_c4_scheduling_instance_at_1024_replicas_per_gpu(sg):
             assert "entries=packed-32bit" in d and "path=half-integer-fast" in d, d
             e.set_ladder(temps_g)
             assert np.array_equal(e.temperatures(), temps_g[replica0:replica0 + R])
-            out = e.sweep(1, energy_trace=True)
+            out = e.sweep(ns, energy_trace=True)
             tracked = e.energies()
             e.recompute_energies()
             # |E| ~ 1e9: the from-scratch value is rounded to fp32 as torch.dot rounds it
             # (core/ising_model.py:161-168), the tracked one is a double sum of exact fp32 dE's
             assert np.allclose(e.energies(), tracked, rtol=1e-6, atol=0)
-            runs[replica0] = (out["energy_trace"], e.spins())
+            runs[replica0] = (out["energy_trace"], e.spins(), e.stats()[0])
+    # the oracle follows the hot end, the middle and the cold end of EVERY share for all ten sweeps: replica
+    # 7 * 1024 + 1023 = 8191 is the coldest of the whole 8192-temperature ladder (T = 5 against couplings of 50..100)
     prob = oracle.Problem(csr=csr, h=h)
-    k = 3
-    for replica0, (trace, spins) in runs.items():
-        s = oracle.init_spins(n, k, seed, replica0=replica0)
-        ref = oracle.sweeps(prob, s, temps_g[replica0:replica0 + k], 1, seed=seed,
-                            replica0=replica0, n_threads=k)
-        assert np.array_equal(trace[:, :k], ref["energy_trace"])
-        assert np.array_equal(spins[:k], s)
+    for replica0, (trace, spins, acc) in runs.items():
+        ids = [replica0 + r for r in ladder_ends(R, extra=(1,))]
+        for g, (ref_trace, s, n_acc) in follow(prob, n, seed, temps_g, ids, ns).items():
+            assert np.array_equal(trace[:, g - replica0], ref_trace), g
+            assert np.array_equal(spins[g - replica0], s), g
+            assert acc[g - replica0] == n_acc, g
 
 
 # ----------------------------------------------------------------------------- configs[4]

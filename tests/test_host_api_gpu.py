@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import oracle
+from oracle_follow import follow, ladder_ends
 from conftest import load_golden
 from oracle_engine import OracleEngine
 
@@ -600,7 +601,10 @@ def test_c2b_assignment_instance_full_size(sg, cache):
         if cache == "sparse":
             assert "updates_per_step=4" in e.describe(), e.describe()
         e.set_ladder(temps)
-        out = e.sweep(3, energy_trace=True)
+        ns, followed = 10, ladder_ends(R)
+        out = e.sweep(ns, energy_trace=True)
+        after = {r: e.spins(r) for r in followed}
+        acc = e.stats()[0]
         if cache == "sparse":
             assert "sweep_csr_rows_kernel" in last_kernel() and "16 entries per lane" in last_kernel(), last_kernel()
         e.exchange()
@@ -609,10 +613,13 @@ def test_c2b_assignment_instance_full_size(sg, cache):
         e.recompute_energies()
         assert np.array_equal(e.energies(), tracked)
         cold = e.spins(R - 1)
+    # the oracle follows the hot end (T = 400), the middle and the COLD end (T = 1 against penalties of 25..50: nearly
+    # every uphill proposal is refused) of the ladder for all ten sweeps
     prob = oracle.Problem(J=b.to_dense(), h=h)
-    s = oracle.init_spins(n, 2, seed)
-    ref = oracle.sweeps(prob, s, temps[:2], 3, seed=seed, n_threads=2)
-    assert np.array_equal(out["energy_trace"][:, :2], ref["energy_trace"])
+    for r, (trace, s, n_acc) in follow(prob, n, seed, temps, followed, ns).items():
+        assert np.array_equal(out["energy_trace"][:, r], trace), r
+        assert np.array_equal(after[r], s), r
+        assert acc[r] == n_acc, r
     x = cold.reshape(100, 100) > 0       # the coldest replica is already nearly one-hot
     assert abs(int(x.sum()) - 100) <= 30
 
