@@ -276,21 +276,36 @@ def pmc_counters(tag, kernel):
     return None, None
 
 
+IC_BYTES = 256 * 1024 * 1024   # Infinity Cache (MI355X_MICROARCH.md)
+IC_GATHER_GBS = 8600.0          # that guide's measured chip-wide rate of random row gathers from an Infinity-Cache-resident
+                                # table (38 MB, 1,152-B rows: 8.6 TB/s); it gives no spec figure for the cache
+
+
 def roofline_block(wl, name, R, avg_launch_s, launches, kernel_inst, copy_gbs=None, read_gbs=None):
     """The `roofline` object of one bench line: algorithmic bytes per launch (one coupling row per
-    attempt) over the HIP-event-timed launch duration, against the HBM spec peak -- unless the committed PMC pass of
-    this configuration shows that the bytes never leave the caches (traffic < 0.2 x algorithmic): then the line
-    reports the bound the kernel really has (vector-instruction issue / the per-update dependent chain), with the
-    issue fraction from the committed instruction counts, and keeps the byte rate as `cache_served_GBs`."""
+    attempt) over the HIP-event-timed launch duration, against the roof the streamed structure really has:
+      * "hbm": the structure is larger than the 256 MiB Infinity Cache -- against the 8 TB/s HBM spec peak.  Between 256
+        and 512 MiB part of every pass is still re-served on chip (`cache_served: true`): the ratio is printed raw, it
+        can exceed 1, and the HBM-only figure is the line's `roofline_beyond_cache`;
+      * "infinity-cache": the structure fits the Infinity Cache (C4: 239 MB, C5 at 100 cities: 32 MB) but not L2 -- against
+        the guide's measured gather rate from an Infinity-Cache-resident table (it has no spec figure); the ratio to the
+        HBM spec number is kept as `frac_of_hbm_spec`;
+      * "valu-issue" / "latency": the committed PMC pass of this configuration shows that the bytes never leave L2
+        (traffic < 0.2 x algorithmic): the line reports vector-instruction issue from the committed instruction counts
+        and keeps the byte rate as `cache_served_GBs`.
+    No ratio is capped."""
     n, csr, implicit, cities, storage = wl["n"], wl["csr"], wl["implicit"], wl["cities"], wl["storage"]
     elem = {"f32": 4, "i8": 1, "t2": 0.25}[storage]
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     if implicit:
         bytes_per_attempt = 8.0 * cities + 8.0       # two fp32 distance rows + the field (its own byte model)
+        structure_bytes = 8.0 * cities * cities      # the two distance tables
     elif csr is None:
         bytes_per_attempt = float(n * elem)          # one coupling row (SURVEY.md 8d)
+        structure_bytes = float(n) * n * elem
     else:
         bytes_per_attempt = float(len(csr[1])) / n * 8.0 + 8.0   # deg*(val+idx) + row extent
+        structure_bytes = float(len(csr[1])) * 8.0
     algo = per_launch_attempts * bytes_per_attempt
     achieved = algo / avg_launch_s / 1e9 if launches else 0.0
     # the committed PMC passes were taken on exactly these configurations
@@ -314,60 +329,84 @@ def roofline_block(wl, name, R, avg_launch_s, launches, kernel_inst, copy_gbs=No
     counters, counters_src = pmc_counters(pmc_tag, kernel_name)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-         "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+         "traffic_unit": "fabric-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes): HBM and "
+                         "Infinity Cache together -- the counters sit at L2's far side",
          "traffic_source": traffic_src,
-         "algorithmic_bytes_per_launch": algo,
+         "algorithmic_bytes_per_launch": algo, "structure_bytes": structure_bytes,
          "kernel": kernel_name, "kernel_instantiation": kernel_inst,
          "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
          "algorithmic_bytes_per_attempt": bytes_per_attempt}
+    if traffic_src:  # which instantiation the committed profile holds (the autotuner's pick is deterministic: ties -> fewest waves)
+        try:
+            with open(os.path.join(ROOT, traffic_src)) as f:
+                r["traffic_source_note"] = json.load(f).get("note")
+        except (OSError, ValueError):
+            pass
     if copy_gbs:
         r["measured_stream_copy_GBs"] = copy_gbs
         r["frac_of_measured_stream_copy"] = achieved / copy_gbs
     if read_gbs:
         r["measured_stream_read_GBs"] = read_gbs
         r["frac_of_measured_stream_read"] = achieved / read_gbs
-    nbytes = None if csr is None else float(len(csr[1])) * 8.0
-    cache_resident = (traffic is not None and traffic < 0.2 * algo) or (traffic is None and implicit) or \
-                     (traffic is None and nbytes is not None and nbytes < 3.0e7)
-    if cache_resident:
-        # not an HBM-bound kernel: the bytes are served by L2 / the Infinity Cache.  What bounds it is how fast the
-        # SIMDs issue its (dependent) instruction stream: report the vector-issue fraction from the committed
-        # instruction counts of the same configuration -- wave-instructions x 2 cycles over SIMD-cycles of the launch
+    l2_resident = (traffic is not None and traffic < 0.2 * algo) or (traffic is None and structure_bytes < 3.0e7)
+    if l2_resident or implicit:
+        # not a bandwidth-bound kernel: the bytes are served by L2 (implicit TSP form: L2 and the Infinity Cache, half
+        # each).  What paces it is how fast the SIMDs get through its (dependent) instruction stream: the vector-issue
+        # fraction from the committed instruction counts of the same configuration -- wave-instructions x cycles per
+        # instruction over SIMD-cycles of the launch.  profiles/r05_valu_issue_probe.txt: v_add / v_fma / v_and hold a
+        # SIMD for 2 cycles, VOP3 / DPP / compare / convert / dot4 / readlane forms for 4 -- `frac` is the 2-cycle figure
+        # (a lower bound), `frac_at_4_cycles_per_instruction` the upper one.
         r["cache_served_GBs"] = achieved
-        r["bound"] = "valu-issue" if kernel_name in ("sweep_csr_rows_kernel",) else "latency"
+        r["cache_served"] = True
+        r["bound"] = "valu-issue" if kernel_name in ("sweep_csr_rows_kernel", "sweep_tsp_par_kernel") else "latency"
         valu = (counters or {}).get("SQ_INSTS_VALU")
         issue_peak = SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9   # G wave-instructions / s
         if valu and launches:
             rate = valu / avg_launch_s / 1e9
-            r.update(achieved=rate, peak=issue_peak, unit="G wave-instr/s (VALU)", frac=min(rate / issue_peak, 1.0),
+            r.update(achieved=rate, peak=issue_peak, unit="G wave-instr/s (VALU)", frac=rate / issue_peak,
                      issue_counters_source=counters_src, valu_wave_instructions_per_launch=valu,
                      salu_wave_instructions_per_launch=(counters or {}).get("SQ_INSTS_SALU"),
                      lds_wave_instructions_per_launch=(counters or {}).get("SQ_INSTS_LDS"),
-                     frac_at_4_cycles_per_instruction=min(2.0 * rate / issue_peak, 1.0))
+                     frac_at_4_cycles_per_instruction=2.0 * rate / issue_peak)
+            wc = (counters or {}).get("SQ_WAVE_CYCLES")
+            if wc:  # where a wave's time goes (quad-cycles of its lifetime; MI355X_MICROARCH.md, rocprofv3 PMC slots)
+                r["wave_time_shares"] = {
+                    "waiting (s_waitcnt / barrier)": (counters.get("SQ_WAIT_ANY") or 0.0) / wc,
+                    "issue stalled": (counters.get("SQ_WAIT_INST_ANY") or 0.0) / wc,
+                    "instruction in flight": (counters.get("SQ_ACTIVE_INST_ANY") or 0.0) / wc,
+                    "of which VALU": (counters.get("SQ_ACTIVE_INST_VALU") or 0.0) / wc,
+                    "of which scalar": (counters.get("SQ_ACTIVE_INST_SCA") or 0.0) / wc,
+                    "of which LDS": (counters.get("SQ_ACTIVE_INST_LDS") or 0.0) / wc}
         else:
             r.update(achieved=None, peak=issue_peak, unit="G wave-instr/s (VALU)", frac=None)
         r["note"] = ("cache resident (PMC traffic far below the algorithmic bytes): paced by " +
-                     ("vector-instruction issue (several updates per step, one per row of lanes: sweep_csr_rows.hip)"
+                     ("vector-instruction issue and the dependent chain of a step (sweep_csr_rows.hip / sweep_tsp.hip; "
+                      "profiles/r05_experiments.md has the per-step cycle budget)"
                       if r["bound"] == "valu-issue" else
                       "the dependent chain of one update (reduction, barrier, decision)") +
-                     ", not by HBM; `frac` = VALU wave-instructions x 2 cycles / SIMD-cycles of the launch (SIMD-32: a "
-                     "wave64 instruction issues over 2 cycles), `cache_served_GBs` = algorithmic bytes / launch time")
+                     ", not by HBM; `frac` = VALU wave-instructions x 2 cycles / SIMD-cycles of the launch, "
+                     "`cache_served_GBs` = algorithmic bytes / launch time")
         if implicit:
             r["note"] += ("; different byte model from the graded CSR figure: the couplings are never stored, an attempt "
                           f"reads two {4 * cities}-byte rows of the scaled distance table "
-                          f"({8 * cities ** 2 / 1e6:.0f} MB); the same chain as the CSR form, bit for bit")
+                          f"({8 * cities ** 2 / 1e6:.0f} MB: L2 and Infinity Cache); the same chain as the CSR form, bit for bit")
+    elif structure_bytes <= IC_BYTES:
+        r.update(bound="infinity-cache", peak=IC_GATHER_GBS, frac=achieved / IC_GATHER_GBS, cache_served=True,
+                 frac_of_hbm_spec=achieved / HBM_PEAK_GBS,
+                 peak_source="MI355X_MICROARCH.md, 'Indexed rows': random rows of a 38 MB table (Infinity Cache) gathered at "
+                             "8.6 TB/s chip-wide -- measured; the guide has no spec figure for the cache")
+        r["note"] = (f"streamed structure = {structure_bytes / 1e6:.0f} MB <= 256 MiB: re-read from the Infinity Cache every sweep "
+                     "(beyond L2: the fabric-side counters see every byte), not from HBM -- bandwidth bound against that "
+                     "cache; the HBM-bound figures are roofline_beyond_cache (dense) and configs.c5_1000_csr (32 GB of CSR)")
     elif csr is not None:
-        r["note"] = (f"CSR structure = {nbytes / 1e6:.0f} MB: streamed from HBM (up to 256 MB partly re-served by the "
-                     "Infinity Cache); bandwidth bound, DESIGN.md 4.2")
+        r["cache_served"] = False
+        r["note"] = (f"CSR structure = {structure_bytes / 1e9:.1f} GB: streamed from HBM; bandwidth bound, DESIGN.md 4.2")
     elif name == "c2a":
+        r["cache_served"] = bool(structure_bytes <= 2 * IC_BYTES)
         r["note"] = (
-            f"{n * n * elem / 1e6:.0f} MB of couplings against a 256 MB Infinity Cache: part of every pass is re-served "
-            "on chip, so this algorithmic rate is a fabric figure and can touch the HBM spec number; the HBM-bound "
-            "figure on a matrix beyond every cache is roofline_beyond_cache")
-    if r["frac"] is not None and r["frac"] > 1.0:   # (a byte rate above the HBM spec: cache served in part)
-        r["cache_served_GBs"] = achieved
-        r["frac"] = 1.0
-        r["frac_note"] = "algorithmic rate above the HBM spec figure (part of the matrix is re-served on chip): capped at 1"
+            f"{structure_bytes / 1e6:.0f} MB of couplings against a 256 MiB Infinity Cache: part of every pass is re-served "
+            "on chip, so this algorithmic rate is a fabric figure and can touch or pass the HBM spec number (the ratio is "
+            "printed raw); the HBM-bound figure on a matrix beyond every cache is roofline_beyond_cache")
     return r
 
 
@@ -376,7 +415,6 @@ def cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev, exchange_interva
     the engine holds: the same chain bit for bit, a row's entries read only when a proposal is ACCEPTED.  A variant with
     its own byte model -- B = acceptance rate x (deg x 8 + 8) bytes per attempt (last sentence) --
     reported beside the graded one-row-per-proposal figure, never instead of it."""
-    from spin_glass_anneal_rl_amd.engine import last_kernel
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
     n, csr = wl["n"], wl["csr"]
     eng.set_field_cache("on")
@@ -416,7 +454,7 @@ def cached_csr_variant(eng, wl, R, n_ladders, ladder, comm_dev, exchange_interva
     out = {"available": True, "value": val, "unit": "attempts/s", "ms_per_step": dt / steps * 1e3,
            "kernel_ms_per_step": ms / steps, "sweeps": f"{warm}..{warm + steps}", "sweeps_per_launch": exchange_interval,
            "acceptance_rate": rate, "algorithmic_bytes_per_attempt": rate * row_bytes,
-           "achieved_GBs": val * rate * row_bytes / 1e9, "kernel_instantiation": last_kernel(), "geometry": eng.describe(),
+           "achieved_GBs": val * rate * row_bytes / 1e9, "kernel_instantiation": eng.last_kernel(), "geometry": eng.describe(),
            "roofline": {"bound": "latency (one serial chain per replica: evaluation rounds + one row fetch per accept)",
                         "byte_model": "B = acceptance rate x (deg x 8 + 8) bytes per attempt", "row_bytes": row_bytes,
                         "achieved": val * rate * row_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -457,7 +495,6 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
     shared stream, identical decisions everywhere); C5 = whole 64-temperature ladders per rank (exchange rounds are
     local: no collective).  Timing: barrier + synchronize on both sides, MAX over ranks."""
     import spin_glass_anneal_rl_amd as sg
-    from spin_glass_anneal_rl_amd.engine import last_kernel
     from spin_glass_anneal_rl_amd.sharded import ShardedTempering
     from spin_glass_anneal_rl_amd import encoders as enc
     t_setup = time.perf_counter()
@@ -511,7 +548,7 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
         dt = float(tmax.item())
     launches, kernel_ms = eng.kernel_time(reset=True)
     eng.enable_timing(False)
-    kernel_inst = last_kernel()
+    kernel_inst = eng.last_kernel()
     what = ("couplings implicit (TSP structure: 2 distance rows per attempt)" if wl["implicit"] else
             f"CSR mean degree {len(wl['csr'][1]) / n:.1f}")
     line = {"workload": (wl["label"] or f"C3: {n}-spin CSR +-1 Ising") +
@@ -736,15 +773,18 @@ def main():
     pt = tempering()
     implicit = a.workload == "c5" and a.implicit
     autotuned = (not a.no_autotune) and csr is None and a.waves == 0 and not implicit
+    autotune_ms = None
     if autotuned:
         if dist is None:
             eng.autotune()  # keeps its winner; sweeps per launch stay as set above
+            autotune_ms = eng.autotune_table()
         else:
             # every rank times the SAME geometry: rank 0 measures, its winner is broadcast (results do
             # not depend on the geometry, the pace of the slowest rank would)
             w = torch.zeros(1, dtype=torch.int32, device=comm_dev)
             if rank == 0:
                 eng.autotune()
+                autotune_ms = eng.autotune_table()
                 w[0] = eng.geometry()[0]
             dist.broadcast(w, src=0)
             eng.set_tuning(waves_per_replica=int(w.item()), sweeps_per_launch=1)
@@ -825,8 +865,7 @@ def main():
     per_launch_attempts = float(R) * n  # one sweep per launch on this rank
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
     best_e, _, _ = eng.best(with_spins=False)
-    from spin_glass_anneal_rl_amd.engine import last_kernel
-    kernel_inst = last_kernel()  # template arguments of what the timed steps launched
+    kernel_inst = eng.last_kernel()  # template arguments of what the timed steps launched (this engine's)
     roof = roofline_block(wl, a.workload, R, avg_launch_s, launches, kernel_inst, copy_gbs, read_gbs)
 
     out = {
@@ -862,6 +901,9 @@ def main():
                    "coupling_storage": "implicit-tsp" if implicit else (a.storage if csr is None else "csr"),
                    "geometry": geometry,
                    "geometry_autotuned": autotuned,
+                   # what the autotuner measured (ms per sweep by waves x chunks per wave); ties within 1 % go to the fewest
+                   # waves, so the pick is the same on every box whose timings agree to that
+                   "autotune_ms": autotune_ms,
                    "best_energy_rank0": best_e},
         "roofline": roof,
     }
@@ -944,10 +986,10 @@ def main():
 
         clf_steps(a.warmup)
         first = clf_timed(a.steps)          # the same sweeps the headline times
-        first["kernel_instantiation_these_sweeps"] = last_kernel()   # (the engine picks the form by the hottest replica's acceptance)
+        first["kernel_instantiation_these_sweeps"] = eng.last_kernel()   # (the engine picks the form by the hottest replica's acceptance)
         clf_steps(max(0, 100 - done))
         later = clf_timed(a.steps)          # after 100 sweeps of the same ladder
-        later["kernel_instantiation_these_sweeps"] = last_kernel()
+        later["kernel_instantiation_these_sweeps"] = eng.last_kernel()
         later["one_sweep_per_launch"] = clf_timed(a.steps, per_launch=1)
         tracked = eng.energies()
         eng.recompute_energies()
@@ -957,7 +999,7 @@ def main():
             "sweeps_per_launch": f"up to the next exchange round (interval {a.exchange_interval})",
             "after_100_sweeps": later,
             "tracked_energy_equals_recomputed": exact,
-            "kernel_instantiation": last_kernel(), "geometry": eng.describe(),
+            "kernel_instantiation": eng.last_kernel(), "geometry": eng.describe(),
             "roofline": {"bound": "latency (one serial chain per replica: evaluation rounds + one row fetch per "
                                   "accept)", "byte_model": "B = acceptance rate x row bytes per attempt",
                          "row_bytes": row_bytes, "achieved": first["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -1031,7 +1073,7 @@ def main():
             "spins": nb, "coupling_bytes": float(nb) * nb * 4.0, "replicas": R,
             "algorithmic_bytes_per_launch": algo, "launches": lb, "avg_launch_ms": msb / max(lb, 1),
             "value": float(R) * nb * 2 / dtb, "unit_value": "attempts/s", "geometry": eng.describe(),
-            "kernel": "sweep_dense_kernel"}
+            "kernel": "sweep_dense_kernel", "kernel_instantiation": eng.last_kernel(), "cache_served": False}
         eng.set_dense(J, h, storage=a.storage)  # back to the headline instance (cpu_baseline replays on it)
     substitute = None
     if csr is not None and csr[0] is None and not implicit and rank == 0 and world == 1 and not a.no_cpu_baseline:

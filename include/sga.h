@@ -335,7 +335,9 @@ int sga_set_field_cache(sga_engine *e, int mode);
  * environment is read once, in sga_create, for the defaults (variable in brackets); afterwards only these calls
  * count, so two engines of one process can run different forms.  SGA_ERR_INVALID: unknown key, value out of range.
  * When a value takes effect: [set] at the next sga_set_dense / sga_set_csr, [init] at the next sga_init_replicas,
- * [sweep] at the next sga_sweep / sga_recompute_energies.
+ * [sweep] at the next sga_sweep / sga_recompute_energies.  A [set] option changed while couplings are set, or an
+ * [init] option changed while replicas exist, cannot act on them any more: sga_sweep then refuses (SGA_ERR_INVALID,
+ * naming the key) until the couplings / replicas are set up again -- it never silently runs the form the old value chose.
  *   "look_ahead"            0 | 1 (default)   dense integer problems: several updates reduced together  [sweep; SGA_NO_LOOK_AHEAD]
  *   "force_general"         0 (default) | 1   general kernel builds even for production arguments       [sweep; SGA_FORCE_GENERAL]
  *   "clf_waves"             0 = measured table (default), 1 ... 16 (capped at 8): waves per replica of the windowed cached-field
@@ -378,10 +380,69 @@ int sga_set_tuning(sga_engine *e, int waves_per_replica, int sweeps_per_launch);
  * current replicas (a few sweeps each) and keeps the fastest -- dense problems: waves per replica; CSR problems
  * (round 4): waves per replica x several updates per step or one, i.e. every form sga_init_replicas chooses between
  * by thresholds (the state travels through the geometry-independent blob of sga_export_state).  The chain does not
- * depend on the form and the replicas' state, best states and counters are restored, so results are unaffected;
- * timing statistics are reset.  No-op for sga_set_tsp problems.
+ * depend on the form and the replicas' state, best states, counters and kernel-timing statistics are restored, so
+ * results are unaffected.  Candidates within 1 % of the fastest are a tie, which goes to the fewest waves / the simpler
+ * form (a fixed preference order: other boxes and later profiles see the same pick).  The pick stays as
+ * sga_set_tuning / option "csr_updates_per_step" would have set it (readable through sga_get_geometry /
+ * sga_get_option).  No-op for sga_set_tsp problems.
  * (No reference counterpart: the reference has no launch geometry.) */
 int sga_autotune(sga_engine *e, double *best_ms_per_sweep);
+/* What the last sga_autotune of this engine measured: "candidate=ms per sweep;..." (dense: "<waves>x<chunks per wave>",
+ * the first entry "heuristic:..." being the untuned choice; CSR: the kernel instantiation).  Empty before. */
+int sga_get_autotune_table(sga_engine *e, char *buf, int buflen);
+
+/* ---- form selection, inspectable without a GPU ---------------------------------------------------------------
+ * WHICH kernel form sweeps a problem (never what it computes) is a pure function of the problem's traits -- what the
+ * set-time scans found -- the replica count, the tuning and the options: csrc/sga_route.cpp, a translation unit
+ * without a device call.  The engine fills a sga_route_query from its own state and asks that function; tests fill
+ * one by hand and pin the answer (tests/test_host_logic.py: the five BASELINE configs and the fuzz shapes).
+ * (No reference counterpart: the reference has one code path, core/spin_dynamics.py:61-152.) */
+#define SGA_ROUTE_DENSE 0
+#define SGA_ROUTE_CSR 1
+#define SGA_ROUTE_TSP 2
+#define SGA_ROUTE_MAX_OPTS 32
+typedef struct sga_route_query {
+    int32_t kind;         /* SGA_ROUTE_DENSE | SGA_ROUTE_CSR | SGA_ROUTE_TSP (sga_set_tsp) */
+    int32_t n;            /* spins */
+    int32_t n_models;     /* dense batches (sga_set_dense_batch), else 1 */
+    int32_t R_local;      /* replicas on this engine (0: none yet) */
+    int32_t cus;          /* compute units of the device (MI355X: 256) */
+    int32_t tune_waves;   /* sga_set_tuning waves_per_replica (0 = heuristic) */
+    int32_t field_cache;  /* SGA_FIELD_CACHE_* */
+    /* what the set-time scans found */
+    int32_t storage;      /* dense: SGA_J_F32 | SGA_J_I8 | SGA_J_T2 as resolved; CSR: SGA_CSR_STORAGE_* as requested */
+    int32_t acc;          /* dense: 0 fp32 (exact) | 1 fp64, any order | 2 fp64 canonical order;
+                             CSR: 0 fp32 + accept table | 1 fp32 | 2 fp64 | 3 fp64 canonical */
+    int32_t table_m;      /* entries of the accept table (integer problems), 0 = none */
+    int32_t table_scale;  /* 2: half-integer fields, table at twice the resolution */
+    int32_t clf_ok;       /* the problem qualifies for the cached-local-field sweep (integer, symmetric, ...) */
+    int32_t clf_bits;     /* dense: 16 | 32-bit resident fields */
+    int32_t clf_scale;    /* dense: 2 = half-integer fields */
+    int32_t from_dense;   /* CSR taken from a sparse matrix handed over dense */
+    /* CSR structure */
+    int64_t nnz;          /* entries (TSP: 4 (cities - 1) n) */
+    int64_t max_row_len;  /* entries of the longest row */
+    int64_t layout_entries; /* entries of the layout the kernels read (padding included) */
+    int32_t slotted;      /* rows padded to whole 64-entry slots */
+    int32_t rowptr32;     /* the layout has < 2^31 entries: 32-bit extents exist */
+    int32_t packed_ok;    /* every entry fits the packed form (integer |J| <= 127, n < 2^24) */
+    int32_t n_cities;     /* TSP */
+    /* as laid out (0 = derive from the rest) */
+    int32_t sstride;      /* spin stride of the replicas */
+    int32_t reserved_;
+    int64_t ldj;          /* dense: row stride of the packed couplings in elements */
+    int64_t opt[SGA_ROUTE_MAX_OPTS]; /* option values, index = sga_option_name order */
+} sga_route_query;
+/* zeroes *q and fills the option defaults (the environment is NOT consulted), cus = 256, n_models = 1 */
+int sga_route_query_init(sga_route_query *q);
+/* one line naming every decision for q: "dense storage=... waves=... chunks_per_wave=... kernel=..." |
+ * "csr form=rows|narrow|narrow-bits|wide-bits|wide-bytes spins=... waves=... updates_per_step=..." | "tsp waves=... passes=..."
+ * followed by " cached=..." (what sga_set_field_cache would run).  Pure: no device needed. */
+int sga_explain_route(const sga_route_query *q, char *buf, int buflen);
+/* the query the engine itself would pose for its current problem / replicas / options */
+int sga_get_route_query(sga_engine *e, sga_route_query *out);
+/* the instantiation this ENGINE's last sweep launch ran (sga_last_kernel: this thread's last launch of any engine) */
+int sga_get_last_kernel(sga_engine *e, char *buf, int buflen);
 
 #ifdef __cplusplus
 }

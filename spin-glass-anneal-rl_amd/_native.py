@@ -18,9 +18,29 @@ SITE_RANDOM, SITE_SEQUENTIAL, SITE_REPLAY = 0, 1, 2
 ARITH_F64, ARITH_F32 = 0, 1
 RULE_METROPOLIS, RULE_GLAUBER, RULE_HEAT_BATH, RULE_WOLFF = 0, 1, 2, 3
 
-# every symbol include/sga.h declares: (name, restype, argtypes)
 _p, _i, _i64, _u64, _u32, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_double
+
+ROUTE_DENSE, ROUTE_CSR, ROUTE_TSP = 0, 1, 2
+ROUTE_MAX_OPTS = 32
+
+
+class RouteQuery(C.Structure):
+    """sga_route_query (include/sga.h): a problem's traits, replica count, tuning and options -- what the form
+    selection (csrc/sga_route.cpp, no device call) is a pure function of."""
+    _fields_ = [(k, C.c_int32) for k in ("kind", "n", "n_models", "R_local", "cus", "tune_waves", "field_cache", "storage",
+                                         "acc", "table_m", "table_scale", "clf_ok", "clf_bits", "clf_scale", "from_dense")] + \
+               [("nnz", C.c_int64), ("max_row_len", C.c_int64), ("layout_entries", C.c_int64)] + \
+               [(k, C.c_int32) for k in ("slotted", "rowptr32", "packed_ok", "n_cities", "sstride", "reserved_")] + \
+               [("ldj", C.c_int64), ("opt", C.c_int64 * ROUTE_MAX_OPTS)]
+
+
+# every symbol include/sga.h declares: (name, restype, argtypes)
 SYMBOLS = [
+    ("sga_route_query_init", _i, [C.POINTER(RouteQuery)]),
+    ("sga_explain_route", _i, [C.POINTER(RouteQuery), C.c_char_p, _i]),
+    ("sga_get_route_query", _i, [_p, C.POINTER(RouteQuery)]),
+    ("sga_get_last_kernel", _i, [_p, C.c_char_p, _i]),
+    ("sga_get_autotune_table", _i, [_p, C.c_char_p, _i]),
     ("sga_create", _i, [_i, C.POINTER(_p)]),
     ("sga_destroy", None, [_p]),
     ("sga_last_error", C.c_char_p, []),
@@ -125,3 +145,34 @@ def check(rc: int, what: str = "") -> None:
     if rc == ERR_MEMORY:
         raise ResourceError(msg, {"code": rc})
     raise AnnealingError(msg, {"code": rc})
+
+
+def option_names():
+    """The option keys in sga_option_name order (= the index into sga_route_query.opt)."""
+    names, buf, i = [], C.create_string_buffer(64), 0
+    while lib().sga_option_name(i, buf, 64) == OK:
+        names.append(buf.value.decode())
+        i += 1
+    return names
+
+
+def route_query(**fields) -> RouteQuery:
+    """A sga_route_query with the defaults of sga_route_query_init (no environment), then `fields`; `options` = {key: value}."""
+    q = RouteQuery()
+    check(lib().sga_route_query_init(C.byref(q)), "sga_route_query_init")
+    opts = fields.pop("options", None) or {}
+    names = option_names()
+    for k, v in opts.items():
+        q.opt[names.index(k)] = int(v)
+    for k, v in fields.items():
+        if k not in dict(RouteQuery._fields_):
+            raise AnnealingError(f"sga_route_query has no field {k!r}")
+        setattr(q, k, int(v))
+    return q
+
+
+def explain_route(q: RouteQuery) -> str:
+    """The form selection's answer for q, one line (sga_explain_route): works without a GPU."""
+    buf = C.create_string_buffer(1024)
+    check(lib().sga_explain_route(C.byref(q), buf, 1024), "sga_explain_route")
+    return buf.value.decode()

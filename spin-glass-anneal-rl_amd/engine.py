@@ -168,6 +168,17 @@ class AnnealEngine:
         N.check(self._lib.sga_autotune(self._h, C.byref(ms)), "sga_autotune")
         return float(ms.value)
 
+    def autotune_table(self) -> dict:
+        """{candidate: kernel ms per sweep} of the last autotune() (dense: "<waves>x<chunks per wave>")."""
+        buf = C.create_string_buffer(4096)
+        N.check(self._lib.sga_get_autotune_table(self._h, buf, 4096), "sga_get_autotune_table")
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.rsplit("=", 1)
+                out[k] = float(v)
+        return out
+
     def maybe_autotune(self, n_sweeps: int, setting: Optional[bool] = None) -> bool:
         """Host-loop helper: autotune when asked to (`setting=True`), never when `False`, and by
         default (`None`) only when the run is long enough to pay for the ~30 trial sweeps."""
@@ -467,6 +478,23 @@ class AnnealEngine:
         N.check(self._lib.sga_get_slot_map(self._h, out.ctypes.data_as(C.c_void_p)),
                 "sga_get_slot_map")
         return out
+
+    def route_query(self):
+        """The query the engine itself poses to the form selection (sga_get_route_query)."""
+        q = N.RouteQuery()
+        N.check(self._lib.sga_get_route_query(self._h, C.byref(q)), "sga_get_route_query")
+        return q
+
+    def explain_route(self) -> str:
+        """What csrc/sga_route.cpp answers for this engine's problem, replicas and options."""
+        return N.explain_route(self.route_query())
+
+    def last_kernel(self) -> str:
+        """The kernel instantiation THIS engine's last sweep launched (sga_get_last_kernel; per engine, so that two
+        engines on two threads do not see each other's)."""
+        buf = C.create_string_buffer(512)
+        N.check(self._lib.sga_get_last_kernel(self._h, buf, 512), "sga_get_last_kernel")
+        return buf.value.decode()
 
     def exchange_stats(self):
         a, b = np.zeros(self.R_global, np.int64), np.zeros(self.R_global, np.int64)

@@ -281,3 +281,62 @@ def test_memory_optimizer_keeps_the_reference_method_names():
     assert opt.memory_pool == {}
     st = opt.get_memory_stats()
     assert set(st) == {"device", "memory_allocated", "memory_reserved", "max_memory_allocated", "memory_stats"} and st["memory_allocated"] == 0
+
+
+# ----------------------------------------------------------------------------- form selection (csrc/sga_route.cpp)
+def _route_cases():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "route_table.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_route_table():
+    """WHICH kernel form sweeps a problem is a pure function (csrc/sga_route.cpp, no device call) of the traits the
+    set-time scans report, the replica count, the tuning and the options.  tests/golden/route_table.json holds, for the
+    five BASELINE configs as bench.py builds them and for 30 shapes drawn like the fuzz's, the query a real engine posed
+    on an MI355X and the answer (profiles/r05_route_table.py, which also checked the answer against sga_describe and the
+    launched kernel): the same queries must get the same answers here, without a GPU -- a threshold edit that reroutes
+    one of them fails this test."""
+    from spin_glass_anneal_rl_amd import _native as N
+    cases = _route_cases()
+    assert sum(c["name"].startswith("BASELINE") for c in cases) == 5 and sum(c["name"].startswith("fuzz") for c in cases) >= 20
+    for c in cases:
+        q = N.route_query(**c["query"])
+        assert N.explain_route(q) == c["explain"], c["name"]
+    # what the table says about the BASELINE configs, in words
+    by = {c["name"].split(":")[0]: c["explain"] for c in cases if c["name"].startswith("BASELINE")}
+    assert by["BASELINE c2a"].startswith("dense storage=f32 acc=f32 waves=8 chunks_per_wave=5 ")       # (the heuristic; bench.py autotunes)
+    assert "form=rows spins=int8 waves=1 replicas_per_block=4 updates_per_step=4" in by["BASELINE c3"]
+    assert "form=wide-bits spins=bits waves=2" in by["BASELINE c4"] and "slots=1" in by["BASELINE c4"]
+    assert "form=wide-bits spins=bits waves=1" in by["BASELINE c5"]
+    assert by["BASELINE c5_1000_implicit"].startswith("tsp n_cities=1000 waves=2 passes=2")
+    # configs[4] at 1000 cities with its 32 GB of CSR written out (traits as tests/test_baseline_configs_gpu.py sees them)
+    q = N.route_query(kind=N.ROUTE_CSR, n=10 ** 6, R_local=256, nnz=3996 * 10 ** 6, max_row_len=3996, layout_entries=4032 * 10 ** 6,
+                      slotted=1, rowptr32=0, acc=2, table_m=0)
+    assert N.explain_route(q).startswith("csr form=wide-bits spins=bits waves=8 replicas_per_block=1 ")
+    # ... and C4 as the engine takes it by itself (entries packed to one dword; bench.py's graded line asks for fp32 values)
+    c4 = next(c for c in cases if c["name"].startswith("BASELINE c4"))
+    q = N.route_query(**{**c4["query"], "storage": 0, "packed_ok": 1})
+    assert "entries=packed" in N.explain_route(q)
+
+
+def test_route_answers_move_with_their_inputs():
+    """Sanity of the pure function itself: tuning, replica count, options and the field-cache request each change the answer
+    the way include/sga.h says."""
+    from spin_glass_anneal_rl_amd import _native as N
+    c3 = next(c for c in _route_cases() if c["name"].startswith("BASELINE c3"))["query"]
+    base = N.explain_route(N.route_query(**c3))
+    assert "updates_per_step=4" in base
+    assert "form=narrow " in N.explain_route(N.route_query(**{**c3, "options": {"csr_updates_per_step": 0}}))
+    # (a row dealt to four waves: one replica per workgroup; 4096 of them are LDS resident only with the spins as bits)
+    assert "form=wide-bits spins=bits waves=4 replicas_per_block=1" in N.explain_route(N.route_query(**{**c3, "tune_waves": 4}))
+    assert "form=wide-bytes spins=int8 waves=4" in N.explain_route(N.route_query(**{**c3, "tune_waves": 4, "R_local": 512}))
+    assert "spins=bits" in N.explain_route(N.route_query(**{**c3, "options": {"force_csr_bits": 1}}))
+    assert " cached=on(waves=4)" in N.explain_route(N.route_query(**{**c3, "field_cache": 1}))
+    assert " cached=auto(start=rows" in N.explain_route(N.route_query(**{**c3, "field_cache": 2}))
+    dense = dict(kind=N.ROUTE_DENSE, n=10000, R_local=1024, storage=2, acc=0, table_m=2048, clf_ok=1)
+    assert " cached=auto(start=cached" in N.explain_route(N.route_query(**dense, field_cache=2))
+    assert "waves=13 chunks_per_wave=4" in N.explain_route(N.route_query(**{**dense, "storage": 1, "tune_waves": 13}))
+    assert N.explain_route(N.route_query(kind=N.ROUTE_TSP, n=250000, n_cities=500)).startswith("tsp n_cities=500 waves=2 passes=1")
+    with pytest.raises(Exception):
+        N.explain_route(N.route_query(kind=7, n=10))

@@ -1,0 +1,182 @@
+"""Form selection on real engines: what csrc/sga_route.cpp answers IS what the engine lays out and launches, the pinned
+table (tests/golden/route_table.json) is what engines report today, options are refused where they can no longer act,
+and the kernel name is kept per engine."""
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import spin_glass_anneal_rl_amd as m
+    return m
+
+
+def pm1(n, seed):
+    rng = np.random.RandomState(seed)
+    J = np.triu(rng.randint(0, 2, (n, n)) * 2 - 1, 1).astype(np.float32)
+    return J + J.T
+
+
+def test_the_pinned_route_table_is_what_engines_report_today(sg):
+    """The generator of tests/golden/route_table.json run again: the same 30 fuzz-drawn problems on real engines pose the
+    same queries (set-time scans, layouts), get the same answers, launch the same kernels -- and every answer agrees with
+    sga_describe and the launched kernel (the generator asserts that itself)."""
+    import r05_route_table as gen
+    out = []
+    gen.fuzz_shapes(out)
+    with open(os.path.join(ROOT, "tests", "golden", "route_table.json")) as f:
+        golden = [c for c in json.load(f)["cases"] if c["name"].startswith("fuzz")]
+    assert len(out) == len(golden) >= 20
+    for now, then in zip(out, golden):
+        assert now["name"] == then["name"]
+        assert now["query"] == then["query"], now["name"]
+        assert now["explain"] == then["explain"] and now["kernel"] == then["kernel"], now["name"]
+
+
+def test_baseline_c3_poses_the_pinned_query(sg):
+    """BASELINE configs[2] as bench.py builds it: the engine's own query equals the table's (the CPU test's input)."""
+    import bench
+    import r05_route_table as gen
+    with open(os.path.join(ROOT, "tests", "golden", "route_table.json")) as f:
+        then = next(c for c in json.load(f)["cases"] if c["name"].startswith("BASELINE c3"))
+    csr = bench.make_sparse_instance(10000, 16, 3)
+    with sg.AnnealEngine(0) as e:
+        e.set_tuning(waves_per_replica=0, sweeps_per_launch=1)
+        e.set_csr(*csr, np.zeros(10000, np.float32))
+        e.set_field_cache("off")
+        e.init_replicas(4096, seed=42)
+        assert gen.query_dict(e.route_query()) == then["query"]
+        assert e.explain_route() == then["explain"]
+
+
+def test_an_option_changed_after_its_stage_is_refused_not_ignored(sg):
+    """[set] options are read by sga_set_*, [init] options by sga_init_replicas (include/sga.h): changed later they cannot
+    act on what is already laid out -- the next sweep says so, naming the key, until the stage is run again."""
+    n = 600
+    J = pm1(n, 3) * (np.random.RandomState(1).rand(n, n) < 0.02)
+    J = np.triu(J, 1)
+    J = (J + J.T).astype(np.float32)
+    rowptr = np.concatenate([[0], np.cumsum((J != 0).sum(1))]).astype(np.int32)
+    col = np.concatenate([np.nonzero(J[i])[0] for i in range(n)]).astype(np.int32)
+    val = np.concatenate([J[i][J[i] != 0] for i in range(n)]).astype(np.float32)
+    h = np.zeros(n, np.float32)
+    with sg.AnnealEngine(0) as e:
+        e.set_csr(rowptr, col, val, h)
+        e.init_replicas(8, seed=1)
+        e.set_temperatures(np.full(8, 2.0))
+        e.sweep(1)
+        assert "spins=lds-int8" in e.describe()
+        e.set_option("force_csr_bits", 1)          # [init]: the replicas are already laid out
+        with pytest.raises(sg.AnnealingError, match="force_csr_bits.*sga_init_replicas"):
+            e.sweep(1)
+        e.init_replicas(8, seed=1)
+        e.set_temperatures(np.full(8, 2.0))
+        e.sweep(1)
+        assert "spins=lds-bits" in e.describe()
+        e.set_option("force_csr_bits", 1)          # the same value again: nothing to refuse
+        e.sweep(1)
+        e.set_option("force_csr_acc", 3)           # [set]: the couplings are already classified
+        with pytest.raises(sg.AnnealingError, match="force_csr_acc.*set them again"):
+            e.sweep(1)
+        e.set_csr(rowptr, col, val, h)
+        e.init_replicas(8, seed=1)
+        e.set_temperatures(np.full(8, 2.0))
+        e.sweep(1)
+        assert "acc=f64-canonical" in e.describe()
+        e.set_option("look_ahead", 0)              # [sweep]: acts at once, never refused
+        e.sweep(1)
+
+
+def test_switching_the_field_cache_mode_forgets_what_the_old_mode_learnt(sg):
+    """AUTO routes replicas by their own acceptance; ON afterwards must put EVERY replica on the cached-field kernel (the
+    routes of the AUTO phase do not survive the switch), with the same chain throughout."""
+    import oracle
+    n, R, seed = 2000, 24, 99
+    J = pm1(n, 8)
+    h = np.zeros(n, np.float32)
+    temps = np.geomspace(60.0, 0.5, R)  # a hot end: AUTO gives those replicas to the row kernels
+    with sg.AnnealEngine(0) as e:
+        e.set_field_cache("auto")
+        e.set_dense(J, h, storage="i8")
+        e.init_replicas(R, seed=seed)
+        e.set_temperatures(temps)
+        e.sweep(12)
+        auto_kernel = e.last_kernel()
+        e.set_field_cache("on")
+        e.sweep(4)
+        assert e.last_kernel().startswith("sweep_clf") and "mixed launch" not in e.last_kernel(), (auto_kernel, e.last_kernel())
+        assert "sweep=cached-local-fields" in e.describe()
+        spins, trace_end = e.spins(), e.energies()
+    s = oracle.init_spins(n, R, seed)
+    ref = oracle.sweeps(oracle.Problem(J=J, h=h), s, temps, 16, seed=seed, n_threads=8)
+    assert np.array_equal(spins, s) and np.array_equal(trace_end, ref["energy_trace"][-1])
+
+
+def test_the_last_kernel_is_kept_per_engine(sg):
+    """Two engines driven from two threads (a documented use): each reports ITS last launch (sga_get_last_kernel), whatever
+    the other thread launched in between."""
+    n = 700
+    J = pm1(n, 5)
+    h = np.zeros(n, np.float32)
+    rowptr = np.arange(0, 2 * n + 1, 2, dtype=np.int32)     # a ring: degree 2
+    col = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], 1).astype(np.int32)
+    col.sort(axis=1)
+    val = np.ones(2 * n, np.float32)
+    with sg.AnnealEngine(0) as a, sg.AnnealEngine(0) as b:
+        a.set_dense(J, h, storage="f32")
+        b.set_csr(rowptr, col.ravel(), val, h)
+        for e in (a, b):
+            e.init_replicas(8, seed=1)
+            e.set_temperatures(np.full(8, 2.0))
+        errs = []
+
+        def run(e, want):
+            try:
+                for _ in range(20):
+                    e.sweep(1)
+                    assert e.last_kernel().startswith(want), (want, e.last_kernel())
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+
+        ta = threading.Thread(target=run, args=(a, "sweep_dense_kernel"))
+        tb = threading.Thread(target=run, args=(b, "sweep_csr_rows_kernel"))
+        ta.start(), tb.start()
+        ta.join(), tb.join()
+        assert not errs, errs
+        assert a.last_kernel().startswith("sweep_dense_kernel") and b.last_kernel().startswith("sweep_csr_rows_kernel")
+
+
+def test_autotune_reports_its_table_and_keeps_the_callers_timing(sg):
+    n, R = 3000, 64
+    J = pm1(n, 11)
+    with sg.AnnealEngine(0) as e:
+        e.set_dense(J, np.zeros(n, np.float32), storage="f32")
+        e.init_replicas(R, seed=3)
+        e.set_temperatures(np.geomspace(10.0, 0.5, R))
+        assert e.autotune_table() == {}
+        e.enable_timing(True)
+        e.sweep(3)
+        before = e.kernel_time(reset=False)
+        assert before[0] >= 1
+        best = e.autotune()
+        table = e.autotune_table()
+        assert len(table) >= 3 and any(k.startswith("heuristic:") for k in table)
+        w, c = e.geometry()
+        picked = [v for k, v in table.items() if k.split(":")[-1] == f"{w}x{c}"]
+        assert picked and min(table.values()) <= min(picked) <= 1.01 * min(table.values()) + 1e-9
+        assert best == pytest.approx(min(table.values()), rel=1e-3)
+        # fewest waves among the candidates within 1 % of the fastest (a fixed preference order)
+        tied = [int(k.split(":")[-1].split("x")[0]) for k, v in table.items() if not k.startswith("heuristic:") and v <= 1.01 * min(table.values())]
+        assert w == min(tied)
+        after = e.kernel_time(reset=False)
+        assert after[0] == before[0] and after[1] == pytest.approx(before[1])   # the trials left the caller's statistics alone
