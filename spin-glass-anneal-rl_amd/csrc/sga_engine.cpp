@@ -805,6 +805,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.csr_row_cap = (e->csr && e->max_row_len <= 256)
                             ? (int)std::max<long long>(e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len, 1) : 0;
         a.csr_pair_ahead = csr_updates_per_step(e);
+        a.wave_prio = (int)e->opt[OPT_CSR_WAVE_PRIO];
         // (option "look_ahead" = 0: A/B switch and the parity tests' cross-check)
         a.look_ahead = e->opt[OPT_LOOK_AHEAD] != 0 ? 1 : 0;
         a.force_general = e->opt[OPT_FORCE_GENERAL] != 0 ? 1 : 0;
@@ -839,6 +840,7 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.rule = e->rule;
         a.table_m = exact_mode ? 0 : e->table_m;
         a.table_scale = e->csr ? e->table_scale : 1;
+        a.table_covers = (e->csr && a.table_m > 0 && (double)e->table_scale * (double)e->csr_row_abs_max <= (double)a.table_m) ? 1 : 0;
         if (a.csr_acc == sga::CSR_ACC_F32_TABLE && a.table_m == 0) a.csr_acc = sga::CSR_ACC_F32;
         a.no_best = exact_mode ? 1 : 0;
         a.reps_per_model = e->n_models > 1 ? e->Rg / e->n_models : 0;

@@ -184,6 +184,7 @@ struct sga_engine {
     // table applies, dE of the rule == energy change; the fields are then D = J s as int16, h stays outside
     bool clf_csr_problem = false;
     float row_j_abs_max = 0.0f;  // max_i sum_j |J_ij|
+    float csr_row_abs_max = 0.0f;  // CSR: max_i (sum_j |J_ij| + |h_i|): no |fk| of a move exceeds it
     int *hq = nullptr;           // [n] table_scale * h_i as integers (built with the first cached sweep)
     int clf_scale = 1, clf_bits = 16;
     void *fields = nullptr;    // [R][ldf] int16 | int32: clf_scale * (J s + h), valid while fields_valid

@@ -269,6 +269,7 @@ int set_csr_common(sga_engine *e, const void *rowptr, bool wide_extents, const i
     // tabulated at twice the resolution)
     e->table_m = 0;
     e->table_scale = 1;
+    e->csr_row_abs_max = m;
     if (!flags[sga::CSR_NOT_INTEGRAL] && m >= 1.0f && m < 16777216.0f) {
         e->table_m = (int)std::min(m, 2048.0f);
     } else if ((flags[sga::CSR_NOT_INTEGRAL] & 5) == 0 && m >= 1.0f && m < 8388608.0f &&

@@ -26,6 +26,8 @@
 // vectorised Philox pass (lane l: block l), re-laid so that lane i holds update i (ds_bpermute); a step
 // picks its G updates with one more permute each.  Sites, row extents and row entries are requested
 // two / one steps ahead (the site sequence is known from the counter RNG).
+#include <type_traits>
+
 #include "sweep_csr_impl.h"
 
 namespace sga {
@@ -164,7 +166,12 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     };
     // this row's decision against the spins as they stand: flips?, dE of the move (table form: 2 fk, fk = s_i
     // (row sum + h), an integer)
-    auto decide = [&](const Step &st, int &si, double &dE) -> bool {
+    // (the mask of a wave-wide predicate, straight from the compare: __ballot() materialises the bool in a VGPR first)
+    auto ballot = [](bool p) -> unsigned long long { return __builtin_amdgcn_ballot_w64(p); };
+    // dE of a move: REAL builds a double; table builds 2 fk as a float (an integer below 2^25: exact), widened only
+    // where a move is accepted
+    using DE = typename std::conditional<REAL, double, float>::type;
+    auto decide = [&](const Step &st, int &si, DE &dE) -> bool {
         const int left = st.end - st.beg - EPL * j;  // entries of the row from this lane's first on
         si = spin_at(st.site);
         if constexpr (REAL) {
@@ -180,7 +187,9 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
                 for (int q = 0; q + stride < EPL; q += 2 * stride) tr[q] += tr[q + stride];
             const float dotr = (float)row_sum(tr[0]);  // rounded to fp32 once (core/ising_model.py:183)
             const float u = (float)st.ru * 0x1.0p-24f;
-            const bool flipr = metropolis_accept(SGA_RULE_METROPOLIS, SGA_ARITH_F64, dotr, si, st.h, 0.0f, T, u, dE);
+            double dEr;
+            const bool flipr = metropolis_accept(SGA_RULE_METROPOLIS, SGA_ARITH_F64, dotr, si, st.h, 0.0f, T, u, dEr);
+            dE = (DE)dEr;
             return st.live != 0 && flipr;
         }
         float fk;
@@ -208,20 +217,25 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         fk = (float)si * (dot + st.h);
         const float fq = fk * (float)a.table_scale;
         const int idx = min(max((int)fq, 0), a.table_m);
-        bool flip = fk <= 0.0f || st.ru < itab[idx];  // u < p on the uniform's raw bits
-        const bool beyond = fq > (float)a.table_m;
-        dE = (double)(2.0f * fk);
-        if (__ballot(beyond)) {  // beyond the table (p == 0 past -104)
-            if (beyond) flip = (dE > T * 104.0) ? false : ((float)st.ru * 0x1.0p-24f < expf_det((float)(-dE / T)));
+        // u < p on the uniform's raw bits.  Entry 0 (fk <= 0: downhill or flat, p = 1) holds 2^24, above every 24-bit
+        // uniform: those moves are accepted by the same compare, no branch around the look-up
+        bool flip = st.ru < itab[idx];
+        dE = (DE)(2.0f * fk);
+        if (!a.table_covers) {  // (wave-uniform: the table holds every move this problem can propose -- C3, C4)
+            const bool beyond = fq > (float)a.table_m;
+            if (ballot(beyond)) {  // beyond the table (p == 0 past -104)
+                const double dEd = (double)(2.0f * fk);
+                if (beyond) flip = (dEd > T * 104.0) ? false : ((float)st.ru * 0x1.0p-24f < expf_det((float)(-dEd / T)));
+            }
         }
         return st.live != 0 && flip;
     };
     constexpr unsigned long long HEADS = G == 4 ? 0x0001000100010001ull : 0x0101010101010101ull;  // lane 0 of every row
     auto step = [&](const Step &st) {
         int si;
-        double dE;
+        DE dE;
         const bool flip = decide(st, si, dE);
-        const unsigned long long acc = __ballot(flip) & HEADS;
+        const unsigned long long acc = ballot(flip) & HEADS;
         // does an accepted update touch a LATER one of the step?  (its site among their columns or their
         // sites; entries past a row's end take part -- a stray hit costs a replay, nothing else)
         unsigned long long hit = 0;
@@ -233,7 +247,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
                     bool mine = st.site == sq;
 #pragma unroll
                     for (int x = 0; x < EPL; ++x) mine = mine || st.e[x].x == sq;
-                    hit |= __ballot(mine && st.live != 0 && g > q);
+                    hit |= ballot(mine && st.live != 0 && g > q);
                 }
             }
         }
@@ -246,13 +260,13 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
                     while (order) {  // chain order
                         const int q = (int)__builtin_ctzll(order);
                         order &= order - 1;
-                        E += read_lane(dE, q);
+                        E += read_lane((double)dE, q);
                     }
                 } else {
                     // dE = 2 fk is an integer: lane 0 of a row keeps the sum of its accepted moves, added to E
                     // at the end of the sweep (exact in any order, far below 2^53; a wave sum per step cost ~14
                     // instructions)
-                    dE_lane += (flip && j == 0) ? dE : 0.0;
+                    dE_lane += (flip && j == 0) ? (double)dE : 0.0;
                 }
                 nacc += (unsigned long long)__builtin_popcountll(acc);
             }
@@ -267,11 +281,11 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
             // operations of a wave execute in order, so no hardware fence is needed, only the reload.)
             asm volatile("" ::: "memory");
             int si2;
-            double dE2;
+            DE dE2;
             const bool flip2 = decide(st, si2, dE2);
-            if ((__ballot(flip2) >> (LPR * q)) & 1ull) {
+            if ((ballot(flip2) >> (LPR * q)) & 1ull) {
                 if (lane == LPR * q) flip_at(st.site, si2);
-                E += read_lane(dE2, LPR * q);
+                E += read_lane((double)dE2, LPR * q);
                 ++nacc;
             }
         }
@@ -303,7 +317,30 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         stage_heads(n1);          // one step ahead: its extents were requested a step ago
         step(c);
     };
+    // Issue priority by acceptance (a.wave_prio, engine option "csr_wave_priority"): every replica is one wave and a
+    // launch lasts as long as its slowest wave -- the hot replicas', whose steps carry the conflict checks, the flips and
+    // the replays.  A SIMD holds waves of four temperatures: the arbiter prefers the one that accepts most
+    // (s_setprio 3 ... 0), the cold ones -- done early anyway -- yield.  Scheduling only: the chain is untouched.
+    unsigned long long nacc_before = 0;
+    if (a.wave_prio) {
+        const unsigned long long done = (unsigned long long)a.sweep0 * (unsigned long long)n;  // attempts before this launch
+        const unsigned long long acc0 = a.n_accepted[r];
+        // (no history yet: everybody at the same priority)
+        const int p = done == 0 ? 0 : (acc0 * 4 >= done ? 3 : (acc0 * 20 >= done ? 2 : (acc0 * 100 >= done ? 1 : 0)));
+        if (p == 3) __builtin_amdgcn_s_setprio(3);
+        else if (p == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    }
     for (int k = 0; k < a.n_sweeps; ++k) {
+        if (a.wave_prio && k > 0) {  // the sweep before this one
+            const unsigned long long d = nacc - nacc_before;
+            const unsigned long long nn = (unsigned long long)n;
+            if (d * 4 >= nn) __builtin_amdgcn_s_setprio(3);
+            else if (d * 20 >= nn) __builtin_amdgcn_s_setprio(2);
+            else if (d * 100 >= nn) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        nacc_before = nacc;
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         // exp(float32(-dE / T)) for dE = 2 q / table_scale as integer thresholds on the uniform's raw bits
         if constexpr (!REAL)

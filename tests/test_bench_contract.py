@@ -136,3 +136,75 @@ def test_round4_headline_carries_the_other_configs_and_honest_roofs():
     assert f"sweep_dense_kernel<float, {m.group(1)}, false, true, {'true' if m.group(2) == '1' else 'false'}, false, false>" in stats
     avg_ms = [float(l.split(",")[-5]) / 1e6 for l in stats.splitlines() if "sweep_dense_kernel" in l][0]
     assert abs(avg_ms / r["avg_launch_ms"] - 1.0) < 0.02
+
+
+def test_round5_line_evidence_lines_up_and_no_ratio_is_capped():
+    import re
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_c2a_f32.json")))
+    r = d["roofline"]
+    # the profiled instantiation IS the line's: the committed profile ran `bench.py --waves <the line's pick>` ...
+    m = re.match(r"sweep_dense_kernel<float, CPW=(\d+), ACC64=0, LEAN=1, BATCH=(\d), SINGLE=0, CANON=0> x (\d+) wave", r["kernel_instantiation"])
+    assert m and r["traffic_source"] == "profiles/r05_c2a_f32_pmc.json"
+    assert f"--waves {m.group(3)} " in r["traffic_source_note"]
+    stats = open(os.path.join(ROOT, "profiles", "r05_c2a_f32_kernel_stats.csv")).read()
+    assert f"sweep_dense_kernel<float, {m.group(1)}, false, true, {'true' if m.group(2) == '1' else 'false'}, false, false>" in stats
+    avg_ms = [float(l.split(",")[-5]) / 1e6 for l in stats.splitlines() if "sweep_dense_kernel" in l][0]
+    assert abs(avg_ms / r["avg_launch_ms"] - 1.0) < 0.02
+    # ... and the pick is deterministic: the fewest waves among the candidates within 1 % of the fastest, table in the line
+    table = {k: v for k, v in d["config"]["autotune_ms"].items() if not k.startswith("heuristic:")}
+    tied = [int(k.split("x")[0]) for k, v in table.items() if v <= 1.01 * min(table.values())]
+    assert int(m.group(3)) == min(tied) and len(table) >= 8
+    # no cap anywhere: every ratio is achieved / peak as measured
+    blocks = [r, d["roofline_beyond_cache"]] + [c["roofline"] for c in d["configs"].values()]
+    for b in blocks:
+        if b["frac"] is not None:
+            assert b["frac"] == pytest.approx(b["achieved"] / b["peak"], rel=1e-12), b["kernel"]
+        assert "frac_note" not in b
+    assert r["bound"] == "hbm" and r["cache_served"] is True and 0.9 < r["frac"] < 1.05
+    # the beyond-cache block: this round's PMC pass of the final build, the HBM-only figure
+    b = d["roofline_beyond_cache"]
+    assert b["traffic_source"] == "profiles/r05_dense_f32_n32768_pmc.json" and b["cache_served"] is False
+    assert 0.6 <= b["frac"] < 0.9 and abs(b["traffic"] / b["algorithmic_bytes_per_launch"] - 1.0) < 0.01
+    # structures that fit the 256 MiB Infinity Cache are not called HBM bound
+    cfg = d["configs"]
+    assert sorted(cfg) == ["c3", "c4", "c5", "c5_1000", "c5_1000_csr"]
+    for name in ("c4", "c5"):
+        rr = cfg[name]["roofline"]
+        assert rr["bound"] == "infinity-cache" and rr["structure_bytes"] <= 256 * 2 ** 20 and rr["cache_served"] is True
+        assert rr["frac_of_hbm_spec"] == pytest.approx(rr["achieved"] / 8000.0)
+    assert cfg["c5_1000_csr"]["roofline"]["bound"] == "hbm" and cfg["c5_1000_csr"]["roofline"]["structure_bytes"] > 3e10
+    assert cfg["c5_1000_csr"]["roofline"]["frac"] >= 0.6
+    # configs[4] at its stated size: a number, with its own profile
+    k = cfg["c5_1000"]
+    assert "1000-city" in k["workload"] and "couplings implicit" in k["workload"] and "256 replicas/GPU, 4 geometric ladder" in k["workload"]
+    assert k["roofline"]["bound"] == "valu-issue" and 0.0 < k["roofline"]["frac"] < 1.0
+    assert k["roofline"]["issue_counters_source"] == "profiles/r05_c5_1000_implicit_pmc.json"
+    assert k["kernel_instantiation"].startswith("sweep_tsp_par_kernel")
+    for name, c in cfg.items():
+        assert c["cpu_baseline"]["energy_gap_vs_gpu"]["max_abs_energy_gap"] == 0.0, name
+        assert c["cpu_baseline"]["energy_gap_vs_gpu"]["spins_identical"] is True, name
+        assert c["setup_ms"]["engine_load"] > 0 and c["energies_sha256"]
+    assert "500 of the 1000 cities" in k["cpu_baseline"]["substitute_instance"]
+    assert cfg["c5_1000_csr"]["setup_ms"]["engine_load"] > 500.0          # (the symmetry pass over 4e9 entries is in there)
+    # C3: where a wave's time goes, from this round's counters
+    c3 = cfg["c3"]["roofline"]
+    assert c3["bound"] == "valu-issue" and c3["issue_counters_source"] == "profiles/r05_c3_csr_pmc.json"
+    shares = c3["wave_time_shares"]
+    assert 0.9 < shares["waiting (s_waitcnt / barrier)"] + shares["issue stalled"] + shares["instruction in flight"] < 1.1
+
+
+def test_round5_two_rank_rehearsal_line_carries_configs_3_and_4_sharded():
+    """`bench.py --gpus 2 --backend gloo --share-device` on one GPU (what the driver's `--gpus 8` run does over RCCL):
+    after the headline, configs[3] as ONE ladder spanning the ranks and configs[4] as whole ladders per rank."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_2rank_gloo.json")))
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak"
+    cfg = d["configs"]
+    assert sorted(cfg) == ["c4", "c5", "c5_1000"]
+    c4, c5, k = cfg["c4"], cfg["c5"], cfg["c5_1000"]
+    for c in (c4, c5, k):
+        assert c["ranks_seen"] == 2 and c["n_gpus"] == 2 and c["couplings_checksum_agree"] is True and c["value"] > 0
+    assert c4["replicas_total"] == 2048 and "1024 replicas/GPU, 1 geometric ladder" in c4["workload"]
+    assert c4["exchange"]["allgathers_timed"] == c4["exchange"]["rounds_timed"] >= 1 and c4["exchange"]["bytes_per_rank"] == 8192
+    assert c5["replicas_total"] == 512 and "256 replicas/GPU, 8 geometric ladder" in c5["workload"]
+    assert c5["exchange"]["allgathers_timed"] == 0 and c5["exchange"]["bytes_per_rank"] == 0 and c5["exchange"]["rounds_timed"] >= 1
+    assert "whole ladders per rank" in c5["placement"] and "whole ladders per rank" in k["placement"]
