@@ -45,8 +45,11 @@ namespace sga {
 // DPP steps over the row's lanes continue the same tree (IEEE addition commutes, so which side a partner comes
 // from does not matter) -- the same bits as the one-update form for every launch geometry.  The energy is
 // then added in chain order.
-template <int G, int EPL, bool BIG, bool REAL>
+// MODE: 0 = accept table, moves beyond the table computed | 1 = REAL | 2 = accept table that holds EVERY move the problem can
+// propose (a.table_covers: C3, C4 -- the beyond-the-table test and its exp path are not compiled in)
+template <int G, int EPL, bool BIG, int MODE>
 __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kernel(const SweepArgs a) {
+    constexpr bool REAL = MODE == 1, COVERS = MODE == 2;
     constexpr int LPR = 64 / G;   // lanes per row
     // (rows of 65 ... 256 entries: G = 4 with 8 | 16 entries per lane, accept-table builds only -- the canonical
     //  order of real-valued sums is defined on 64-entry virtual waves, which a lane's 16 consecutive entries straddle)
@@ -135,7 +138,9 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         const int sv = permute(from, p < 64 ? ws_lo : ws_hi), uv = permute(from, p < 64 ? wu_lo : wu_hi);
         st.live = (valid && t0 + g < n) ? 1 : 0;
         st.site = st.live ? sv : 0;
-        st.ru = (uint32_t)uv;
+        // (a dead row never flips: table builds give it a uniform above every table entry, so that the accept compare
+        //  alone is the row's decision -- 24-bit uniforms, entries <= 2^24)
+        st.ru = (REAL || st.live) ? (uint32_t)uv : 0xFFFFFFFFu;
     };
     // scalar base + 32-bit lane offset: the scalar-base form of global_load (as in sweep_csr_impl.h)
     auto stage_extents = [&](Step &st) {
@@ -221,13 +226,14 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         // uniform: those moves are accepted by the same compare, no branch around the look-up
         bool flip = st.ru < itab[idx];
         dE = (DE)(2.0f * fk);
-        if (!a.table_covers) {  // (wave-uniform: the table holds every move this problem can propose -- C3, C4)
+        if constexpr (!COVERS) {
             const bool beyond = fq > (float)a.table_m;
             if (ballot(beyond)) {  // beyond the table (p == 0 past -104)
                 const double dEd = (double)(2.0f * fk);
                 if (beyond) flip = (dEd > T * 104.0) ? false : ((float)st.ru * 0x1.0p-24f < expf_det((float)(-dEd / T)));
             }
         }
+        if constexpr (COVERS) return flip;  // (st.live is in st.ru: the compare above is the whole decision)
         return st.live != 0 && flip;
     };
     constexpr unsigned long long HEADS = G == 4 ? 0x0001000100010001ull : 0x0101010101010101ull;  // lane 0 of every row
@@ -389,23 +395,24 @@ bool sweep_csr_rows_applies(const SweepArgs &a) {
     return a.csr_row_cap <= 64 || (a.csr_pair_ahead == 4 && rows_table_form(a));  // longer rows: integer problems, four per step
 }
 
-template <bool BIG, bool REAL>
+template <bool BIG, int MODE>
 static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
+    constexpr bool REAL = MODE == 1;
     const int cap = a.csr_row_cap;  // entries of the problem's longest row (<= 64)
     void (*kern)(const SweepArgs) = nullptr;
     int g = 4, epl = 4;
     if (a.csr_pair_ahead == 8) {  // rows of 8 lanes
         g = 8;
         epl = cap <= 8 ? 1 : cap <= 16 ? 2 : cap <= 32 ? 4 : 8;
-        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG, REAL>
-             : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG, REAL> : sweep_csr_rows_kernel<8, 8, BIG, REAL>;
+        kern = epl == 1 ? sweep_csr_rows_kernel<8, 1, BIG, MODE> : epl == 2 ? sweep_csr_rows_kernel<8, 2, BIG, MODE>
+             : epl == 4 ? sweep_csr_rows_kernel<8, 4, BIG, MODE> : sweep_csr_rows_kernel<8, 8, BIG, MODE>;
     } else {                      // rows of 16 lanes
         epl = cap <= 16 ? 1 : cap <= 32 ? 2 : cap <= 64 ? 4 : cap <= 128 ? 8 : 16;
-        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG, REAL> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG, REAL>
-             : epl == 4 ? sweep_csr_rows_kernel<4, 4, BIG, REAL> : nullptr;
+        kern = epl == 1 ? sweep_csr_rows_kernel<4, 1, BIG, MODE> : epl == 2 ? sweep_csr_rows_kernel<4, 2, BIG, MODE>
+             : epl == 4 ? sweep_csr_rows_kernel<4, 4, BIG, MODE> : nullptr;
         if constexpr (!REAL) {
-            if (epl == 8) kern = sweep_csr_rows_kernel<4, 8, BIG, false>;
-            if (epl == 16) kern = sweep_csr_rows_kernel<4, 16, BIG, false>;
+            if (epl == 8) kern = sweep_csr_rows_kernel<4, 8, BIG, MODE>;
+            if (epl == 16) kern = sweep_csr_rows_kernel<4, 16, BIG, MODE>;
         }
         if (!kern) return hipErrorInvalidValue;
     }
@@ -417,10 +424,11 @@ static hipError_t launch_rows(const SweepArgs &a, int waves_per_block, hipStream
 
 hipError_t launch_sweep_csr_rows(const SweepArgs &a, int waves_per_block, hipStream_t st) {
     // Everything but the accept-table class -- real-valued couplings, integer problems with larger sums -- runs the
-    // fp64 builds (exact for integers too).
+    // fp64 builds (exact for integers too).  Table builds: with or without the beyond-the-table path (a.table_covers).
     const bool table = rows_table_form(a);
-    if (a.big) return table ? launch_rows<true, false>(a, waves_per_block, st) : launch_rows<true, true>(a, waves_per_block, st);
-    return table ? launch_rows<false, false>(a, waves_per_block, st) : launch_rows<false, true>(a, waves_per_block, st);
+    if (table && a.table_covers) return a.big ? launch_rows<true, 2>(a, waves_per_block, st) : launch_rows<false, 2>(a, waves_per_block, st);
+    if (a.big) return table ? launch_rows<true, 0>(a, waves_per_block, st) : launch_rows<true, 1>(a, waves_per_block, st);
+    return table ? launch_rows<false, 0>(a, waves_per_block, st) : launch_rows<false, 1>(a, waves_per_block, st);
 }
 
 }  // namespace sga
