@@ -805,7 +805,6 @@ int sga_sweep(sga_engine *e, int n_sweeps, int site_mode, int arith, const doubl
         a.csr_row_cap = (e->csr && e->max_row_len <= 256)
                             ? (int)std::max<long long>(e->slotted ? (e->max_row_len + 63) / 64 * 64 : e->max_row_len, 1) : 0;
         a.csr_pair_ahead = csr_updates_per_step(e);
-        a.wave_prio = (int)e->opt[OPT_CSR_WAVE_PRIO];
         // (option "look_ahead" = 0: A/B switch and the parity tests' cross-check)
         a.look_ahead = e->opt[OPT_LOOK_AHEAD] != 0 ? 1 : 0;
         a.force_general = e->opt[OPT_FORCE_GENERAL] != 0 ? 1 : 0;

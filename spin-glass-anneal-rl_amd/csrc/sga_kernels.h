@@ -73,7 +73,6 @@ struct SweepArgs {
                          // (opt-in), 4 | 8 = that many updates per step, one per row of 16 | 8 lanes (sweep_csr_rows.hip)
     int csr_row_cap;     // CSR: entries of the longest row when that is <= 64 (else 0): sweep_csr_rows.hip picks its build by it
     int table_covers;    // CSR accept-table forms: 1 = no move of this problem lies beyond the table (scale * max_i(sum_j |J_ij| + |h_i|) <= table_m)
-    int wave_prio;       // sweep_csr_rows.hip: 1 = a wave's issue priority follows its replica's acceptance (engine option "csr_wave_priority")
     int look_ahead;      // dense, integer problems: reduce LOOK updates together (sweep_dense_impl.h)
     int force_general;   // 1: the general kernel builds even for production arguments (engine option "force_general")
     int tsp_parallel;    // implicit TSP form: updates per step (-1: by the number of cities, 0 | 1: one at a time)

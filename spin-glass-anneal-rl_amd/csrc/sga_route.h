@@ -27,7 +27,7 @@ enum Opt {
     OPT_LOOK_AHEAD, OPT_CLF_WAVES, OPT_SPARSE_ROUTE, OPT_BATCHED_ENERGY, OPT_FORCE_GENERAL, OPT_CSR_UPDATES_PER_STEP,
     OPT_TSP_PARALLEL, OPT_FORCE_CSR_BITS, OPT_CSR_BITS, OPT_CSR_SLOTS, OPT_HALF_TABLE, OPT_FORCE_CSR_ACC,
     OPT_FORCE_DENSE_CANON, OPT_ZERO_SLOT_EVERY, OPT_REPLICA_ROUTING, OPT_FIELDS_SCRATCH_MB, OPT_CLF_BATCHED,
-    OPT_CLF_TAIL_WAVES, OPT_CSR_WAVE_PRIO, OPT_COUNT
+    OPT_CLF_TAIL_WAVES, OPT_COUNT
 };
 struct OptDef {
     const char *key;
@@ -56,7 +56,6 @@ constexpr OptDef OPT_DEFS[OPT_COUNT] = {
     {"fields_scratch_mb", "SGA_FIELDS_SCRATCH_MB", 0, 0, 256, 1, 65536, 0},
     {"clf_batched", "SGA_CLF_BATCHED", 0, 0, 2, 0, 2, 0},
     {"clf_tail_waves", "SGA_NO_CLF_TAIL_WAVES", 1, 0, 1, 0, 1, 0},
-    {"csr_wave_priority", "SGA_CSR_WAVE_PRIORITY", 0, 0, 0, 0, 1, 0},
 };
 inline int find_option(const char *key) {
     if (!key) return -1;

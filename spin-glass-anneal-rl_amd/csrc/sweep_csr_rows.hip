@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         // fields: table_scale = 2, the table is indexed by 2 fk = dE); sweep_csr_impl.h, TABLE branch
         fk = (float)si * (dot + st.h);
         const float fq = fk * (float)a.table_scale;
-        const int idx = min(max((int)fq, 0), a.table_m);
+        const int idx = COVERS ? max((int)fq, 0) : min(max((int)fq, 0), a.table_m);  // (COVERS: no fq beyond the table)
         // u < p on the uniform's raw bits.  Entry 0 (fk <= 0: downhill or flat, p = 1) holds 2^24, above every 24-bit
         // uniform: those moves are accepted by the same compare, no branch around the look-up
         bool flip = st.ru < itab[idx];
@@ -323,30 +323,7 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         stage_heads(n1);          // one step ahead: its extents were requested a step ago
         step(c);
     };
-    // Issue priority by acceptance (a.wave_prio, engine option "csr_wave_priority"): every replica is one wave and a
-    // launch lasts as long as its slowest wave -- the hot replicas', whose steps carry the conflict checks, the flips and
-    // the replays.  A SIMD holds waves of four temperatures: the arbiter prefers the one that accepts most
-    // (s_setprio 3 ... 0), the cold ones -- done early anyway -- yield.  Scheduling only: the chain is untouched.
-    unsigned long long nacc_before = 0;
-    if (a.wave_prio) {
-        const unsigned long long done = (unsigned long long)a.sweep0 * (unsigned long long)n;  // attempts before this launch
-        const unsigned long long acc0 = a.n_accepted[r];
-        // (no history yet: everybody at the same priority)
-        const int p = done == 0 ? 0 : (acc0 * 4 >= done ? 3 : (acc0 * 20 >= done ? 2 : (acc0 * 100 >= done ? 1 : 0)));
-        if (p == 3) __builtin_amdgcn_s_setprio(3);
-        else if (p == 2) __builtin_amdgcn_s_setprio(2);
-        else if (p == 1) __builtin_amdgcn_s_setprio(1);
-    }
     for (int k = 0; k < a.n_sweeps; ++k) {
-        if (a.wave_prio && k > 0) {  // the sweep before this one
-            const unsigned long long d = nacc - nacc_before;
-            const unsigned long long nn = (unsigned long long)n;
-            if (d * 4 >= nn) __builtin_amdgcn_s_setprio(3);
-            else if (d * 20 >= nn) __builtin_amdgcn_s_setprio(2);
-            else if (d * 100 >= nn) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        nacc_before = nacc;
         T = a.sched ? a.sched[k * a.sched_ss + r * a.sched_rs] : a.rep_temp[r];
         // exp(float32(-dE / T)) for dE = 2 q / table_scale as integer thresholds on the uniform's raw bits
         if constexpr (!REAL)
