@@ -225,7 +225,7 @@ int ensure_packed(sga_engine *e) {
 extern "C" {
 
 const char *sga_last_error(void) { return g_last_error.c_str(); }
-int sga_version(void) { return 400; }  // round 4: + sga_set_option / sga_get_option / sga_option_name, per-replica routing
+int sga_version(void) { return 500; }  // round 5: + sga_explain_route / sga_get_route_query, sga_get_last_kernel, sga_get_autotune_table, ladder-local sga_exchange
 
 int sga_create(int device, sga_engine **out) {
     if (!out) return fail(SGA_ERR_INVALID, "out is NULL");

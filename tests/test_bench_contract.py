@@ -22,12 +22,15 @@ def test_committed_bench_line_follows_the_contract(path):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    if r["bound"] in ("hbm", "mfma"):
+    if r["bound"] in ("hbm", "mfma", "infinity-cache"):
         assert r["unit"] in ("GB/s", "TFLOP/s")
-        if os.path.basename(path) >= "r04":      # (a byte rate above the spec figure is capped, and says so)
+        if "r04" <= os.path.basename(path) < "r05":   # (round 4 capped a byte rate above the spec figure, and said so)
             assert r["frac"] == pytest.approx(min(r["achieved"] / r["peak"], 1.0)) and r["frac"] <= 1.0
-        else:
+        else:                                         # (round 5: raw ratios, `cache_served` says what may lift them)
             assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+        if r["bound"] == "infinity-cache":       # round 5: a structure that fits the 256 MiB cache is not called HBM bound
+            assert r["structure_bytes"] <= 256 * 2 ** 20 and r["cache_served"] is True and r["peak"] == 8600.0
+            assert r["frac_of_hbm_spec"] == pytest.approx(r["achieved"] / 8000.0)
     else:
         # round 4: a cache-resident kernel reports the bound it really has -- vector-instruction issue / the
         # per-update dependent chain -- with the issue fraction from the committed instruction counts (or None
