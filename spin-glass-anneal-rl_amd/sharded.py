@@ -168,6 +168,7 @@ class LocalShardedTempering:
         self.world = len(self.engines)
         self.R_local = int(R_local)
         self.R_global = self.R_local * self.world
+        self._pool = None
         for k, e in enumerate(self.engines):
             part = None if s0 is None else s0[k * R_local:(k + 1) * R_local]
             e.init_replicas(self.R_local, seed=seed, s0=part, R_global=self.R_global,
@@ -176,8 +177,18 @@ class LocalShardedTempering:
                 e.set_ladder(np.asarray(slot_temps, np.float64), n_ladders)
 
     def sweep(self, n_sweeps: int = 1):
-        for e in self.engines:  # launches return immediately: the GPUs overlap
-            e.sweep(n_sweeps)
+        """All engines sweep concurrently.  A plain sga_sweep only enqueues its launches, but under the field-cache
+        modes a call may read the acceptance counters back (a host synchronisation every 4 ... 16 sweeps), so one
+        thread per engine drives them: ctypes drops the GIL during the call, every call sets its own device, and each
+        engine serialises its own calls (engine.py)."""
+        if self.world == 1:
+            self.engines[0].sweep(n_sweeps)
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.world, thread_name_prefix="sga-shard")
+        for f in [self._pool.submit(e.sweep, n_sweeps) for e in self.engines]:
+            f.result()  # (an engine's error surfaces here)
 
     def gather_energies(self) -> np.ndarray:
         return np.concatenate([e.energies() for e in self.engines])
