@@ -173,10 +173,13 @@ def test_autotune_reports_its_table_and_keeps_the_callers_timing(sg):
         assert len(table) >= 3 and any(k.startswith("heuristic:") for k in table)
         w, c = e.geometry()
         picked = [v for k, v in table.items() if k.split(":")[-1] == f"{w}x{c}"]
-        assert picked and min(table.values()) <= min(picked) <= 1.01 * min(table.values()) + 1e-9
+        assert picked and min(table.values()) <= min(picked) <= 1.011 * min(table.values())
         assert best == pytest.approx(min(table.values()), rel=1e-3)
         # fewest waves among the candidates within 1 % of the fastest (a fixed preference order)
-        tied = [int(k.split(":")[-1].split("x")[0]) for k, v in table.items() if not k.startswith("heuristic:") and v <= 1.01 * min(table.values())]
-        assert w == min(tied)
+        # (the table is printed to 4 decimals: a candidate sitting exactly on the 1 % line may fall either way)
+        best_ms = min(table.values())
+        waves_within = lambda f: [int(k.split(":")[-1].split("x")[0]) for k, v in table.items()  # noqa: E731
+                                  if not k.startswith("heuristic:") and v <= f * best_ms]
+        assert min(waves_within(1.011)) <= w <= min(waves_within(1.009))
         after = e.kernel_time(reset=False)
         assert after[0] == before[0] and after[1] == pytest.approx(before[1])   # the trials left the caller's statistics alone

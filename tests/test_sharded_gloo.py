@@ -26,11 +26,11 @@ def _ladder(R, n_ladders):
     return np.asarray(one * n_ladders)
 
 
-def _run(rank, world, n_ladders, sink, dist_mod, force=False):
+def _run(rank, world, n_ladders, sink, dist_mod, force=False, R=R_GLOBAL):
     import spin_glass_anneal_rl_amd as sg
     J, h = _instance()
-    pt = sg.ShardedTempering(OracleEngine(J=J, h=h), R_GLOBAL // world, rank, world, SEED,
-                             _ladder(R_GLOBAL, n_ladders), n_ladders, dist_mod,
+    pt = sg.ShardedTempering(OracleEngine(J=J, h=h), R // world, rank, world, SEED,
+                             _ladder(R, n_ladders), n_ladders, dist_mod,
                              torch.device("cpu"), force_dist=force)
     assert (pt.dist is not None) == (world > 1 or force)
     swaps = []
@@ -49,11 +49,11 @@ def _run(rank, world, n_ladders, sink, dist_mod, force=False):
                 slot_map=pt.engine.slot_map())
 
 
-def _worker(rank, world, port, n_ladders, q, force=False):
+def _worker(rank, world, port, n_ladders, q, force=False, R=R_GLOBAL):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = {}
-    _run(rank, world, n_ladders, out, dist, force)
+    _run(rank, world, n_ladders, out, dist, force, R)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -65,11 +65,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ranks(world, n_ladders, force=False):
+def _ranks(world, n_ladders, force=False, R=R_GLOBAL):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ladders, q, force)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ladders, q, force, R)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in procs)
@@ -79,12 +79,12 @@ def _ranks(world, n_ladders, force=False):
     return got
 
 
-def _check(n_ladders, world=2):
+def _check(n_ladders, world=2, R=R_GLOBAL):
     single = {}
-    _run(0, 1, n_ladders, single, None)
+    _run(0, 1, n_ladders, single, None, R=R)
     assert sum(single["swaps"]) > 0
-    got = _ranks(world, n_ladders)
-    half = R_GLOBAL // world
+    got = _ranks(world, n_ladders, R=R)
+    half = R // world
     for rank in range(world):
         o = got[rank]
         assert o["swaps"] == single["swaps"]
@@ -115,6 +115,12 @@ def test_whole_ladders_per_rank_exchange_without_any_gather():
     _check(4)
     _check(6)
     _check(6, world=3)
+
+
+def test_eight_ranks_with_four_whole_ladders_each_as_baseline_configs_4_places_them():
+    """BASELINE configs[4] in miniature: 32 ladders over 8 ranks = 4 whole ladders per rank (here 3 temperatures per
+    ladder, 96 replicas) -- every exchange round is local, and the run equals the one-rank run."""
+    _check(32, world=8, R=96)
 
 
 def test_four_rank_run_equals_single_rank_ladders_straddling_ranks():
