@@ -527,6 +527,10 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (as in the headline: no collector pause of the interpreter inside a timed region of a few milliseconds --
+    #  profiles/r02_experiments.md 13; `kernel_ms_total` beside `ms_per_step` would show any other host gap)
+    gc.collect()
+    gc.disable()
     for _ in range(warmup):
         step()
     if a.exchange_interval > 0:
@@ -541,6 +545,7 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
         step()
     barrier()
     dt_mine = time.perf_counter() - t0
+    gc.enable()
     dt = dt_mine
     if dist is not None:
         tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
