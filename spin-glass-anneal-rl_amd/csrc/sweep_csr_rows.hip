@@ -97,6 +97,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
         else s[c] = (int8_t)(-si_old);
     };
     const int g = lane / LPR, j = lane % LPR;  // row of the wave = update of the step, lane in the row
+#if defined(ROWS_SENS_VALU2) || defined(ROWS_SENS_VALU4) || defined(ROWS_SENS_SALU) || defined(ROWS_SENS_LDS)
+    unsigned int sens_v = (unsigned int)lane, sens_s = 0u;
+    unsigned int sens_a = (unsigned int)((long long)w * sbytes + ((lane * 37) % 997));  // (random-ish bytes of the wave's own slice)
+#endif
     double E = a.energy[r], bestE = a.best_energy[r];
     unsigned long long nacc = 0;
     double T = 1.0;
@@ -240,6 +244,22 @@ __global__ void __launch_bounds__(64 * CSR_WAVES_PER_BLOCK) sweep_csr_rows_kerne
     auto step = [&](const Step &st) {
         int si;
         DE dE;
+#ifdef ROWS_SENS_VALU2   // sensitivity builds (profiles/r05_experiments.md 2): N more instructions of one class per step
+#pragma unroll
+        for (int z = 0; z < ROWS_SENS_VALU2; ++z) asm volatile("v_add_u32 %0, %0, %0" : "+v"(sens_v));
+#endif
+#ifdef ROWS_SENS_VALU4
+#pragma unroll
+        for (int z = 0; z < ROWS_SENS_VALU4; ++z) asm volatile("v_bfe_u32 %0, %0, 1, 7" : "+v"(sens_v));
+#endif
+#ifdef ROWS_SENS_SALU
+#pragma unroll
+        for (int z = 0; z < ROWS_SENS_SALU; ++z) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sens_s) : : "scc");
+#endif
+#ifdef ROWS_SENS_LDS
+#pragma unroll
+        for (int z = 0; z < ROWS_SENS_LDS; ++z) { int t; asm volatile("ds_read_i8 %0, %1" : "=v"(t) : "v"(sens_a)); asm volatile("" : : "v"(t)); }
+#endif
         const bool flip = decide(st, si, dE);
         const unsigned long long acc = ballot(flip) & HEADS;
         // does an accepted update touch a LATER one of the step?  (its site among their columns or their
