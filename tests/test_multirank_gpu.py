@@ -322,3 +322,62 @@ def test_a_refused_run_closes_its_engine_and_hands_the_default_stream_back(tmp_p
     o = dict(np.load(path))
     assert "different couplings" in str(o["err"])
     assert int(o["made"]) == 1 and bool(o["closed"]) and int(o["left"]) == 0 and bool(o["default_stream"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_ladders,L", [(2, 2, 5), (2, 6, 3), (3, 6, 4), (4, 8, 2), (8, 32, 2)])
+def test_ladder_local_exchange_equals_the_unsharded_engine(world, n_ladders, L):
+    """sga_exchange with energies_global = NULL on sharded replicas (every ladder whole on one shard): `world` engines
+    in one process, each deciding only its own ladders from its own energies, walk the chain of ONE engine holding all
+    replicas -- swaps per round, temperatures, spins, the slot map and the exchange statistics of the local ladders."""
+    import spin_glass_anneal_rl_amd as sg
+    n, seed, rounds = 300, 909, 7
+    R = n_ladders * L
+    Rl = R // world
+    assert Rl % L == 0
+    rng = np.random.RandomState(3)
+    J = np.triu(rng.randint(0, 2, (n, n)) * 2 - 1, 1).astype(np.float32)
+    J, h = J + J.T, rng.randint(-1, 2, n).astype(np.float32)
+    ladder = np.tile(np.geomspace(8.0, 0.4, L), n_ladders)
+
+    def engine(R_local, replica0):
+        e = sg.AnnealEngine(0)
+        e.set_dense(J, h)
+        e.init_replicas(R_local, seed=seed, R_global=R, replica0=replica0)
+        e.set_ladder(ladder, n_ladders)
+        return e
+
+    whole = engine(R, 0)
+    shards = [engine(Rl, k * Rl) for k in range(world)]
+    try:
+        for _ in range(rounds):
+            whole.sweep(2)
+            want = whole.exchange()
+            got = 0
+            for e in shards:
+                e.sweep(2)
+                got += e.exchange()          # no energies from anybody else
+            assert got == want
+        assert want >= 0 and int(whole.exchange_stats()[1].sum()) > 0
+        att, acc = whole.exchange_stats()
+        for k, e in enumerate(shards):
+            sl = slice(k * Rl, (k + 1) * Rl)
+            assert np.array_equal(e.spins(), whole.spins()[sl])
+            assert np.array_equal(e.temperatures(), whole.temperatures()[sl])
+            assert np.array_equal(e.energies(), whole.energies()[sl])
+            assert np.array_equal(e.slot_map()[sl], whole.slot_map()[sl])
+            a2, c2 = e.exchange_stats()
+            assert np.array_equal(a2[sl], att[sl]) and np.array_equal(c2[sl], acc[sl])
+        # a ladder that straddles two shards still needs the gathered energies
+        if L > 1 and Rl > 1:
+            bad = sg.AnnealEngine(0)
+            bad.set_dense(J, h)
+            bad.init_replicas(Rl, seed=seed, R_global=R, replica0=1)
+            bad.set_ladder(ladder, n_ladders)
+            with pytest.raises(sg.AnnealingError, match="all-gathered energies"):
+                bad.exchange()
+            bad.close()
+    finally:
+        whole.close()
+        for e in shards:
+            e.close()
