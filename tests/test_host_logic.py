@@ -340,3 +340,19 @@ def test_route_answers_move_with_their_inputs():
     assert N.explain_route(N.route_query(kind=N.ROUTE_TSP, n=250000, n_cities=500)).startswith("tsp n_cities=500 waves=2 passes=1")
     with pytest.raises(Exception):
         N.explain_route(N.route_query(kind=7, n=10))
+
+
+def test_integration_md_route_snippet_runs_as_written_without_a_gpu(capsys):
+    """INTEGRATION.md shows how to ask the form selection about a problem from plain ctypes; executed here as it stands."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("### Which kernel form will run"):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    assert "sga_explain_route" in code
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(compile(code, "INTEGRATION.md#route", "exec"), {})
+    finally:
+        os.chdir(cwd)
+    assert capsys.readouterr().out.startswith("csr form=rows spins=int8 waves=1 replicas_per_block=4 updates_per_step=4 ")
