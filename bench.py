@@ -674,7 +674,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2a", choices=["c2a", "c3", "c4", "c5"],
                     help="c2a: dense SK instance (headline); c3: CSR, degree ~32, 4096 replicas; "
                          "c4: 50k-spin scheduling penalties (CSR), 1024 replicas/GPU; "
