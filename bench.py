@@ -511,7 +511,7 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
     eng.set_field_cache("off")  # the graded form: one coupling-row read per proposal
     ladder = np.tile(geometric_ladder(Rg // n_ladders, wl["t_hot"], wl["t_cold"]), n_ladders)
     pt = ShardedTempering(eng, R_local=R, rank=rank, world=world, seed=42, slot_temps=ladder, n_ladders=n_ladders,
-                          dist=dist, device=comm_dev)
+                          dist=dist, device=comm_dev, force_dist=a.force_dist)
     agree, checksum = checksums_agree(eng, dist, a.backend, world, comm_dev)
     done = 0
 
@@ -567,7 +567,7 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
                                  "symmetry pass, layout, packing)"},
             "roofline": roofline_block(wl, name, R, (kernel_ms / max(launches, 1)) * 1e-3, launches, kernel_inst),
             "best_energy": eng.best(with_spins=False)[0]}
-    if world > 1:
+    if pt.dist is not None:   # N > 1 ranks, or the one-rank process group of --force-dist
         line.update({
             "n_gpus": world, "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "scaling": "weak",
             "replicas_total": Rg, "couplings_checksum_agree": agree, "couplings_checksum": f"{checksum:016x}",
@@ -583,7 +583,7 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
                          "enqueue_ms_per_round": (pt.gather_ms / pt.gather_calls) if pt.gather_calls else None,
                          "bytes_per_rank": 0 if pt.ladders_local else 8 * R}})
     import hashlib
-    e_all = pt.gather_energies().cpu().numpy() if world > 1 else eng.energies()
+    e_all = pt.gather_energies().cpu().numpy() if pt.dist is not None else eng.energies()
     line["energies_sha256"] = hashlib.sha256(np.ascontiguousarray(e_all, np.float64).tobytes()).hexdigest()[:16]
     e_best, _, who = pt.global_best()
     line["best_energy_global"], line["best_replica_global"] = e_best, who

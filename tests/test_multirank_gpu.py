@@ -204,7 +204,8 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     """`python bench.py --gpus 1 --force-dist`: a one-rank RCCL group in a child process; the line says so
     and reports that the ranks' couplings agree."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "12",
-           "--warmup", "2", "--spins", "2000", "--replicas", "64", "--no-variants", "--no-cpu-baseline"]
+           "--warmup", "2", "--spins", "2000", "--replicas", "64", "--no-variants", "--no-cpu-baseline",
+           "--configs", "c4,c5", "--config-replicas", "128"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -220,6 +221,14 @@ def test_bench_force_dist_runs_the_rccl_path_on_one_gpu():
     q = json.loads(plain.stdout.splitlines()[0])
     assert q["backend"] is None and q["couplings_checksum"] == d["couplings_checksum"]
     assert q["config"]["best_energy_rank0"] == d["config"]["best_energy_rank0"]
+    # the config lines of BASELINE configs[3] / [4] through the same one-rank RCCL group: checksum all-gather, energies
+    # all-gather on the shared stream (device tensors), MAX all-reduce of the time, best all-gather + broadcast
+    for c in ("c4", "c5"):
+        assert d["configs"][c]["backend"] == "nccl" and d["configs"][c]["ranks_seen"] == 1
+        assert d["configs"][c]["exchange"]["allgathers_timed"] >= 1 and d["configs"][c]["exchange"]["allgather_ms_per_round"] > 0
+        assert "backend" not in q["configs"][c]
+        assert d["configs"][c]["energies_sha256"] == q["configs"][c]["energies_sha256"]
+        assert d["configs"][c]["best_energy_global"] == q["configs"][c]["best_energy_global"]
 
 
 def _class_rank_main(with_dist, port, out_path):
