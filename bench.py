@@ -574,8 +574,9 @@ def config_line(name, a, dev, local_rank, comm_dev, rank=0, world=1, dist=None, 
             "ms_per_step_this_rank": dt_mine / steps * 1e3,
             "placement": ("whole ladders per rank: exchange rounds are local, no collective (SURVEY.md 8e)"
                           if pt.ladders_local else
-                          f"one ladder of {Rg // n_ladders} temperatures spans the ranks: all-gather of the energies per round, "
-                          "identical Philox decisions on every rank, temperature labels swap"),
+                          f"{n_ladders} ladder(s) of {Rg // n_ladders} temperatures over {world} rank(s), ladders may span ranks: "
+                          "all-gather of the energies per round, identical Philox decisions on every rank, temperature "
+                          "labels swap"),
             "exchange": {"rounds_timed": (done // a.exchange_interval - warmup // a.exchange_interval)
                                          if a.exchange_interval > 0 else 0,
                          "allgathers_timed": pt.gather_calls,

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 b() { tag=$1; shift; timeout -k 10 900 python bench.py "$@" > gpurun_out/r05_bench_$tag.json 2> gpurun_out/r05_bench_$tag.err; echo "bench $tag rc=$?"; }
 b c2a_f32 --steps 20 --warmup 5
 b 2rank_gloo --gpus 2 --backend gloo --share-device --steps 20 --warmup 5
-b c2a_f32_force_dist --force-dist --no-variants --no-cpu-baseline
+b c2a_f32_force_dist --force-dist --no-variants --no-cpu-baseline --configs c4,c5,c5_1000
 b c3_csr --workload c3
 b c4_csr --workload c4
 b c5_csr --workload c5

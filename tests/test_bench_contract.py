@@ -211,3 +211,17 @@ def test_round5_two_rank_rehearsal_line_carries_configs_3_and_4_sharded():
     assert c5["replicas_total"] == 512 and "256 replicas/GPU, 8 geometric ladder" in c5["workload"]
     assert c5["exchange"]["allgathers_timed"] == 0 and c5["exchange"]["bytes_per_rank"] == 0 and c5["exchange"]["rounds_timed"] >= 1
     assert "whole ladders per rank" in c5["placement"] and "whole ladders per rank" in k["placement"]
+
+
+def test_round5_one_rank_rccl_line_carries_the_config_lines():
+    """`bench.py --force-dist --configs c4,c5,c5_1000`: headline and config lines through a one-rank RCCL group on the GPU --
+    the collectives of the multi-rank path (checksum and energies all-gather on device tensors, time all-reduce, best
+    broadcast) executed by RCCL, timed with events on the shared stream."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_c2a_f32_force_dist.json")))
+    assert d["backend"] == "nccl" and d["ranks_seen"] == 1 and d["couplings_checksum_agree"] is True
+    assert sorted(d["configs"]) == ["c4", "c5", "c5_1000"]
+    for name, c in d["configs"].items():
+        assert c["backend"] == "nccl" and c["ranks_seen"] == 1 and c["couplings_checksum_agree"] is True, name
+    for name in ("c4", "c5"):
+        ex = d["configs"][name]["exchange"]
+        assert ex["allgathers_timed"] == ex["rounds_timed"] >= 1 and 0 < ex["allgather_ms_per_round"] < 1.0
