@@ -133,6 +133,11 @@ __device__ __forceinline__ double dpp_move(double v) {
     const uint32_t hi = (uint32_t)dpp_i<CTRL, ROWS>((int)(uint32_t)(b >> 32));
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
+// The lane mask of a wave-wide predicate.  HIP's __ballot(int) compares an INTEGER against zero, so a predicate that is the
+// result of a vector compare is first materialised in a VGPR (v_cndmask 0 / 1) and compared again; the w64 builtin
+// takes the compare's own mask (two vector instructions less on a dependent chain, per use).
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ float read_lane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }

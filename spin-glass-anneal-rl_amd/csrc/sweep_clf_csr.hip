@@ -208,12 +208,12 @@ __global__ void __launch_bounds__(64 * CLFS_MAX_WAVES) sweep_clf_csr_kernel(cons
                     bool accA = liveA && uA < ptab[min(max(kA, 0), a.table_m)];
                     bool accB = liveB && uB < ptab[min(max(kB, 0), a.table_m)];
                     const bool beyondA = liveA && kA > a.table_m, beyondB = liveB && kB > a.table_m;
-                    if (__ballot(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
+                    if (ballot64(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
                         const double dA = (double)(2 * kA) * inv_sc, dB = (double)(2 * kB) * inv_sc;
                         if (beyondA) accA = !(dA > T * 104.0) && uA < expf_det((float)(-dA / T));
                         if (beyondB) accB = !(dB > T * 104.0) && uB < expf_det((float)(-dB / T));
                     }
-                    unsigned long long mA = __ballot(accA), mB = __ballot(accB);
+                    unsigned long long mA = ballot64(accA), mB = ballot64(accB);
                     p = first_of(mA, mB);
                     if (p < NONE) {
                         if (p & 1) mB &= mB - 1;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(64 * CLFS_MAX_WAVES) sweep_clf_csr_kernel(cons
                         const int4 *theirs = reinterpret_cast<const int4 *>(slots + CLFS_SLOT_INTS * lane);
                         q0 = theirs[0], q1 = theirs[1], q2 = theirs[2];
                     }
-                    const unsigned long long have = __ballot(q0.x < NONE);
+                    const unsigned long long have = ballot64(q0.x < NONE);
                     if (have == 0ull) {
                         p = NONE;
                     } else {

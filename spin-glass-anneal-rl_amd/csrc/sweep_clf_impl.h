@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
             const float pa = ptab[min(max(ka, 0), a.table_m)], pb = ptab[min(max(kb, 0), a.table_m)];
             bool accA = uA < pa, accB = uB < pb;
             const bool beyondA = liveA && ka > a.table_m, beyondB = liveB && kb > a.table_m;
-            if (__ballot(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
+            if (ballot64(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
                 const double dA = (double)(2 * ka) * inv_sc, dB = (double)(2 * kb) * inv_sc;
                 if (beyondA) accA = !(dA > T * 104.0) && uA < expf_det((float)(-dA / T));
                 if (beyondB) accB = !(dB > T * 104.0) && uB < expf_det((float)(-dB / T));
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                 if ((w + 1) * CLF_WINDOW > pos) {  // wave-uniform
                     bool fA, fB;
                     decide2(sA, uA, vA && gA >= pos, vdA, sB, uB, vB && gB >= pos, vdB, fA, fB);
-                    mA = __ballot(fA), mB = __ballot(fB);
+                    mA = ballot64(fA), mB = ballot64(fB);
                     p = first_of(mA, mB);
                 }
                 if (p < NONE) {
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(64 * CLF_MAX_WAVES) sweep_clf_kernel(const Swe
                         const int4 *theirs = reinterpret_cast<const int4 *>(slots + CLF_SLOT_INTS * lane);
                         q0 = theirs[0], q1 = theirs[1];
                     }
-                    const unsigned long long have = __ballot(q0.x < NONE);
+                    const unsigned long long have = ballot64(q0.x < NONE);
                     if (have == 0ull) {
                         p = NONE;
                     } else {

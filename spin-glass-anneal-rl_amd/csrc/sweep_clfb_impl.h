@@ -224,7 +224,7 @@ sweep_clfb_kernel(const SweepArgs a) {
         const float pa = ptab[min(max(ka, 0), a.table_m)], pb = ptab[min(max(kb, 0), a.table_m)];
         bool accA = uA < pa, accB = uB < pb;
         const bool beyondA = liveA && ka > a.table_m, beyondB = liveB && kb > a.table_m;
-        if (__ballot(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
+        if (ballot64(beyondA || beyondB)) {  // rare: large uphill moves (p == 0 past -104, sweep_common.h)
             const double dA = (double)(2 * ka) * inv_sc, dB = (double)(2 * kb) * inv_sc;
             if (beyondA) accA = !(dA > T * 104.0) && uA < expf_det((float)(-dA / T));
             if (beyondB) accB = !(dB > T * 104.0) && uB < expf_det((float)(-dB / T));
@@ -271,7 +271,7 @@ sweep_clfb_kernel(const SweepArgs a) {
         {
             bool up = false;
             for (int q = tid; q < a.table_m; q += blockDim.x) up = up || (ptab[q] < ptab[q + 1]);
-            if (__ballot(up) != 0ull && lane == 0) atomicAdd(&sums[1], 1ull);
+            if (ballot64(up) != 0ull && lane == 0) atomicAdd(&sums[1], 1ull);
         }
         __syncthreads();
         const int D = 2 * sc * a.clf_jmax;  // the most one flip moves k = s_i F_i of another site
@@ -329,7 +329,7 @@ sweep_clfb_kernel(const SweepArgs a) {
                     siA = (wa & bitA) ? -1 : 1;
                     siB = (wb & bitB) ? -1 : 1;
                     accept2(siA * fa, uA, vA && gA >= pos, gsA, siB * fb, uB, vB && gB >= pos, gsB);
-                    mA = __ballot(gsA), mB = __ballot(gsB);
+                    mA = ballot64(gsA), mB = ballot64(gsB);
                 }
                 // rank in chain order within the wave = guessed accepts of this window before the candidate
                 const int rA = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mA, 0u)) +
@@ -357,7 +357,7 @@ sweep_clfb_kernel(const SweepArgs a) {
                 const int2 ent = list[lane];
                 const int cv = slot_ok ? count[my_v] : 0;
                 const bool valid = my_j < cv;  // (my_j < S; cv = 0 beyond the last wave)
-                const unsigned long long vm = __ballot(valid);
+                const unsigned long long vm = ballot64(valid);
                 if (vm == 0ull) return true;  // the rest of the super-window is rejected
                 int L = END;
                 if (__popcll(vm) > CLFB_LIST) {
@@ -365,12 +365,12 @@ sweep_clfb_kernel(const SweepArgs a) {
                     for (int i = 0; i < CLFB_LIST; ++i) t &= t - 1ull;
                     L = __builtin_amdgcn_readlane(ent.x, (int)__builtin_ctzll(t));
                 }
-                if (__ballot(cv > S)) {
+                if (ballot64(cv > S)) {
                     const int ov = lane < W ? over[lane] : NONE;
                     for (int v = 0; v < W; ++v) L = min(L, __builtin_amdgcn_readlane(ov, v));
                 }
                 const bool inb = valid && ent.x < L;
-                const unsigned long long vmL = __ballot(inb);  // (never empty: the first accept lies before L)
+                const unsigned long long vmL = ballot64(inb);  // (never empty: the first accept lies before L)
                 const int ent_site = ent.y & 0x7fffffff;
                 const unsigned int rowoff = (unsigned int)ent_site * pitch;
                 const corr_t multl = (corr_t)(ent.y < 0 ? 2 * sc : -2 * sc);  // -2 scale s_a
@@ -403,7 +403,7 @@ sweep_clfb_kernel(const SweepArgs a) {
                 {
                     // one lane per listed accept: J[a][site] of the accepts before the candidate, summed over the wave;
                     // up to CLFB_PASS candidates of either stream per pass, all their loads in flight together
-                    unsigned long long nA = __ballot(needA), nB = __ballot(needB);
+                    unsigned long long nA = ballot64(needA), nB = ballot64(needB);
                     bool first_pass = true;
                     do {  // wave-uniform
                         int ls[2 * CLFB_PASS], hp[2 * CLFB_PASS];
@@ -419,7 +419,7 @@ sweep_clfb_kernel(const SweepArgs a) {
                             if (on[j]) {
                                 const int s_c = __builtin_amdgcn_readlane(j < CLFB_PASS ? sA : sB, ls[j]);
                                 const bool act = inb && ent.x < wbase + 2 * ls[j] + (j < CLFB_PASS ? 0 : 1);
-                                hp[j] = (int)__popcll(__ballot(act && ent_site == s_c));
+                                hp[j] = (int)__popcll(ballot64(act && ent_site == s_c));
                                 if (act) xs[j] = *reinterpret_cast<const JT *>(Jbytes + (unsigned long long)(unsigned int)s_c * sizeof(JT) + rowoff);
                             }
                         }
@@ -452,8 +452,8 @@ sweep_clfb_kernel(const SweepArgs a) {
                     // (a candidate that did not have to look keeps the guess: a rejection)
                     accept2(k2A, uA, needA, acA, k2B, uB, needB, acB);
                     // an accept behind an accept of its own site ends the batch too: the list carries its old spin
-                    bA = __ballot(inA && (acA != gsA || (acA && hA != 0)));
-                    bB = __ballot(inB && (acB != gsB || (acB && hB != 0)));
+                    bA = ballot64(inA && (acA != gsA || (acA && hA != 0)));
+                    bB = ballot64(inB && (acB != gsB || (acB && hB != 0)));
                     fa = k2A, fb = k2B, siA = si2A, siB = si2B;  // (from here on: the checked move and spin)
                 }
                 {
@@ -471,10 +471,10 @@ sweep_clfb_kernel(const SweepArgs a) {
                 CLFB_ADD(15, CLFB_TICK() - tick1a);
                 clfb_barrier();  // (A2) every wave has checked its window
                 [[maybe_unused]] const long long tick2 = CLFB_TICK();
-                CLFB_ADD(7, tick2 - tick1), CLFB_ADD(4, __popcll(vmL)), CLFB_ADD(5, __popcll(__ballot(needA)) + __popcll(__ballot(needB)));
+                CLFB_ADD(7, tick2 - tick1), CLFB_ADD(4, __popcll(vmL)), CLFB_ADD(5, __popcll(ballot64(needA)) + __popcll(ballot64(needB)));
                 int4 ck = make_int4(NONE, 0, 0, 1);
                 if (lane < W) ck = check[lane];
-                const unsigned long long have = __ballot(ck.x < NONE);
+                const unsigned long long have = ballot64(ck.x < NONE);
                 int Q = L, qpos = NONE, xacc = 0, xsite = 0, xsi = 1;
                 if (have) {  // (windows are in chain order: the first wave that reports holds the earliest position)
                     const int win = (int)__builtin_ctzll(have);
@@ -494,7 +494,7 @@ sweep_clfb_kernel(const SweepArgs a) {
                     if (gsB && dupB) atomicAnd(&accb[sB >> 5], ~bitB);
                 }
                 const bool mine_row = valid && ent.x < Q;
-                unsigned long long rows = __ballot(mine_row);  // >= 1 bit: the first accept always stands
+                unsigned long long rows = ballot64(mine_row);  // >= 1 bit: the first accept always stands
                 const int nrows = (int)__popcll(rows) + (xacc ? 1 : 0);
                 if (w == 0) {
                     if (mine_row) atomicXor(&bits[ent_site >> 5], 1u << (ent_site & 31));

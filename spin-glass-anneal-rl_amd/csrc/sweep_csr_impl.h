@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(64 * (WIDE ? CSR_MAX_WIDE : CSR_WAVES_PER_BLOC
             if (flipA) {
                 E += dEA;
                 ++nacc;
-                unsigned long long mm = __ballot(inB && c.hB.col[0] == sA);
+                unsigned long long mm = ballot64(inB && c.hB.col[0] == sA);
                 while (mm) {  // (duplicate entries add up; usually no entry at all)
                     dotB -= 2.0f * read_lane(c.hB.val[0], (int)__builtin_ctzll(mm)) * (float)siA;
                     mm &= mm - 1;

@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_par_kernel(const
             q1 = *reinterpret_cast<const int2 *>(theirs + 4);
         }
         turn ^= 1;
-        const unsigned long long acc = __ballot(q0.x != 0);
+        const unsigned long long acc = ballot64(q0.x != 0);
         // does an accepted update matter to a later one of the step?
         unsigned long long hit = 0;
         unsigned long long rest = acc;
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(64 * TSP_MAX_WAVES) sweep_tsp_par_kernel(const
             int dp = q0.z - pq;
             dp = dp < 0 ? -dp : dp;
             const bool near = dp <= 1 || dp == n - 1;  // p' in {p - 1, p, p + 1} (mod n)
-            hit |= __ballot(lane > q && lane < W && q0.w != 0 && (q0.y == cq || near));
+            hit |= ballot64(lane > q && lane < W && q0.w != 0 && (q0.y == cq || near));
         }
         if (hit == 0ull) {
             if (flip) apply(sl, si);
